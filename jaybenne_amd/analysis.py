@@ -1,0 +1,43 @@
+"""Acceptance metric of the reference's regression harness, restated.
+
+``ur_solution`` is the analytic diffusion profile of reference tst/stepdiff.py:33-46 (and
+tst/stepdiff_smr.py:35-48); ``analytic_errors`` reproduces the loop of
+tst/regression_test.py:361-406 over every interior cell of every block.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict
+
+import numpy as np
+from scipy.special import erf
+
+TAU = 1.000692e-7
+UR0 = 7.5646e5
+SHIFT = 0.5
+
+
+def ur_solution(t, x, y=0.0, z=0.0):
+    s = 2.0 * np.sqrt(t / TAU)
+    return UR0 / 2.0 * (erf(((x + SHIFT) + 0.5) / s) - erf(((x + SHIFT) - 0.5) / s))
+
+
+def analytic_errors(mesh, tally: np.ndarray, t: float,
+                    solution: Callable = ur_solution) -> Dict[str, float]:
+    """tally: [nblocks, nk, nj, ni] (ghosts included).  Returns the five numbers the reference
+    prints; ``mean_frac_error_weighted`` is its default pass criterion."""
+    sl = mesh.interior()
+    val = np.asarray(tally)[sl]
+    sol = np.empty_like(val)
+    for b in range(mesh.nblocks):
+        xc = mesh.cell_centers(b, 0)[sl[3]]
+        sol[b] = solution(t, xc)[None, None, :]
+    err = np.abs(sol - val)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        frac = err / np.abs((sol + val) / 2.0)
+    return {
+        "mean_error": float(err.mean()),
+        "max_error": float(err.max()),
+        "mean_frac_error": float(frac.mean()),
+        "max_frac_error": float(frac.max()),
+        "mean_frac_error_weighted": float((frac * sol).sum() / sol.sum()),
+    }

@@ -1,0 +1,132 @@
+"""Host material package: the part of the reference's ``mcblock`` application that the history
+loop needs around it (reference src/mcblock/mcblock.cpp).
+
+* ``Initialize``            parameters, EOS / opacity / scattering models   mcblock.cpp:37-150
+* ``ProblemGenerator``      rho = rho0, sie = cv T0, stepdiff step at x >= 0  mcblock.cpp:155-203
+* ``PostInitialization``    u = rho sie                                       mcblock.cpp:237-262
+* ``UpdateDerived``         sie = u / rho over the entire block               mcblock.cpp:208-232
+
+Everything here is setup-time host code on numpy arrays; the per-cycle work is in
+``jaybenne_amd.jaybenne`` (HIP).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict
+
+import numpy as np
+
+from . import constants
+from .deck import ParameterInput
+from .mesh import Mesh
+
+EOS_IDEAL_GAS = 0
+OPAC_GRAY = 0
+OPAC_EPBREMSS = 1
+SCAT_GRAY = 0
+SCAT_THOMSON = 1
+
+
+@dataclass
+class EOS:
+    """singularity::IdealGas(gm1, cv): T = sie / cv (reference mcblock.cpp:78-82)."""
+    gm1: float
+    cv: float
+    model: int = EOS_IDEAL_GAS
+
+    def TemperatureFromDensityInternalEnergy(self, rho, sie):
+        return np.maximum(sie / self.cv, 0.0)
+
+    def SpecificHeatFromDensityInternalEnergy(self, rho, sie):
+        return self.cv
+
+
+@dataclass
+class Opacity:
+    """singularity::photons::Gray(kappa) in code units (reference mcblock.cpp:95-121)."""
+    kappa: float
+    model: int = OPAC_GRAY
+    c: float = constants.SPEED_OF_LIGHT
+    sb: float = constants.STEFAN_BOLTZMANN
+
+    def GetRuntimePhysicalConstants(self):
+        return self
+
+
+@dataclass
+class Scattering:
+    """singularity::photons::GrayS(kappa_s, apm) (reference mcblock.cpp:126-145)."""
+    kappa_s: float
+    apm: float
+    model: int = SCAT_GRAY
+
+
+@dataclass
+class McblockPackage:
+    problem_id: str
+    initial_temperature: float
+    initial_density: float
+    initial_radiation: str
+    eos: EOS
+    opacity: Opacity
+    scattering: Scattering
+
+
+def Initialize(pin: ParameterInput) -> McblockPackage:
+    """reference mcblock.cpp:37-150"""
+    if pin.GetString("parthenon/time", "integrator") != "rk1":
+        raise ValueError("McBlock driver only supports first order time integration")
+    problem_id = pin.GetString("parthenon/job", "problem_id")
+    t0 = pin.GetReal("mcblock", "initial_temperature")
+    rho0 = pin.GetReal("mcblock", "initial_density")
+    initial_radiation = pin.GetString("mcblock", "initial_radiation")
+    if initial_radiation not in ("none", "thermal"):
+        raise ValueError("Only none or thermal initial radiation supported!")
+    gamma = pin.GetOrAddReal("mcblock", "gamma", 1.66666666667)
+    cv = pin.GetOrAddReal("mcblock", "cv", 1.0 / (gamma - 1.0))
+    eos = EOS(gamma - 1.0, cv)
+    for key in ("time_scale", "mass_scale", "length_scale", "temperature_scale"):
+        if pin.GetOrAddReal("mcblock", key, 1.0) != 1.0:
+            raise NotImplementedError("non-CGS unit scales are not supported")
+    name = pin.GetString("mcblock", "opacity_model")
+    if name == "none":
+        opacity = Opacity(0.0)
+    elif name == "constant":
+        opacity = Opacity(pin.GetReal("mcblock", "opacity_constant_value"))
+    elif name == "ep_bremss":
+        raise NotImplementedError("EPBremss opacity is not built (no stepdiff deck uses it)")
+    else:
+        raise ValueError("Only none or constant opacity models supported!")
+    apm = pin.GetOrAddReal("mcblock", "apm", 1.0)
+    sname = pin.GetOrAddString("mcblock", "scattering_model", "none")
+    if sname == "none":
+        scattering = Scattering(0.0, apm)
+    elif sname == "constant":
+        scattering = Scattering(pin.GetReal("mcblock", "scattering_constant_value"), apm)
+    else:
+        raise ValueError("Only none or constant scattering models supported!")
+    return McblockPackage(problem_id, t0, rho0, initial_radiation, eos, opacity, scattering)
+
+
+def ProblemGenerator(mesh: Mesh, pkg: McblockPackage) -> Dict[str, np.ndarray]:
+    """Initial material state on the host: returns rho, sie, u with ghost zones filled
+    (reference mcblock.cpp:155-203, 237-262 followed by the ghost exchange + FillDerived that
+    Parthenon runs at the end of initialisation)."""
+    rho = mesh.new_field(pkg.initial_density)
+    cv = pkg.eos.SpecificHeatFromDensityInternalEnergy(pkg.initial_density, 1.0)
+    sie = mesh.new_field(cv * pkg.initial_temperature)
+    if pkg.problem_id == "stepdiff":
+        ttlow = 1.0e-5 * pkg.initial_temperature
+        for b in range(mesh.nblocks):
+            x1v = mesh.cell_centers(b, 0)
+            sie[b][:, :, x1v >= 0.0] = cv * ttlow
+    u = rho * sie                       # PostInitialization
+    mesh.fill_ghosts(rho)
+    mesh.fill_ghosts(u)
+    sie = UpdateDerived(rho, u)
+    return {"rho": rho, "sie": sie, "u": u}
+
+
+def UpdateDerived(rho: np.ndarray, u: np.ndarray) -> np.ndarray:
+    """sie = u / rho over the entire block incl. ghosts (reference mcblock.cpp:208-232)."""
+    return u / rho

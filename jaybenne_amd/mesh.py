@@ -1,0 +1,330 @@
+"""Block-structured mesh with static refinement: the part of Parthenon's ``Mesh`` the history
+loop depends on (block list, per-block geometry, destination-block lookup, neighbour levels,
+ghost-zone fill, block -> rank partition).
+
+Parthenon itself is an empty submodule in the reference tree, so its semantics are restated from
+the call sites:
+
+* interior index range ``ng .. ng+nx-1`` in active dimensions, a single index ``0`` otherwise
+  (reference transport.cpp:57-59, sourcing.cpp:59-66);
+* ``<parthenon/mesh>``, ``<parthenon/meshblock>``, ``<parthenon/static_refinementN>`` and
+  ``<parthenon/swarm>`` deck blocks (reference inputs/stepdiff_smr.in:16-59);
+* a particle that leaves its block is handed to the leaf block that contains it
+  (``GetNeighborBlockIndex`` + ``Swarm::Send``, reference transport.cpp:149-155,
+  jaybenne.cpp:26-61).  Here that lookup is a table over blocks of the finest level
+  (``leaf_map``) instead of Parthenon's per-block 4x4x4 neighbour table: same destination,
+  one gather.
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+BC_PERIODIC, BC_REFLECT, BC_OUTFLOW = 0, 1, 2
+_SWARM_BC = {"periodic": BC_PERIODIC, "jaybenne_reflecting": BC_REFLECT, "outflow": BC_OUTFLOW}
+
+
+@dataclass
+class Refinement:
+    level: int
+    lo: Tuple[float, float, float]
+    hi: Tuple[float, float, float]
+
+
+def _morton(l: Sequence[int], bits: int) -> int:
+    key = 0
+    for b in range(bits):
+        for d in range(3):
+            key |= ((int(l[d]) >> b) & 1) << (3 * b + d)
+    return key
+
+
+class Mesh:
+    """Leaf blocks in Z-order with everything the kernels need as flat numpy arrays."""
+
+    def __init__(self, ndim: int, mesh_nx: Sequence[int], block_nx: Sequence[int],
+                 gmin: Sequence[float], gmax: Sequence[float], ng: int = 2,
+                 mesh_bc: Sequence[int] = (BC_OUTFLOW, BC_OUTFLOW, BC_PERIODIC, BC_PERIODIC,
+                                           BC_PERIODIC, BC_PERIODIC),
+                 swarm_bc: Sequence[int] = (BC_REFLECT, BC_REFLECT, BC_PERIODIC, BC_PERIODIC,
+                                            BC_PERIODIC, BC_PERIODIC),
+                 refinements: Sequence[Refinement] = ()):
+        self.ndim = int(ndim)
+        self.mesh_nx = [int(v) for v in mesh_nx]
+        self.nx = [int(v) for v in block_nx]
+        for d in range(3):
+            if d >= self.ndim and (self.mesh_nx[d] != 1 or self.nx[d] != 1):
+                raise ValueError("inactive dimensions must have nx = 1")
+            if self.mesh_nx[d] % self.nx[d] != 0:
+                raise ValueError("mesh size must be a multiple of the block size")
+        if ng < 1:
+            raise ValueError("at least one ghost layer is needed (face fields share the cell layout)")
+        self.ng = int(ng)
+        self.gmin = np.asarray(gmin, dtype=np.float64).copy()
+        self.gmax = np.asarray(gmax, dtype=np.float64).copy()
+        self.mesh_bc = [int(v) for v in mesh_bc]
+        self.swarm_bc = [int(v) for v in swarm_bc]
+        self.nroot = [self.mesh_nx[d] // self.nx[d] for d in range(3)]
+        self.refinements = list(refinements)
+        self._build_tree()
+        self._build_arrays()
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_deck(cls, pin) -> "Mesh":
+        mb = "parthenon/mesh"
+        mesh_nx = [pin.GetInteger(mb, f"nx{d}") for d in (1, 2, 3)]
+        ndim = 1 + int(mesh_nx[1] > 1) + int(mesh_nx[2] > 1)
+        if mesh_nx[2] > 1 and mesh_nx[1] == 1:
+            raise ValueError("nx3 > 1 requires nx2 > 1")
+        gmin = [pin.GetReal(mb, f"x{d}min") for d in (1, 2, 3)]
+        gmax = [pin.GetReal(mb, f"x{d}max") for d in (1, 2, 3)]
+        block_nx = [pin.GetOrAddInteger("parthenon/meshblock", f"nx{d}", mesh_nx[d - 1])
+                    for d in (1, 2, 3)]
+        ng = pin.GetOrAddInteger(mb, "nghost", 2)
+
+        def bcs(block, default):
+            out = []
+            for d in (1, 2, 3):
+                for side in ("i", "o"):
+                    name = pin.GetOrAddString(block, f"{side}x{d}_bc", default)
+                    if name not in _SWARM_BC:
+                        raise ValueError(f"unsupported boundary condition '{name}' in <{block}>")
+                    out.append(_SWARM_BC[name])
+            return out
+
+        mesh_bc = bcs(mb, "periodic")
+        # a reflecting *mesh* boundary is not used by any deck; treat non-periodic as outflow
+        mesh_bc = [BC_PERIODIC if b == BC_PERIODIC else BC_OUTFLOW for b in mesh_bc]
+        swarm_bc = bcs("parthenon/swarm", "periodic")
+        refs = []
+        if pin.GetOrAddString(mb, "refinement", "none") == "static":
+            n = 1
+            while pin.DoesBlockExist(f"parthenon/static_refinement{n}"):
+                rb = f"parthenon/static_refinement{n}"
+                lo = [pin.GetOrAddReal(rb, f"x{d}min", gmin[d - 1]) for d in (1, 2, 3)]
+                hi = [pin.GetOrAddReal(rb, f"x{d}max", gmax[d - 1]) for d in (1, 2, 3)]
+                refs.append(Refinement(pin.GetInteger(rb, "level"), tuple(lo), tuple(hi)))
+                n += 1
+        return cls(ndim, mesh_nx, block_nx, gmin, gmax, ng, mesh_bc, swarm_bc, refs)
+
+    def _block_bounds(self, level: int, lx: Sequence[int]):
+        lo = np.empty(3)
+        hi = np.empty(3)
+        for d in range(3):
+            nb = self.nroot[d] * (1 << level if d < self.ndim else 1)
+            ext = self.gmax[d] - self.gmin[d]
+            lo[d] = self.gmin[d] + ext * (lx[d] / nb)
+            hi[d] = self.gmin[d] + ext * ((lx[d] + 1) / nb)
+        return lo, hi
+
+    def _children(self, level: int, lx):
+        rng = [(0, 1) if d < self.ndim else (0,) for d in range(3)]
+        return [(level + 1, tuple(2 * lx[d] + o[d] if d < self.ndim else lx[d] for d in range(3)))
+                for o in itertools.product(*rng)]
+
+    def _build_tree(self) -> None:
+        leaves = {(0, (i, j, k)) for k in range(self.nroot[2]) for j in range(self.nroot[1])
+                  for i in range(self.nroot[0])}
+        max_level = max([r.level for r in self.refinements], default=0)
+        # refine every leaf that overlaps (open overlap) a region of higher level
+        for target in range(1, max_level + 1):
+            for (lev, lx) in sorted(leaves):
+                if lev != target - 1:
+                    continue
+                lo, hi = self._block_bounds(lev, lx)
+                for r in self.refinements:
+                    if r.level < target:
+                        continue
+                    if all(lo[d] < r.hi[d] and hi[d] > r.lo[d] for d in range(self.ndim)):
+                        leaves.remove((lev, lx))
+                        leaves.update(self._children(lev, lx))
+                        break
+        # 2:1 balance across faces, edges and corners
+        changed = True
+        while changed:
+            changed = False
+            max_level = max(l for l, _ in leaves)
+            lmap = self._leaf_map_from(leaves, max_level)
+            for (lev, lx) in sorted(leaves):
+                if lev < 2:
+                    continue
+                scale = 1 << (max_level - lev)
+                offs = [(-1, 0, 1) if d < self.ndim else (0,) for d in range(3)]
+                for o in itertools.product(*offs):
+                    # same-level logical location of the neighbour region, mapped to the
+                    # finest-level block grid of the leaf map
+                    q = []
+                    ok = True
+                    for d in range(3):
+                        n = lmap["shape"][d]
+                        c = (lx[d] + o[d]) * scale if d < self.ndim else 0
+                        if c < 0 or c >= n:
+                            if self.mesh_bc[2 * d] == BC_PERIODIC:
+                                c %= n
+                            else:
+                                ok = False
+                        q.append(c)
+                    if not ok:
+                        continue
+                    nb = lmap["leaf"][q[2]][q[1]][q[0]]
+                    if nb[0] < lev - 1 and nb in leaves:
+                        leaves.remove(nb)
+                        leaves.update(self._children(*nb))
+                        changed = True
+                if changed:
+                    break
+        self.max_level = max(l for l, _ in leaves)
+        bits = max(1, int(np.ceil(np.log2(max(self.nroot) * (1 << self.max_level) + 1))))
+        self.leaves: List[Tuple[int, Tuple[int, int, int]]] = sorted(
+            leaves,
+            key=lambda b: _morton([b[1][d] << (self.max_level - b[0]) if d < self.ndim else 0
+                                   for d in range(3)], bits))
+
+    def _leaf_map_from(self, leaves, max_level):
+        shape = [self.nroot[d] * ((1 << max_level) if d < self.ndim else 1) for d in range(3)]
+        leaf = [[[None] * shape[0] for _ in range(shape[1])] for _ in range(shape[2])]
+        for (lev, lx) in leaves:
+            s = 1 << (max_level - lev)
+            r = [range(lx[d] * s, (lx[d] + 1) * s) if d < self.ndim else range(1) for d in range(3)]
+            for k in r[2]:
+                for j in r[1]:
+                    for i in r[0]:
+                        leaf[k][j][i] = (lev, lx)
+        return {"shape": shape, "leaf": leaf}
+
+    def _build_arrays(self) -> None:
+        nb = len(self.leaves)
+        self.nblocks = nb
+        self.blk_level = np.array([l for l, _ in self.leaves], dtype=np.int32)
+        self.blk_lloc = np.array([lx for _, lx in self.leaves], dtype=np.int32)
+        self.blk_xmin = np.empty((nb, 3))
+        self.blk_xmax = np.empty((nb, 3))
+        for b, (lev, lx) in enumerate(self.leaves):
+            self.blk_xmin[b], self.blk_xmax[b] = self._block_bounds(lev, lx)
+        self.blk_dx = (self.blk_xmax - self.blk_xmin) / np.asarray(self.nx, dtype=np.float64)
+        self.nleaf = [self.nroot[d] * ((1 << self.max_level) if d < self.ndim else 1)
+                      for d in range(3)]
+        index = {blk: b for b, blk in enumerate(self.leaves)}
+        lm = self._leaf_map_from(set(self.leaves), self.max_level)["leaf"]
+        self.leaf_map = np.array([[[index[lm[k][j][i]] for i in range(self.nleaf[0])]
+                                   for j in range(self.nleaf[1])] for k in range(self.nleaf[2])],
+                                 dtype=np.int32)
+        # index space
+        self.is_ = [self.ng if d < self.ndim else 0 for d in range(3)]
+        self.ntot_dim = [self.nx[d] + 2 * self.is_[d] for d in range(3)]   # (ni, nj, nk)
+        self.ntot = int(np.prod(self.ntot_dim))
+        self.ncell = int(np.prod(self.nx))
+        self.field_shape = (nb, self.ntot_dim[2], self.ntot_dim[1], self.ntot_dim[0])
+        # neighbour levels across the six faces (own level at physical boundaries)
+        self.blk_nbr_lev = np.empty((nb, 6), dtype=np.int32)
+        fine = (self.gmax - self.gmin) / np.asarray(self.nleaf, dtype=np.float64)
+        for b in range(nb):
+            ctr = 0.5 * (self.blk_xmin[b] + self.blk_xmax[b])
+            for d in range(3):
+                for side in (0, 1):
+                    if d >= self.ndim:
+                        self.blk_nbr_lev[b, 2 * d + side] = self.blk_level[b]
+                        continue
+                    p = ctr + 0.25 * fine * np.array([dd < self.ndim for dd in range(3)])
+                    p[d] = (self.blk_xmin[b, d] - 0.25 * fine[d]) if side == 0 else \
+                        (self.blk_xmax[b, d] + 0.25 * fine[d])
+                    if p[d] < self.gmin[d] or p[d] > self.gmax[d]:
+                        if self.mesh_bc[2 * d + side] != BC_PERIODIC:
+                            self.blk_nbr_lev[b, 2 * d + side] = self.blk_level[b]
+                            continue
+                        p[d] += (self.gmax[d] - self.gmin[d]) * (1 if side == 0 else -1)
+                    self.blk_nbr_lev[b, 2 * d + side] = self.blk_level[self.find_block(p[None, :])[0]]
+        self.owner = np.zeros(nb, dtype=np.int32)
+
+    # ------------------------------------------------------------------ geometry helpers
+    def find_block(self, pts: np.ndarray) -> np.ndarray:
+        """Leaf block containing each point (points must lie inside the domain)."""
+        q = []
+        for d in range(3):
+            ln = (self.gmax[d] - self.gmin[d]) / self.nleaf[d]
+            q.append(np.clip(np.floor((pts[:, d] - self.gmin[d]) / ln).astype(np.int64), 0,
+                             self.nleaf[d] - 1))
+        return self.leaf_map[q[2], q[1], q[0]]
+
+    def cell_centers(self, b: int, d: int) -> np.ndarray:
+        """Xc(idx) for every index (ghosts included) of dimension d of block b."""
+        dx = self.blk_dx[b, d]
+        x0 = self.blk_xmin[b, d] - self.is_[d] * dx
+        return x0 + (np.arange(self.ntot_dim[d]) + 0.5) * dx
+
+    def interior(self) -> Tuple[slice, slice, slice, slice]:
+        s = [slice(self.is_[d], self.is_[d] + self.nx[d]) for d in range(3)]
+        return (slice(None), s[2], s[1], s[0])
+
+    def cell_volume(self, b: int) -> float:
+        return float(self.blk_dx[b, 0] * self.blk_dx[b, 1] * self.blk_dx[b, 2])
+
+    def new_field(self, fill: float = 0.0) -> np.ndarray:
+        return np.full(self.field_shape, fill, dtype=np.float64)
+
+    # ------------------------------------------------------------------ ghost zones
+    def fill_ghosts(self, f: np.ndarray) -> None:
+        """Fill ghost cells of a cell-centred field from the leaf that owns each ghost's
+        location: copy (same level), volume average (finer neighbour), injection (coarser
+        neighbour); periodic wrap or nearest-interior copy (outflow) at the domain boundary.
+        This stands in for Parthenon's ``AddBoundaryExchangeTasks`` on ``FillGhost`` fields
+        (reference mcblock_driver.cpp:68, mcblock.cpp:68-71).  Parthenon prolongates coarse
+        data with limited linear interpolation; injection differs from it only where the
+        field varies inside a coarse cell's neighbourhood."""
+        src = f.copy()
+        offs = list(itertools.product(*[(-0.25, 0.25) if d < self.ndim else (0.0,)
+                                        for d in range(3)]))
+        for b in range(self.nblocks):
+            xs = [self.cell_centers(b, d) for d in range(3)]
+            K, J, I = np.meshgrid(np.arange(self.ntot_dim[2]), np.arange(self.ntot_dim[1]),
+                                  np.arange(self.ntot_dim[0]), indexing="ij")
+            ghost = np.zeros(K.shape, dtype=bool)
+            for d, idx in ((0, I), (1, J), (2, K)):
+                if d < self.ndim:
+                    ghost |= (idx < self.is_[d]) | (idx >= self.is_[d] + self.nx[d])
+            if not ghost.any():
+                continue
+            kk, jj, ii = K[ghost], J[ghost], I[ghost]
+            base = np.stack([xs[0][ii], xs[1][jj], xs[2][kk]], axis=1)
+            acc = np.zeros(len(ii))
+            for o in offs:
+                p = base + np.asarray(o) * self.blk_dx[b]
+                for d in range(self.ndim):
+                    ext = self.gmax[d] - self.gmin[d]
+                    if self.mesh_bc[2 * d] == BC_PERIODIC:
+                        p[:, d] = np.where(p[:, d] < self.gmin[d], p[:, d] + ext, p[:, d])
+                    else:
+                        p[:, d] = np.maximum(p[:, d], self.gmin[d] + 0.25 * self.blk_dx[b, d])
+                    if self.mesh_bc[2 * d + 1] == BC_PERIODIC:
+                        p[:, d] = np.where(p[:, d] > self.gmax[d], p[:, d] - ext, p[:, d])
+                    else:
+                        p[:, d] = np.minimum(p[:, d], self.gmax[d] - 0.25 * self.blk_dx[b, d])
+                nbk = self.find_block(p)
+                cidx = []
+                for d in range(3):
+                    if d < self.ndim:
+                        c = np.floor((p[:, d] - self.blk_xmin[nbk, d]) / self.blk_dx[nbk, d])
+                        c = np.clip(c.astype(np.int64), 0, self.nx[d] - 1) + self.is_[d]
+                    else:
+                        c = np.zeros(len(ii), dtype=np.int64)
+                    cidx.append(c)
+                acc += src[nbk, cidx[2], cidx[1], cidx[0]]
+            f[b][ghost] = acc / len(offs)
+
+    # ------------------------------------------------------------------ partition
+    def partition(self, nranks: int) -> np.ndarray:
+        """Contiguous runs of the Z-ordered block list per rank (Parthenon's default load
+        balance with unit cost per block).  Returns ``owner[b]``."""
+        nb = self.nblocks
+        if nranks > nb:
+            raise ValueError(f"cannot spread {nb} blocks over {nranks} ranks")
+        bounds = [(r * nb) // nranks for r in range(nranks + 1)]
+        owner = np.empty(nb, dtype=np.int32)
+        for r in range(nranks):
+            owner[bounds[r]:bounds[r + 1]] = r
+        self.owner = owner
+        return owner
