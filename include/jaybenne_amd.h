@@ -1,0 +1,265 @@
+/* jaybenne_amd.h -- C ABI of the MI355X-native Implicit Monte Carlo history loop.
+ *
+ * This is the drop-in boundary for the hot path of lanl/jaybenne: one entry point per task the
+ * reference package exposes to its host application (reference src/jaybenne/jaybenne.hpp:48-78),
+ * over plain pointers and sizes.  The host framework owns every field and particle array (as
+ * Parthenon does for the reference); the library borrows DEVICE pointers per call and owns only
+ * its parameters, small lookup tables and scratch.  Nothing here throws; every function returns
+ * a jb_status and jb_last_error() describes the most recent failure on the calling thread.
+ *
+ * Threading: calls on one jb_context are not re-entrant (the reference's tasks keep
+ * function-local static pack descriptors, transport.cpp:44-52, and require one partition per
+ * rank, jaybenne.cpp:92-95).  Work is enqueued on the context's HIP stream (jb_set_stream);
+ * functions that return counts to the host synchronise that stream, the others do not.
+ *
+ * Index conventions (Parthenon's): a block's cell arrays are [nk][nj][ni]
+ * with i fastest, ni = nx[0] + 2 ng etc. in active dimensions and a single index in inactive
+ * ones; interior cells are ng .. ng+nx-1.  Face field F_d shares the cell layout: face i is
+ * the lower-x_d face of cell i (reference transport_ddmc.cpp:150-159), so ng >= 1 is required.
+ */
+#ifndef JAYBENNE_AMD_H_
+#define JAYBENNE_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* TaskStatus of the reference tasks (jaybenne.cpp:34,55-56; transport.cpp:211-215) + errors */
+typedef enum jb_status {
+  JB_COMPLETE = 0,
+  JB_ITERATE = 1,
+  JB_INCOMPLETE = 2,
+  JB_ERR_INVALID = -1,   /* PARTHENON_REQUIRE / PARTHENON_FAIL conditions of the reference */
+  JB_ERR_HIP = -2,
+  JB_ERR_CAPACITY = -3,
+  JB_ERR_UNSUPPORTED = -4
+} jb_status;
+
+enum { JB_BC_PERIODIC = 0, JB_BC_REFLECT = 1, JB_BC_OUTFLOW = 2 }; /* <parthenon/swarm> i/ox?_bc */
+enum { JB_SOURCE_THERMAL = 0, JB_SOURCE_EMISSION = 1 };  /* SourceType, jaybenne.hpp:56 */
+enum { JB_STRATEGY_UNIFORM = 0, JB_STRATEGY_ENERGY = 1 }; /* SourceStrategy, jaybenne.hpp:55 */
+enum { JB_EOS_IDEAL_GAS = 0 };
+enum { JB_OPAC_GRAY = 0, JB_OPAC_EPBREMSS = 1 };
+enum { JB_SCAT_GRAY = 0, JB_SCAT_THOMSON = 1 };
+/* particle status written by the transport tasks */
+enum {
+  JB_ST_ACTIVE = 0,   /* resident on this device (in flight before, at census after transport) */
+  JB_ST_ABSORBED = 1, /* MarkParticleForRemoval after an absorption (transport.cpp:157-163) */
+  JB_ST_ESCAPED = 2,  /* left through an outflow swarm boundary */
+  JB_ST_OUTGOING = 3  /* destination block lives on another rank; blk holds its GLOBAL id */
+};
+
+/* <jaybenne> input block, keys and defaults of reference jaybenne.cpp:163-223 */
+typedef struct jb_params {
+  int64_t num_particles; /* required */
+  double dt;             /* default DBL_MAX */
+  double min_swarm_occupancy;
+  double numin, numax;   /* parsed, unused */
+  double tau_ddmc;       /* default 5.0 */
+  int32_t unique_rank_seeds;
+  int32_t seed;          /* default 123 */
+  int32_t max_transport_iterations; /* default 10000 */
+  int32_t use_ddmc;
+  int32_t source_strategy;
+  int32_t do_emission;
+  int32_t do_feedback;
+  int32_t rank;          /* Globals::my_rank, used with unique_rank_seeds */
+} jb_params;
+
+/* the host's EOS / opacity / scattering objects (reference jaybenne.hpp:50-52,
+ * jaybenne_config.hpp.in:19-26; mcblock.cpp:78-145), as tagged POD evaluated device-side */
+typedef struct jb_eos {
+  int32_t model, pad;
+  double gm1, cv;        /* IdealGas(gm1, cv): T = sie / cv */
+} jb_eos;
+typedef struct jb_opacity {
+  int32_t model, pad;
+  double kappa;          /* Gray: sigma_a = rho kappa, j = sigma_a 4 sb T^4 */
+  double c, sb;          /* GetRuntimePhysicalConstants(): speed of light, Stefan-Boltzmann */
+} jb_opacity;
+typedef struct jb_scattering {
+  int32_t model, pad;
+  double kappa_s, apm;   /* GrayS: sigma_s = (rho / apm) kappa_s */
+} jb_scattering;
+
+/* The slice of the mesh this rank owns (the MeshData / SparsePack role).  All pointers in this
+ * struct are HOST pointers; rho..P3 are host arrays of per-block DEVICE pointers. */
+typedef struct jb_mesh_view {
+  int32_t ndim, ng;
+  int32_t nblocks;        /* local blocks */
+  int32_t nblocks_total;  /* Mesh::nbtotal */
+  int32_t nx[3];          /* interior cells per block */
+  int32_t nleaf[3];       /* extent of leaf_map (blocks of the finest level) */
+  int32_t bc[6];          /* swarm boundary per face: ix1, ox1, ix2, ox2, ix3, ox3 */
+  int32_t rank, pad;
+  double gmin[3], gmax[3];
+  const int32_t *leaf_map;     /* [nleaf2][nleaf1][nleaf0] -> global block id */
+  const int32_t *owner;        /* [nblocks_total] rank that owns each global block */
+  const int32_t *local_index;  /* [nblocks_total] index in this rank's block list, or -1 */
+  const int32_t *gid;          /* [nblocks] global id of each local block */
+  const double *blk_xmin;      /* [nblocks][3] */
+  const double *blk_xmax;      /* [nblocks][3] */
+  const double *blk_dx;        /* [nblocks][3] (inactive dimensions: full extent) */
+  const int32_t *blk_level;    /* [nblocks] */
+  const int32_t *blk_nbr_lev;  /* [nblocks][6] neighbour level per face; own level at a
+                                  physical boundary (jaybenne.cpp:341-351) */
+  /* HOST_DENSITY, HOST_SPECIFIC_INTERNAL_ENERGY, HOST_UPDATE_ENERGY (jaybenne_config.hpp.in:28-30) */
+  double *const *rho, *const *sie, *const *u;
+  /* field.jaybenne.* (jaybenne_variables.hpp:35-40) */
+  double *const *fleck, *const *tally, *const *edelta, *const *src_ew, *const *src_num;
+  double *const *P1, *const *P2, *const *P3; /* ddmc_face_prob F1/F2/F3; may be NULL w/o DDMC */
+} jb_mesh_view;
+
+/* The photons swarm (jaybenne.cpp:236-245): structure of arrays, DEVICE pointers, particles
+ * 0..n-1 valid.  id/ctr carry each particle's random stream (see csrc/jb_rng.hpp). */
+typedef struct jb_swarm_view {
+  int64_t n, capacity;
+  double *x, *y, *z;      /* swarm_position::x,y,z */
+  double *vx, *vy, *vz;   /* particle.photons.v[3] */
+  double *t, *w, *e;      /* time, weight, energy */
+  int32_t *ip, *jp, *kp;  /* particle.photons.ijk[3] */
+  int32_t *blk;           /* local block index (global id when status == JB_ST_OUTGOING) */
+  int32_t *status;
+  uint64_t *id;
+  uint32_t *ctr;
+} jb_swarm_view;
+
+typedef struct jb_transport_stats {
+  int64_t n_census, n_absorbed, n_escaped, n_outgoing;
+  int64_t n_events;  /* passes through the while loop of transport.cpp:98-171 */
+} jb_transport_stats;
+
+typedef struct jb_context jb_context;
+typedef struct jb_mesh jb_mesh;
+
+const char *jb_last_error(void);
+const char *jb_version(void);
+
+/* jaybenne::Initialize(pin, opacity, scattering, eos) -- jaybenne.hpp:50-52, jaybenne.cpp:158-266 */
+jb_status jb_initialize(const jb_params *params, const jb_eos *eos, const jb_opacity *opacity,
+                        const jb_scattering *scattering, int device, jb_context **ctx);
+jb_status jb_finalize(jb_context *ctx);
+jb_status jb_set_stream(jb_context *ctx, void *hip_stream);
+jb_status jb_synchronize(jb_context *ctx);
+/* Param<int>("seed"): seed + rank when unique_rank_seeds (jaybenne.cpp:187-190).  The random
+ * streams are keyed with the UNADJUSTED seed, as the reference's pool is (quirk 1). */
+int32_t jb_param_seed(const jb_context *ctx);
+
+/* uploads the lookup tables of a mesh view; the view's host arrays may be freed afterwards */
+jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *view, jb_mesh **mesh);
+jb_status jb_mesh_destroy(jb_mesh *mesh);
+
+/* UpdateDerivedTransportFields(md, dt) -- jaybenne.hpp:66, jaybenne.cpp:285-492 */
+jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh *mesh, double dt);
+
+/* SourcePhotons<T,ST>(md, t_start, dt) -- jaybenne.hpp:63-64, sourcing.cpp:25-208, split at the
+ * host round-trip of sourcing.cpp:120-131:
+ *   _count  "SourcePhotons1": per-cell number / energy weight, per-block totals (to the host)
+ *           and per-cell exclusive prefix (device int32 [nblocks][ncells]); blocks_in_call is
+ *           the `nblocks` of sourcing.cpp:68-69 (1 on the MeshBlockData path);
+ *   _fill   "SourcePhotons2": attributes of the nper_block[b] new particles of each block;
+ *           block b writes slots slot_base[b].. and stream ids id_base[b]..  (host arrays
+ *           [nblocks]; the slot assignment is Parthenon's AddEmptyParticles step).
+ * Returns JB_COMPLETE without doing anything for emission when do_emission is false
+ * (sourcing.cpp:41-43); JB_ERR_INVALID for the `energy` strategy (sourcing.cpp:38). */
+jb_status jb_source_photons_count(jb_context *ctx, jb_mesh *mesh, int source_type, double dt,
+                                  int blocks_in_call, uint32_t epoch, int32_t *nper_block_host,
+                                  int32_t *prefix_dev);
+jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                                 int source_type, double t_start, double dt,
+                                 const int32_t *nper_block_host, const int32_t *prefix_dev,
+                                 const int64_t *slot_base_host, const uint64_t *id_base_host);
+
+/* TransportPhotons / TransportPhotons_DDMC(md, t_start, dt) -- jaybenne.hpp:59-60,
+ * transport.cpp:28-181, transport_ddmc.cpp:28-237.  Particles [first,last) with status ACTIVE
+ * are followed until census, absorption, escape, or until they enter a block owned by another
+ * rank (status OUTGOING).  Crossing into a block of THIS rank does not end the launch: the swarm
+ * boundary conditions (boundaries.hpp:46-82, periodic, outflow), the destination-block lookup
+ * and SampleDDMCBlockFace are applied to the particle in flight.  With fuse_census_tally != 0
+ * a particle reaching census adds weight / cell volume to energy_tally (EvaluateRadiationEnergy
+ * fused; the caller zeroes the tally first with jb_zero_energy_tally). */
+jb_status jb_transport_photons(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                               double t_start, double dt, int64_t first, int64_t last,
+                               int fuse_census_tally);
+jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                                    double t_start, double dt, int64_t first, int64_t last,
+                                    int fuse_census_tally);
+/* counters accumulated by the transport tasks since the last reset (synchronises) */
+jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats *stats, int reset);
+
+/* SampleDDMCBlockFace(md) -- jaybenne.hpp:61, sample_ddmc_bface.cpp:81-427; for particles
+ * that arrived from another rank */
+jb_status jb_sample_ddmc_block_face(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                                    int64_t first, int64_t last);
+
+/* CheckCompletion(md, t_end) -- jaybenne.hpp:62, transport.cpp:187-216: JB_ITERATE if any
+ * ACTIVE particle has t < t_end, else JB_COMPLETE; the count goes to *unfinished */
+jb_status jb_check_completion(jb_context *ctx, const jb_swarm_view *swarm, double t_end,
+                              int64_t *unfinished);
+
+/* EvaluateRadiationEnergy<T>(md) -- jaybenne.hpp:67-68, jaybenne.cpp:514-564 */
+jb_status jb_zero_energy_tally(jb_context *ctx, jb_mesh *mesh);
+jb_status jb_evaluate_radiation_energy(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm);
+
+/* UpdateFluid(md) -- jaybenne.hpp:69, jaybenne.cpp:583-615 */
+jb_status jb_update_fluid(jb_context *ctx, jb_mesh *mesh);
+
+/* PhotonReflectBC<BFACE>(swarm) -- boundaries.hpp:24-84; face = 0..5 (ix1, ox1, ix2, ...) */
+jb_status jb_photon_reflect_bc(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm, int face);
+
+/* Swarm::RemoveMarkedParticles (transport.cpp:176-178) / DefragParticles (jaybenne.cpp:499-509):
+ * keeps ACTIVE particles, closes the holes, updates swarm->n */
+jb_status jb_remove_marked_particles(jb_context *ctx, jb_swarm_view *swarm);
+
+/* MeshSend / MeshReceive (jaybenne.cpp:36-61) for the inter-rank part: OUTGOING particles are
+ * copied into fixed-size records (JB_RECORD_WORDS x 8 bytes), ordered by destination rank;
+ * counts_host[r] = records for rank r.  Unpack appends records to the swarm as ACTIVE particles
+ * of this rank's blocks. */
+#define JB_RECORD_WORDS 13
+jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm, int nranks,
+                           int64_t *records_dev, int64_t record_capacity, int64_t *counts_host);
+jb_status jb_unpack_incoming(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm,
+                             const int64_t *records_dev, int64_t nrecords);
+
+/* EstimateTimestepMesh(md) -- jaybenne.hpp:75, jaybenne.cpp:271-275 */
+double jb_estimate_timestep(const jb_context *ctx);
+
+/* RadiationStep(pmesh, t_start, dt) for a mesh held by ONE rank -- jaybenne.hpp:72,
+ * jaybenne.cpp:68-151: derived fields, emission source, transport to completion, census tally,
+ * fluid update.  next_id: first unused stream id (updated); epoch: source-call counter (updated). */
+jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm, double t_start,
+                            double dt, uint64_t *next_id, uint32_t *epoch, int32_t *prefix_dev);
+
+/* ---- debug entry points (parity tests drive the device functions directly) ---------------- */
+jb_status jb_debug_philox(jb_context *ctx, const uint32_t ctr[4], const uint32_t key[2],
+                          uint32_t out[4]);
+jb_status jb_debug_rocrand_philox(jb_context *ctx, uint64_t seed, uint64_t subsequence,
+                                  uint32_t out[8]);
+jb_status jb_debug_draw_stream(jb_context *ctx, uint32_t key0, uint32_t key1, uint64_t id,
+                               uint32_t first, int n, double *out_host);
+/* which: 0 log, 1 sin, 2 cos, 3 acos, 4 sqrt, 5 reciprocal */
+jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n, double *out_host);
+/* step functions on a tape of uniforms.  st: jb_debug_step record (see below); which:
+ * 0 ptcl_transport_step, 1 ptcl_ddmc_step, 2 ptcl_ddmc_albedo */
+typedef struct jb_debug_step {
+  double t_start, dt, ff, aa, ss, vv, dx_push;
+  int32_t multi_d, three_d;
+  double xl, yl, zl, xu, yu, zu, Px_l, Py_l, Pz_l, Px_u, Py_u, Pz_u;
+  double t, x, y, z, vx, vy, vz;
+  int32_t ip, jp, kp, is_absorbed, is_scattered, is_rejected;
+} jb_debug_step;
+jb_status jb_debug_step_call(jb_context *ctx, int which, jb_debug_step *st, const double *tape,
+                             int ntape, int *ndraws);
+/* which: 0 scatter(vv), 1 sample_face_iso_dir(vv), 2 sample_Planck_energy(sb=a0, temp=a1),
+ * 3 SampleFace2D(i_l=i0, dx=a0, P_l=a1, P_u=a2; i=i1, x=a3),
+ * 4 SampleFace3D(i1_l=i0, i2_l=i1, dx1=a0, dx2=a1, P=a2..a5; i=(i2,i3), x=(a6,a7)) */
+jb_status jb_debug_sample_call(jb_context *ctx, int which, const double *a, const int32_t *i,
+                               const double *tape, int ntape, double out[4], int32_t iout[2],
+                               int *ndraws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAYBENNE_AMD_H_ */

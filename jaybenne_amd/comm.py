@@ -1,0 +1,83 @@
+"""Inter-rank exchange for the history loop: one process per GPU, ``torch.distributed`` over
+RCCL (backend "nccl") on xGMI, or gloo on CPU for tests.
+
+The reference's only communication on this path is (i) the neighbour hand-off of particles that
+left a rank's blocks (``MeshSend`` / ``MeshReceive``, reference jaybenne.cpp:36-61) and (ii) the
+global completion test of the iterate-sublist (``TQ::global_sync | TQ::completion``,
+jaybenne.cpp:130-131).  Both are expressed here as two small collectives per transport iteration:
+
+* ``exchange_records``: an all-to-all of the per-destination record counts followed by one
+  all-to-all-v of fixed-size particle records (13 x 8 bytes).  xGMI is a full point-to-point
+  mesh, so every rank pair moves its share over its own link concurrently;
+* ``allreduce_sum_int64``: one integer ("particles that changed rank this iteration").
+
+There is no collective inside the tracking kernel and none on the field data: each rank owns its
+blocks' fields outright.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RECORD_WORDS = 13
+
+
+class Comm:
+    def __init__(self, group=None, device: Optional[torch.device] = None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.nranks = dist.get_world_size(group)
+        backend = dist.get_backend(group)
+        if backend == "nccl":
+            if device is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            self.device = device
+        else:
+            self.device = torch.device("cpu")
+
+    # -- small host-side reductions
+    def allreduce_sum_int64(self, values: np.ndarray) -> np.ndarray:
+        t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.int64)).to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def allreduce_max_float(self, value: float) -> float:
+        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def barrier(self) -> None:
+        dist.barrier(group=self.group)
+
+    # -- particle hand-off
+    def exchange_counts(self, send_counts: np.ndarray) -> np.ndarray:
+        s = torch.from_numpy(np.ascontiguousarray(send_counts, dtype=np.int64)).to(self.device)
+        r = torch.empty_like(s)
+        dist.all_to_all_single(r, s, group=self.group)
+        return r.cpu().numpy()
+
+    def exchange_records(self, send: Optional[torch.Tensor], send_counts: np.ndarray,
+                         out_device: torch.device) -> Optional[torch.Tensor]:
+        """send: [sum(send_counts), 13] int64 ordered by destination rank (or None).  Returns the
+        records addressed to this rank, [nrecv, 13] int64 on ``out_device`` (or None)."""
+        send_counts = np.asarray(send_counts, dtype=np.int64)
+        if send_counts[self.rank] != 0:
+            raise ValueError("a rank does not hand particles to itself")
+        recv_counts = self.exchange_counts(send_counts)
+        nrecv = int(recv_counts.sum())
+        if send is None:
+            send = torch.empty((0, RECORD_WORDS), dtype=torch.int64, device=self.device)
+        if int(send.shape[0]) != int(send_counts.sum()):
+            raise ValueError("record buffer does not match the send counts")
+        send_c = send.to(self.device).contiguous()
+        recv = torch.empty((nrecv, RECORD_WORDS), dtype=torch.int64, device=self.device)
+        dist.all_to_all_single(recv, send_c, output_split_sizes=[int(c) for c in recv_counts],
+                               input_split_sizes=[int(c) for c in send_counts], group=self.group)
+        if nrecv == 0:
+            return None
+        return recv.to(out_device)

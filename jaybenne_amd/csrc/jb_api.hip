@@ -1,0 +1,856 @@
+// jb_api.hip -- host side of the C ABI declared in include/jaybenne_amd.h.
+//
+// Mirrors the task functions of the reference package (src/jaybenne/jaybenne.hpp:48-78) over
+// raw device pointers.  No torch types, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/jaybenne_amd.h"
+#include "jb_kernels.hpp"
+
+using namespace jb;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static jb_status fail(jb_status st, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return st;
+}
+
+#define JB_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(JB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                 \
+  } while (0)
+
+struct jb_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  jb_params params{};
+  jb_eos eos{};
+  jb_opacity opac{};
+  jb_scattering scat{};
+  DevParams dp{};
+  int num_cu = 256;
+  unsigned long long *counters_d = nullptr;   // CNT_N + 2 cursors + per-rank counters
+  unsigned long long *counters_h = nullptr;   // pinned
+  long long *scratch_d = nullptr;             // holes / movers / small tables
+  size_t scratch_words = 0;
+  jb_transport_stats stats{};
+};
+constexpr int kCounterWords = 1024;  // CNT_N.. | 16..17 cursors | 32.. per-rank counts (<= 480 ranks)
+constexpr int kCursorBase = 16;
+constexpr int kRankBase = 32;
+
+struct jb_mesh {
+  jb_context *ctx = nullptr;
+  DevMesh dm{};
+  std::vector<void *> owned;  // device allocations
+  std::vector<int32_t> owner_h, gid_h;
+  int nranks_seen = 1;
+};
+
+extern "C" const char *jb_last_error(void) { return g_err; }
+extern "C" const char *jb_version(void) { return "jaybenne_amd 0.1 (gfx950)"; }
+
+static int grid_for(const jb_context *ctx, long long n, int per_cu = 8) {
+  long long blocks = (n + kBlock - 1) / kBlock;
+  const long long cap = (long long)ctx->num_cu * per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+static jb_status ensure_scratch(jb_context *ctx, size_t words) {
+  if (words <= ctx->scratch_words) return JB_COMPLETE;
+  if (ctx->scratch_d) JB_HIP(hipFree(ctx->scratch_d));
+  ctx->scratch_d = nullptr;
+  ctx->scratch_words = 0;
+  const size_t want = words + words / 4 + 1024;
+  JB_HIP(hipMalloc(&ctx->scratch_d, want * sizeof(long long)));
+  ctx->scratch_words = want;
+  return JB_COMPLETE;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
+                                   const jb_opacity *opacity, const jb_scattering *scattering,
+                                   int device, jb_context **out) {
+  if (!params || !eos || !opacity || !scattering || !out)
+    return fail(JB_ERR_INVALID, "jb_initialize: null argument");
+  // PARTHENON_REQUIRE / PARTHENON_FAIL conditions of jaybenne.cpp:167-171,205-216
+  if (!(params->min_swarm_occupancy >= 0.0 && params->min_swarm_occupancy < 1.0))
+    return fail(JB_ERR_INVALID,
+                "Minimum allowable swarm occupancy must be >= 0 and less than 1");
+  if (params->source_strategy != JB_STRATEGY_UNIFORM && params->source_strategy != JB_STRATEGY_ENERGY)
+    return fail(JB_ERR_INVALID, "Only uniform or energy source strategies supported!");
+  if (params->num_particles < 0) return fail(JB_ERR_INVALID, "num_particles must be >= 0");
+  if (eos->model != JB_EOS_IDEAL_GAS)
+    return fail(JB_ERR_UNSUPPORTED, "only the IdealGas EOS is built");
+  if (opacity->model != JB_OPAC_GRAY)
+    return fail(JB_ERR_UNSUPPORTED, "only the Gray absorption opacity is built");
+  if (scattering->model != JB_SCAT_GRAY)
+    return fail(JB_ERR_UNSUPPORTED, "only the GrayS scattering opacity is built");
+  JB_HIP(hipSetDevice(device));
+  jb_context *ctx = new (std::nothrow) jb_context();
+  if (!ctx) return fail(JB_ERR_HIP, "out of host memory");
+  ctx->device = device;
+  ctx->params = *params;
+  ctx->eos = *eos;
+  ctx->opac = *opacity;
+  ctx->scat = *scattering;
+  ctx->dp.key0 = (uint32_t)params->seed;  // RngPool rng_pool(seed): unadjusted (quirk 1)
+  ctx->dp.use_ddmc = params->use_ddmc;
+  ctx->dp.do_feedback = params->do_feedback;
+  ctx->dp.tau_ddmc = params->tau_ddmc;
+  ctx->dp.c = opacity->c;
+  ctx->dp.sb = opacity->sb;
+  ctx->dp.cv = eos->cv;
+  ctx->dp.kappa_a = opacity->kappa;
+  ctx->dp.kappa_s = scattering->kappa_s;
+  ctx->dp.apm = scattering->apm;
+  hipDeviceProp_t prop;
+  JB_HIP(hipGetDeviceProperties(&prop, device));
+  ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  JB_HIP(hipMalloc(&ctx->counters_d, kCounterWords * sizeof(unsigned long long)));
+  JB_HIP(hipMemset(ctx->counters_d, 0, kCounterWords * sizeof(unsigned long long)));
+  JB_HIP(hipHostMalloc(&ctx->counters_h, kCounterWords * sizeof(unsigned long long)));
+  *out = ctx;
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_finalize(jb_context *ctx) {
+  if (!ctx) return JB_COMPLETE;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->counters_d) (void)hipFree(ctx->counters_d);
+  if (ctx->counters_h) (void)hipHostFree(ctx->counters_h);
+  if (ctx->scratch_d) (void)hipFree(ctx->scratch_d);
+  delete ctx;
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_set_stream(jb_context *ctx, void *hip_stream) {
+  if (!ctx) return fail(JB_ERR_INVALID, "null context");
+  ctx->stream = (hipStream_t)hip_stream;
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_synchronize(jb_context *ctx) {
+  if (!ctx) return fail(JB_ERR_INVALID, "null context");
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  return JB_COMPLETE;
+}
+
+extern "C" int32_t jb_param_seed(const jb_context *ctx) {
+  return ctx->params.unique_rank_seeds ? ctx->params.seed + ctx->params.rank : ctx->params.seed;
+}
+
+extern "C" double jb_estimate_timestep(const jb_context *ctx) { return ctx->params.dt; }
+
+// ------------------------------------------------------------------------------------------------
+template <class T>
+static jb_status upload(jb_mesh *m, const T *host, size_t count, const T **dev) {
+  void *p = nullptr;
+  if (count == 0) count = 1;
+  JB_HIP(hipMalloc(&p, count * sizeof(T)));
+  m->owned.push_back(p);
+  if (host) JB_HIP(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+  *dev = (const T *)p;
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_mesh **out) {
+  if (!ctx || !v || !out) return fail(JB_ERR_INVALID, "jb_mesh_create: null argument");
+  if (v->ndim < 1 || v->ndim > 3) return fail(JB_ERR_INVALID, "ndim must be 1, 2 or 3");
+  if (v->ng < 1) return fail(JB_ERR_INVALID, "ng >= 1 required (face fields share the cell layout)");
+  if (v->nblocks < 1 || v->nblocks_total < v->nblocks)
+    return fail(JB_ERR_INVALID, "bad block counts");
+  for (int d = 0; d < 3; ++d) {
+    if (v->nx[d] < 1 || v->nleaf[d] < 1) return fail(JB_ERR_INVALID, "bad nx / nleaf");
+    if (d >= v->ndim && v->nx[d] != 1) return fail(JB_ERR_INVALID, "inactive dimension with nx != 1");
+    if (!(v->gmax[d] > v->gmin[d])) return fail(JB_ERR_INVALID, "empty domain");
+  }
+  if (!v->leaf_map || !v->owner || !v->local_index || !v->gid || !v->blk_xmin || !v->blk_xmax ||
+      !v->blk_dx || !v->blk_level || !v->blk_nbr_lev)
+    return fail(JB_ERR_INVALID, "jb_mesh_create: missing table");
+  if (!v->rho || !v->sie || !v->u || !v->fleck || !v->tally || !v->edelta || !v->src_ew ||
+      !v->src_num)
+    return fail(JB_ERR_INVALID, "jb_mesh_create: missing field pointer table");
+  if (ctx->params.use_ddmc && (!v->P1 || (v->ndim > 1 && !v->P2) || (v->ndim > 2 && !v->P3)))
+    return fail(JB_ERR_INVALID, "use_ddmc requires the ddmc_face_prob arrays");
+  // every table index the kernels will form is checked here, once
+  const long long nleaf = (long long)v->nleaf[0] * v->nleaf[1] * v->nleaf[2];
+  for (long long q = 0; q < nleaf; ++q)
+    if (v->leaf_map[q] < 0 || v->leaf_map[q] >= v->nblocks_total)
+      return fail(JB_ERR_INVALID, "leaf_map entry out of range");
+  for (int g = 0; g < v->nblocks_total; ++g) {
+    const int li = v->local_index[g];
+    if (v->owner[g] == v->rank) {
+      if (li < 0 || li >= v->nblocks || v->gid[li] != g)
+        return fail(JB_ERR_INVALID, "local_index / gid inconsistent for block %d", g);
+    } else if (li != -1) {
+      return fail(JB_ERR_INVALID, "local_index must be -1 for blocks of other ranks");
+    }
+    if (v->owner[g] < 0) return fail(JB_ERR_INVALID, "negative owner rank");
+  }
+  JB_HIP(hipSetDevice(ctx->device));
+  jb_mesh *m = new (std::nothrow) jb_mesh();
+  if (!m) return fail(JB_ERR_HIP, "out of host memory");
+  m->ctx = ctx;
+  DevMesh &D = m->dm;
+  D.ndim = v->ndim; D.ng = v->ng; D.nblocks = v->nblocks; D.nblocks_total = v->nblocks_total;
+  D.rank = v->rank;
+  for (int d = 0; d < 3; ++d) { D.nx[d] = v->nx[d]; D.nleaf[d] = v->nleaf[d]; D.gmin[d] = v->gmin[d]; D.gmax[d] = v->gmax[d]; }
+  for (int f = 0; f < 6; ++f) {
+    if (v->bc[f] < 0 || v->bc[f] > 2) { delete m; return fail(JB_ERR_INVALID, "unknown swarm boundary"); }
+    D.bc[f] = v->bc[f];
+  }
+  D.is = v->ng; D.js = v->ndim >= 2 ? v->ng : 0; D.ks = v->ndim >= 3 ? v->ng : 0;
+  D.ni = v->nx[0] + 2 * D.is; D.nj = v->nx[1] + 2 * D.js; D.nk = v->nx[2] + 2 * D.ks;
+  D.ie = D.is + v->nx[0] - 1; D.je = D.js + v->nx[1] - 1; D.ke = D.ks + v->nx[2] - 1;
+  D.ncell = v->nx[0] * v->nx[1] * v->nx[2];
+  D.ntot = (long long)D.ni * D.nj * D.nk;
+  int maxrank = 0;
+  for (int g = 0; g < v->nblocks_total; ++g) maxrank = v->owner[g] > maxrank ? v->owner[g] : maxrank;
+  m->nranks_seen = maxrank + 1;
+  m->owner_h.assign(v->owner, v->owner + v->nblocks_total);
+  m->gid_h.assign(v->gid, v->gid + v->nblocks);
+  jb_status st;
+#define UP(field, count)                                                         \
+  if ((st = upload(m, v->field, (size_t)(count), &D.field)) != JB_COMPLETE) {     \
+    jb_mesh_destroy(m);                                                          \
+    return st;                                                                   \
+  }
+  UP(leaf_map, nleaf);
+  UP(owner, v->nblocks_total);
+  UP(local_index, v->nblocks_total);
+  UP(gid, v->nblocks);
+  UP(blk_xmin, 3 * v->nblocks);
+  UP(blk_xmax, 3 * v->nblocks);
+  UP(blk_dx, 3 * v->nblocks);
+  UP(blk_level, v->nblocks);
+  UP(blk_nbr_lev, 6 * v->nblocks);
+#undef UP
+#define UPF(field)                                                                           \
+  if (v->field) {                                                                            \
+    for (int b = 0; b < v->nblocks; ++b)                                                     \
+      if (!v->field[b]) { jb_mesh_destroy(m); return fail(JB_ERR_INVALID, "null block pointer in " #field); } \
+    const double *const *tmp = nullptr;                                                      \
+    if ((st = upload(m, (const double *const *)v->field, (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { \
+      jb_mesh_destroy(m);                                                                    \
+      return st;                                                                             \
+    }                                                                                        \
+    D.field = (double *const *)tmp;                                                          \
+  } else {                                                                                   \
+    D.field = nullptr;                                                                       \
+  }
+  UPF(rho) UPF(sie) UPF(u) UPF(fleck) UPF(tally) UPF(edelta) UPF(src_ew) UPF(src_num)
+  UPF(P1) UPF(P2) UPF(P3)
+#undef UPF
+  *out = m;
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_mesh_destroy(jb_mesh *m) {
+  if (!m) return JB_COMPLETE;
+  for (void *p : m->owned) (void)hipFree(p);
+  delete m;
+  return JB_COMPLETE;
+}
+
+static DevSwarm dev_swarm(const jb_swarm_view *s) {
+  DevSwarm S;
+  S.x = s->x; S.y = s->y; S.z = s->z; S.vx = s->vx; S.vy = s->vy; S.vz = s->vz;
+  S.t = s->t; S.w = s->w; S.e = s->e;
+  S.ip = s->ip; S.jp = s->jp; S.kp = s->kp; S.blk = s->blk; S.status = s->status;
+  S.id = (uint64_t *)s->id; S.ctr = s->ctr;
+  return S;
+}
+
+static jb_status check_swarm(const jb_swarm_view *s, const char *who) {
+  if (!s) return fail(JB_ERR_INVALID, "%s: null swarm", who);
+  if (s->n < 0 || s->n > s->capacity) return fail(JB_ERR_INVALID, "%s: swarm n outside [0, capacity]", who);
+  if (s->capacity > 0 && (!s->x || !s->y || !s->z || !s->vx || !s->vy || !s->vz || !s->t || !s->w ||
+                          !s->e || !s->ip || !s->jp || !s->kp || !s->blk || !s->status || !s->id ||
+                          !s->ctr))
+    return fail(JB_ERR_INVALID, "%s: null swarm array", who);
+  return JB_COMPLETE;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh *mesh, double dt) {
+  if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  const DevMesh &M = mesh->dm;
+  const long long cells = (long long)M.nblocks * M.ncell;
+  hipLaunchKernelGGL(k_fleck, dim3(grid_for(ctx, cells)), dim3(kBlock), 0, ctx->stream, M, ctx->dp, dt);
+  if (ctx->params.use_ddmc) {
+    const int g = grid_for(ctx, cells * 2);
+    hipLaunchKernelGGL(k_face_prob<0>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
+    if (M.ndim > 1) hipLaunchKernelGGL(k_face_prob<1>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
+    if (M.ndim > 2) hipLaunchKernelGGL(k_face_prob<2>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
+  }
+  JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_source_photons_count(jb_context *ctx, jb_mesh *mesh, int source_type,
+                                             double dt, int blocks_in_call, uint32_t epoch,
+                                             int32_t *nper_block_host, int32_t *prefix_dev) {
+  if (!ctx || !mesh || !nper_block_host || !prefix_dev) return fail(JB_ERR_INVALID, "null argument");
+  if (ctx->params.source_strategy == JB_STRATEGY_ENERGY)
+    return fail(JB_ERR_INVALID, "Energy source strategy not implemented!");  // sourcing.cpp:38
+  const DevMesh &M = mesh->dm;
+  if (source_type == JB_SOURCE_EMISSION && !ctx->params.do_emission) {  // sourcing.cpp:41-43
+    for (int b = 0; b < M.nblocks; ++b) nper_block_host[b] = 0;
+    return JB_COMPLETE;
+  }
+  if (blocks_in_call < 1) return fail(JB_ERR_INVALID, "blocks_in_call must be >= 1");
+  jb_status st = ensure_scratch(ctx, (size_t)M.nblocks);
+  if (st != JB_COMPLETE) return st;
+  // sourcing.cpp:68-69
+  const double npc = (double)ctx->params.num_particles / (double)M.ncell /
+                     (double)(blocks_in_call * M.nblocks_total);
+  int *nper_d = (int *)ctx->scratch_d;
+  hipLaunchKernelGGL(k_source_count, dim3(M.nblocks), dim3(kBlock), 0, ctx->stream, M, ctx->dp,
+                     source_type, dt, npc, epoch, nper_d, prefix_dev);
+  JB_HIP(hipGetLastError());
+  JB_HIP(hipMemcpyAsync(nper_block_host, nper_d, sizeof(int) * M.nblocks, hipMemcpyDeviceToHost,
+                        ctx->stream));
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh,
+                                            const jb_swarm_view *swarm, int source_type,
+                                            double t_start, double dt,
+                                            const int32_t *nper_block_host,
+                                            const int32_t *prefix_dev,
+                                            const int64_t *slot_base_host,
+                                            const uint64_t *id_base_host) {
+  if (!ctx || !mesh || !nper_block_host || !prefix_dev || !slot_base_host || !id_base_host)
+    return fail(JB_ERR_INVALID, "null argument");
+  jb_status st = check_swarm(swarm, "jb_source_photons_fill");
+  if (st != JB_COMPLETE) return st;
+  const DevMesh &M = mesh->dm;
+  if (source_type == JB_SOURCE_EMISSION && !ctx->params.do_emission) return JB_COMPLETE;
+  st = ensure_scratch(ctx, (size_t)M.nblocks * 4 + 8);
+  if (st != JB_COMPLETE) return st;
+  const int32_t *nper = nper_block_host;
+  std::vector<long long> tab(3 * (size_t)M.nblocks);
+  long long total = 0;
+  for (int b = 0; b < M.nblocks; ++b) {
+    tab[b] = total;                                   // blk_first
+    tab[M.nblocks + b] = slot_base_host[b];           // slot_base
+    tab[2 * M.nblocks + b] = (long long)id_base_host[b];
+    if (nper[b] < 0) return fail(JB_ERR_INVALID, "negative particle count for block %d", b);
+    if (nper[b] > 0 && (slot_base_host[b] < 0 || slot_base_host[b] + nper[b] > swarm->capacity))
+      return fail(JB_ERR_CAPACITY, "swarm capacity %lld too small for block %d (slots %lld..%lld)",
+                  (long long)swarm->capacity, b, (long long)slot_base_host[b],
+                  (long long)slot_base_host[b] + nper[b]);
+    total += nper[b];
+  }
+  long long *tab_d = ctx->scratch_d + M.nblocks;  // after the int counts (nblocks ints fit in nblocks words)
+  JB_HIP(hipMemcpyAsync(tab_d, tab.data(), sizeof(long long) * tab.size(), hipMemcpyHostToDevice,
+                        ctx->stream));
+  hipLaunchKernelGGL(k_source_edelta, dim3(grid_for(ctx, (long long)M.nblocks * M.ncell)),
+                     dim3(kBlock), 0, ctx->stream, M, source_type);
+  if (total > 0)
+    hipLaunchKernelGGL(k_source_fill, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream, M,
+                       ctx->dp, dev_swarm(swarm), source_type, t_start, dt, (const int *)prefix_dev,
+                       (const long long *)tab_d, (const long long *)(tab_d + M.nblocks),
+                       (const unsigned long long *)(tab_d + 2 * M.nblocks), total);
+  JB_HIP(hipGetLastError());
+  JB_HIP(hipStreamSynchronize(ctx->stream));  // tab lives on this stack frame
+  return JB_COMPLETE;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NDIM, bool DDMC>
+static void launch_transport(jb_context *ctx, const DevMesh &M, const DevSwarm &S, double t_start,
+                             double dt, long long first, long long last, bool tally) {
+  const int g = grid_for(ctx, last - first, 8);
+  if (tally)
+    hipLaunchKernelGGL((k_transport<NDIM, DDMC, true>), dim3(g), dim3(kBlock), 0, ctx->stream, M,
+                       ctx->dp, S, t_start, dt, first, last, ctx->counters_d);
+  else
+    hipLaunchKernelGGL((k_transport<NDIM, DDMC, false>), dim3(g), dim3(kBlock), 0, ctx->stream, M,
+                       ctx->dp, S, t_start, dt, first, last, ctx->counters_d);
+}
+
+static jb_status transport_impl(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                                double t_start, double dt, int64_t first, int64_t last, int tally,
+                                bool ddmc) {
+  if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  jb_status st = check_swarm(swarm, "jb_transport_photons");
+  if (st != JB_COMPLETE) return st;
+  if (first < 0 || last > swarm->n || first > last)
+    return fail(JB_ERR_INVALID, "particle range [%lld,%lld) outside the swarm (n = %lld)",
+                (long long)first, (long long)last, (long long)swarm->n);
+  const DevMesh &M = mesh->dm;
+  if (ddmc && (!M.P1 || (M.ndim > 1 && !M.P2) || (M.ndim > 2 && !M.P3)))
+    return fail(JB_ERR_INVALID, "DDMC transport needs the ddmc_face_prob arrays");
+  if (first == last) return JB_COMPLETE;
+  const DevSwarm S = dev_swarm(swarm);
+  const bool tl = tally != 0;
+  switch (M.ndim * 2 + (ddmc ? 1 : 0)) {
+  case 2: launch_transport<1, false>(ctx, M, S, t_start, dt, first, last, tl); break;
+  case 3: launch_transport<1, true>(ctx, M, S, t_start, dt, first, last, tl); break;
+  case 4: launch_transport<2, false>(ctx, M, S, t_start, dt, first, last, tl); break;
+  case 5: launch_transport<2, true>(ctx, M, S, t_start, dt, first, last, tl); break;
+  case 6: launch_transport<3, false>(ctx, M, S, t_start, dt, first, last, tl); break;
+  default: launch_transport<3, true>(ctx, M, S, t_start, dt, first, last, tl); break;
+  }
+  JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_transport_photons(jb_context *ctx, jb_mesh *mesh,
+                                          const jb_swarm_view *swarm, double t_start, double dt,
+                                          int64_t first, int64_t last, int fuse_census_tally) {
+  return transport_impl(ctx, mesh, swarm, t_start, dt, first, last, fuse_census_tally, false);
+}
+extern "C" jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh,
+                                               const jb_swarm_view *swarm, double t_start, double dt,
+                                               int64_t first, int64_t last, int fuse_census_tally) {
+  return transport_impl(ctx, mesh, swarm, t_start, dt, first, last, fuse_census_tally, true);
+}
+
+static jb_status fetch_counters(jb_context *ctx) {
+  JB_HIP(hipMemcpyAsync(ctx->counters_h, ctx->counters_d, sizeof(unsigned long long) * kRankBase,
+                        hipMemcpyDeviceToHost, ctx->stream));
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats *stats, int reset) {
+  if (!ctx || !stats) return fail(JB_ERR_INVALID, "null argument");
+  jb_status st = fetch_counters(ctx);
+  if (st != JB_COMPLETE) return st;
+  stats->n_census = (int64_t)ctx->counters_h[CNT_CENSUS];
+  stats->n_absorbed = (int64_t)ctx->counters_h[CNT_ABSORBED];
+  stats->n_escaped = (int64_t)ctx->counters_h[CNT_ESCAPED];
+  stats->n_outgoing = (int64_t)ctx->counters_h[CNT_OUTGOING];
+  stats->n_events = (int64_t)ctx->counters_h[CNT_EVENTS];
+  if (reset) JB_HIP(hipMemsetAsync(ctx->counters_d, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_sample_ddmc_block_face(jb_context *ctx, jb_mesh *mesh,
+                                               const jb_swarm_view *swarm, int64_t first,
+                                               int64_t last) {
+  if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  jb_status st = check_swarm(swarm, "jb_sample_ddmc_block_face");
+  if (st != JB_COMPLETE) return st;
+  const DevMesh &M = mesh->dm;
+  if (!(M.ndim > 1)) return JB_COMPLETE;  // sample_ddmc_bface.cpp:90
+  if (first < 0 || last > swarm->n || first > last) return fail(JB_ERR_INVALID, "bad particle range");
+  if (!M.P1 || !M.P2 || (M.ndim > 2 && !M.P3)) return fail(JB_ERR_INVALID, "needs ddmc_face_prob");
+  if (first == last) return JB_COMPLETE;
+  const int g = grid_for(ctx, last - first);
+  if (M.ndim == 2)
+    hipLaunchKernelGGL(k_block_face<2>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, dev_swarm(swarm), first, last);
+  else
+    hipLaunchKernelGGL(k_block_face<3>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, dev_swarm(swarm), first, last);
+  JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_check_completion(jb_context *ctx, const jb_swarm_view *swarm, double t_end,
+                                         int64_t *unfinished) {
+  if (!ctx || !unfinished) return fail(JB_ERR_INVALID, "null argument");
+  jb_status st = check_swarm(swarm, "jb_check_completion");
+  if (st != JB_COMPLETE) return st;
+  JB_HIP(hipMemsetAsync(&ctx->counters_d[CNT_UNFINISHED], 0, sizeof(unsigned long long), ctx->stream));
+  if (swarm->n > 0)
+    hipLaunchKernelGGL(k_check_completion, dim3(grid_for(ctx, swarm->n)), dim3(kBlock), 0, ctx->stream,
+                       dev_swarm(swarm), (long long)swarm->n, t_end, ctx->counters_d);
+  JB_HIP(hipGetLastError());
+  st = fetch_counters(ctx);
+  if (st != JB_COMPLETE) return st;
+  *unfinished = (int64_t)ctx->counters_h[CNT_UNFINISHED];
+  return *unfinished > 0 ? JB_ITERATE : JB_COMPLETE;
+}
+
+extern "C" jb_status jb_zero_energy_tally(jb_context *ctx, jb_mesh *mesh) {
+  if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  const DevMesh &M = mesh->dm;
+  hipLaunchKernelGGL(k_zero_tally, dim3(grid_for(ctx, (long long)M.nblocks * M.ncell)), dim3(kBlock), 0,
+                     ctx->stream, M);
+  JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_evaluate_radiation_energy(jb_context *ctx, jb_mesh *mesh,
+                                                  const jb_swarm_view *swarm) {
+  jb_status st = jb_zero_energy_tally(ctx, mesh);
+  if (st != JB_COMPLETE) return st;
+  st = check_swarm(swarm, "jb_evaluate_radiation_energy");
+  if (st != JB_COMPLETE) return st;
+  if (swarm->n > 0)
+    hipLaunchKernelGGL(k_tally, dim3(grid_for(ctx, swarm->n)), dim3(kBlock), 0, ctx->stream, mesh->dm,
+                       dev_swarm(swarm), (long long)swarm->n);
+  JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_update_fluid(jb_context *ctx, jb_mesh *mesh) {
+  if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  if (!ctx->params.do_feedback) return JB_COMPLETE;  // jaybenne.cpp:590
+  const DevMesh &M = mesh->dm;
+  hipLaunchKernelGGL(k_update_fluid, dim3(grid_for(ctx, (long long)M.nblocks * M.ncell)), dim3(kBlock), 0,
+                     ctx->stream, M);
+  JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_photon_reflect_bc(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                                          int face) {
+  if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  if (face < 0 || face > 5) return fail(JB_ERR_INVALID, "face must be 0..5");
+  jb_status st = check_swarm(swarm, "jb_photon_reflect_bc");
+  if (st != JB_COMPLETE) return st;
+  if (swarm->n > 0)
+    hipLaunchKernelGGL(k_reflect_bc, dim3(grid_for(ctx, swarm->n)), dim3(kBlock), 0, ctx->stream, mesh->dm,
+                       dev_swarm(swarm), (long long)swarm->n, face);
+  JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_remove_marked_particles(jb_context *ctx, jb_swarm_view *swarm) {
+  if (!ctx) return fail(JB_ERR_INVALID, "null argument");
+  jb_status st = check_swarm(swarm, "jb_remove_marked_particles");
+  if (st != JB_COMPLETE) return st;
+  const long long n = swarm->n;
+  if (n == 0) return JB_COMPLETE;
+  const DevSwarm S = dev_swarm(swarm);
+  unsigned long long *cur = ctx->counters_d + kCursorBase;
+  JB_HIP(hipMemsetAsync(cur, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(k_count_active, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, S, n, cur + 2);
+  JB_HIP(hipGetLastError());
+  st = fetch_counters(ctx);
+  if (st != JB_COMPLETE) return st;
+  const long long survivors = (long long)ctx->counters_h[kCursorBase + 2];
+  const long long removed = n - survivors;
+  if (removed > 0 && survivors > 0) {
+    const long long maxlist = removed < survivors ? removed : survivors;
+    st = ensure_scratch(ctx, (size_t)(2 * maxlist));
+    if (st != JB_COMPLETE) return st;
+    long long *holes = ctx->scratch_d, *movers = ctx->scratch_d + maxlist;
+    hipLaunchKernelGGL(k_list_holes_movers, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, S, n,
+                       survivors, holes, movers, cur);
+    JB_HIP(hipGetLastError());
+    st = fetch_counters(ctx);
+    if (st != JB_COMPLETE) return st;
+    const long long nh = (long long)ctx->counters_h[kCursorBase], nm = (long long)ctx->counters_h[kCursorBase + 1];
+    if (nh != nm) return fail(JB_ERR_INVALID, "compaction lists disagree (%lld holes, %lld movers)", nh, nm);
+    if (nh > 0)
+      hipLaunchKernelGGL(k_fill_holes, dim3(grid_for(ctx, nh)), dim3(kBlock), 0, ctx->stream, S, holes,
+                         movers, nh);
+    JB_HIP(hipGetLastError());
+  }
+  swarm->n = survivors;
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                                      int nranks, int64_t *records_dev, int64_t record_capacity,
+                                      int64_t *counts_host) {
+  if (!ctx || !mesh || !counts_host) return fail(JB_ERR_INVALID, "null argument");
+  jb_status st = check_swarm(swarm, "jb_pack_outgoing");
+  if (st != JB_COMPLETE) return st;
+  if (nranks < mesh->nranks_seen || nranks > kCounterWords - kRankBase)
+    return fail(JB_ERR_INVALID, "nranks = %d does not cover the owners in the mesh view", nranks);
+  unsigned long long *per_rank = ctx->counters_d + kRankBase;
+  JB_HIP(hipMemsetAsync(per_rank, 0, sizeof(unsigned long long) * nranks, ctx->stream));
+  const DevSwarm S = dev_swarm(swarm);
+  if (swarm->n > 0)
+    hipLaunchKernelGGL(k_count_outgoing, dim3(grid_for(ctx, swarm->n)), dim3(kBlock), 0, ctx->stream,
+                       mesh->dm, S, (long long)swarm->n, per_rank);
+  JB_HIP(hipGetLastError());
+  JB_HIP(hipMemcpyAsync(ctx->counters_h + kRankBase, per_rank, sizeof(unsigned long long) * nranks,
+                        hipMemcpyDeviceToHost, ctx->stream));
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  long long total = 0;
+  std::vector<long long> firsts(nranks);
+  for (int r = 0; r < nranks; ++r) {
+    counts_host[r] = (int64_t)ctx->counters_h[kRankBase + r];
+    firsts[r] = total;
+    total += counts_host[r];
+  }
+  if (total == 0) return JB_COMPLETE;
+  if (!records_dev || total > record_capacity)
+    return fail(JB_ERR_CAPACITY, "hand-off buffer holds %lld records, %lld needed",
+                (long long)record_capacity, total);
+  st = ensure_scratch(ctx, (size_t)nranks);
+  if (st != JB_COMPLETE) return st;
+  JB_HIP(hipMemcpyAsync(ctx->scratch_d, firsts.data(), sizeof(long long) * nranks, hipMemcpyHostToDevice,
+                        ctx->stream));
+  JB_HIP(hipMemsetAsync(per_rank, 0, sizeof(unsigned long long) * nranks, ctx->stream));
+  hipLaunchKernelGGL(k_pack_outgoing, dim3(grid_for(ctx, swarm->n)), dim3(kBlock), 0, ctx->stream, mesh->dm,
+                     S, (long long)swarm->n, (const long long *)ctx->scratch_d, per_rank,
+                     (long long *)records_dev);
+  JB_HIP(hipGetLastError());
+  JB_HIP(hipStreamSynchronize(ctx->stream));  // firsts lives on this stack frame
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_unpack_incoming(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm,
+                                        const int64_t *records_dev, int64_t nrecords) {
+  if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  jb_status st = check_swarm(swarm, "jb_unpack_incoming");
+  if (st != JB_COMPLETE) return st;
+  if (nrecords < 0) return fail(JB_ERR_INVALID, "negative record count");
+  if (nrecords == 0) return JB_COMPLETE;
+  if (!records_dev) return fail(JB_ERR_INVALID, "null record buffer");
+  if (swarm->n + nrecords > swarm->capacity)
+    return fail(JB_ERR_CAPACITY, "swarm capacity %lld too small for %lld arrivals",
+                (long long)swarm->capacity, (long long)nrecords);
+  hipLaunchKernelGGL(k_unpack_incoming, dim3(grid_for(ctx, nrecords)), dim3(kBlock), 0, ctx->stream,
+                     mesh->dm, dev_swarm(swarm), (long long)swarm->n, (const long long *)records_dev,
+                     (long long)nrecords);
+  JB_HIP(hipGetLastError());
+  swarm->n += nrecords;
+  return JB_COMPLETE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RadiationStep for a mesh held entirely by this rank: the task list of jaybenne.cpp:104-138 with
+// the iterate-sublist collapsed to one launch (every block crossing is resolved in flight).
+extern "C" jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm,
+                                       double t_start, double dt, uint64_t *next_id, uint32_t *epoch,
+                                       int32_t *prefix_dev) {
+  if (!ctx || !mesh || !swarm || !next_id || !epoch) return fail(JB_ERR_INVALID, "null argument");
+  const DevMesh &M = mesh->dm;
+  if (M.nblocks != M.nblocks_total)
+    return fail(JB_ERR_INVALID, "jb_radiation_step needs the whole mesh on one rank");
+  jb_status st = jb_update_derived_transport_fields(ctx, mesh, dt);
+  if (st != JB_COMPLETE) return st;
+  if (ctx->params.do_emission) {
+    if (!prefix_dev) return fail(JB_ERR_INVALID, "emission source needs the prefix workspace");
+    std::vector<int32_t> nper(M.nblocks);
+    st = jb_source_photons_count(ctx, mesh, JB_SOURCE_EMISSION, dt, M.nblocks, *epoch, nper.data(),
+                                 prefix_dev);
+    if (st != JB_COMPLETE) return st;
+    *epoch += 1;
+    std::vector<int64_t> slot(M.nblocks);
+    std::vector<uint64_t> ids(M.nblocks);
+    int64_t tot = 0;
+    for (int b = 0; b < M.nblocks; ++b) {
+      slot[b] = swarm->n + tot;
+      ids[b] = *next_id + (uint64_t)tot;
+      tot += nper[b];
+    }
+    if (swarm->n + tot > swarm->capacity)
+      return fail(JB_ERR_CAPACITY, "swarm capacity %lld too small for %lld new particles",
+                  (long long)swarm->capacity, (long long)tot);
+    st = jb_source_photons_fill(ctx, mesh, swarm, JB_SOURCE_EMISSION, t_start, dt, nper.data(),
+                                prefix_dev, slot.data(), ids.data());
+    if (st != JB_COMPLETE) return st;
+    swarm->n += tot;
+    *next_id += (uint64_t)tot;
+  }
+  st = jb_zero_energy_tally(ctx, mesh);
+  if (st != JB_COMPLETE) return st;
+  jb_transport_stats before;
+  st = jb_get_transport_stats(ctx, &before, 0);
+  if (st != JB_COMPLETE) return st;
+  st = transport_impl(ctx, mesh, swarm, t_start, dt, 0, swarm->n, 1, ctx->params.use_ddmc != 0);
+  if (st != JB_COMPLETE) return st;
+  jb_transport_stats after;
+  st = jb_get_transport_stats(ctx, &after, 0);
+  if (st != JB_COMPLETE) return st;
+  if (after.n_outgoing != before.n_outgoing)
+    return fail(JB_ERR_INVALID, "particles left for another rank in a single-rank step");
+  if (after.n_absorbed != before.n_absorbed || after.n_escaped != before.n_escaped) {
+    st = jb_remove_marked_particles(ctx, swarm);
+    if (st != JB_COMPLETE) return st;
+  }
+  return jb_update_fluid(ctx, mesh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// debug entry points
+__global__ void k_dbg_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                             uint32_t k1, uint32_t *out) {
+  const PhiloxBlock b = philox4x32_10(c0, c1, c2, c3, k0, k1);
+  out[0] = b.w0; out[1] = b.w1; out[2] = b.w2; out[3] = b.w3;
+}
+__global__ void k_dbg_rocrand(unsigned long long seed, unsigned long long subseq, uint32_t *out) {
+  rocrand_state_philox4x32_10 st;
+  rocrand_init(seed, subseq, 0ull, &st);
+  const uint4 a = rocrand4(&st);
+  const uint4 b = rocrand4(&st);
+  out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+  out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+}
+__global__ void k_dbg_draw(uint32_t k0, uint32_t k1, unsigned long long id, uint32_t first, int n,
+                           double *out) {
+  PhiloxRng rng(k0, k1, id, first);
+  for (int i = 0; i < n; ++i) out[i] = rng.drand();
+}
+__global__ void k_dbg_math(int which, const double *x, int n, double *out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double s, c;
+    switch (which) {
+    case 0: out[i] = m_log(x[i]); break;
+    case 1: m_sincos(x[i], s, c); out[i] = s; break;
+    case 2: m_sincos(x[i], s, c); out[i] = c; break;
+    case 3: out[i] = m_acos(x[i]); break;
+    case 4: out[i] = sqrt(x[i]); break;
+    default: out[i] = 1.0 / x[i]; break;
+    }
+  }
+}
+__global__ void k_dbg_step(int which, jb_debug_step *d, const double *tape, int ntape, int *ndraws) {
+  TapeRng rng(tape, ntape);
+  Step s;
+  s.t_start = d->t_start; s.dt = d->dt; s.ff = d->ff; s.aa = d->aa; s.ss = d->ss; s.vv = d->vv;
+  s.dx_push = d->dx_push;
+  s.xl = d->xl; s.yl = d->yl; s.zl = d->zl; s.xu = d->xu; s.yu = d->yu; s.zu = d->zu;
+  s.Px_l = d->Px_l; s.Py_l = d->Py_l; s.Pz_l = d->Pz_l; s.Px_u = d->Px_u; s.Py_u = d->Py_u; s.Pz_u = d->Pz_u;
+  s.t = d->t; s.x = d->x; s.y = d->y; s.z = d->z; s.vx = d->vx; s.vy = d->vy; s.vz = d->vz;
+  s.ip = d->ip; s.jp = d->jp; s.kp = d->kp;
+  s.is_absorbed = d->is_absorbed != 0; s.is_scattered = d->is_scattered != 0;
+  s.is_rejected = d->is_rejected != 0;
+  const int nd = d->three_d ? 3 : (d->multi_d ? 2 : 1);
+#define DISPATCH(fn)                                   \
+  if (nd == 1) fn<1>(s, rng);                          \
+  else if (nd == 2) fn<2>(s, rng);                     \
+  else fn<3>(s, rng);
+  if (which == 0) { DISPATCH(ptcl_transport_step) }
+  else if (which == 1) { DISPATCH(ptcl_ddmc_step) }
+  else { DISPATCH(ptcl_ddmc_albedo) }
+#undef DISPATCH
+  d->t = s.t; d->x = s.x; d->y = s.y; d->z = s.z; d->vx = s.vx; d->vy = s.vy; d->vz = s.vz;
+  d->ip = s.ip; d->jp = s.jp; d->kp = s.kp;
+  d->is_absorbed = s.is_absorbed; d->is_scattered = s.is_scattered; d->is_rejected = s.is_rejected;
+  *ndraws = (int)rng.ctr;
+}
+__global__ void k_dbg_sample(int which, const double *a, const int *iv, const double *tape, int ntape,
+                             double *out, int *iout, int *ndraws) {
+  TapeRng rng(tape, ntape);
+  if (which == 0) {
+    scatter(rng, a[0], out[0], out[1], out[2]);
+  } else if (which == 1) {
+    sample_face_iso_dir(a[0], rng, out[0], out[1], out[2]);
+  } else if (which == 2) {
+    out[0] = sample_planck_energy(rng, a[0], a[1]);
+  } else if (which == 3) {
+    int i = iv[1];
+    double x = a[3];
+    sample_face_2d(iv[0], a[0], a[1], a[2], rng, i, x);
+    iout[0] = i; out[0] = x;
+  } else {
+    int i1 = iv[2], i2 = iv[3];
+    double x1 = a[6], x2 = a[7];
+    sample_face_3d(iv[0], iv[1], a[0], a[1], a[2], a[3], a[4], a[5], rng, i1, i2, x1, x2);
+    iout[0] = i1; iout[1] = i2; out[0] = x1; out[1] = x2;
+  }
+  *ndraws = (int)rng.ctr;
+}
+
+// small helper: run a debug kernel with device copies of host buffers
+struct DbgBuf {
+  void *d = nullptr;
+  size_t bytes = 0;
+  ~DbgBuf() { if (d) (void)hipFree(d); }
+  hipError_t put(const void *h, size_t n) {
+    bytes = n ? n : 8;
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) return e;
+    if (h && n) e = hipMemcpy(d, h, n, hipMemcpyHostToDevice);
+    return e;
+  }
+  hipError_t get(void *h, size_t n) { return hipMemcpy(h, d, n, hipMemcpyDeviceToHost); }
+};
+
+extern "C" jb_status jb_debug_philox(jb_context *ctx, const uint32_t ctr[4], const uint32_t key[2],
+                                     uint32_t out[4]) {
+  if (!ctx) return fail(JB_ERR_INVALID, "null context");
+  DbgBuf o;
+  JB_HIP(o.put(nullptr, 16));
+  hipLaunchKernelGGL(k_dbg_philox, dim3(1), dim3(1), 0, ctx->stream, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], (uint32_t *)o.d);
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  JB_HIP(o.get(out, 16));
+  return JB_COMPLETE;
+}
+extern "C" jb_status jb_debug_rocrand_philox(jb_context *ctx, uint64_t seed, uint64_t subsequence,
+                                             uint32_t out[8]) {
+  if (!ctx) return fail(JB_ERR_INVALID, "null context");
+  DbgBuf o;
+  JB_HIP(o.put(nullptr, 32));
+  hipLaunchKernelGGL(k_dbg_rocrand, dim3(1), dim3(1), 0, ctx->stream, (unsigned long long)seed,
+                     (unsigned long long)subsequence, (uint32_t *)o.d);
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  JB_HIP(o.get(out, 32));
+  return JB_COMPLETE;
+}
+extern "C" jb_status jb_debug_draw_stream(jb_context *ctx, uint32_t key0, uint32_t key1, uint64_t id,
+                                          uint32_t first, int n, double *out_host) {
+  if (!ctx || n < 0) return fail(JB_ERR_INVALID, "bad argument");
+  DbgBuf o;
+  JB_HIP(o.put(nullptr, sizeof(double) * n));
+  hipLaunchKernelGGL(k_dbg_draw, dim3(1), dim3(1), 0, ctx->stream, key0, key1, (unsigned long long)id, first, n, (double *)o.d);
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  JB_HIP(o.get(out_host, sizeof(double) * n));
+  return JB_COMPLETE;
+}
+extern "C" jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n,
+                                   double *out_host) {
+  if (!ctx || n < 0) return fail(JB_ERR_INVALID, "bad argument");
+  DbgBuf x, o;
+  JB_HIP(x.put(x_host, sizeof(double) * n));
+  JB_HIP(o.put(nullptr, sizeof(double) * n));
+  hipLaunchKernelGGL(k_dbg_math, dim3(64), dim3(256), 0, ctx->stream, which, (const double *)x.d, n, (double *)o.d);
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  JB_HIP(o.get(out_host, sizeof(double) * n));
+  return JB_COMPLETE;
+}
+extern "C" jb_status jb_debug_step_call(jb_context *ctx, int which, jb_debug_step *st,
+                                        const double *tape, int ntape, int *ndraws) {
+  if (!ctx || !st || !tape || ntape < 1 || !ndraws) return fail(JB_ERR_INVALID, "bad argument");
+  DbgBuf s, t, n;
+  JB_HIP(s.put(st, sizeof(*st)));
+  JB_HIP(t.put(tape, sizeof(double) * ntape));
+  JB_HIP(n.put(nullptr, sizeof(int)));
+  hipLaunchKernelGGL(k_dbg_step, dim3(1), dim3(1), 0, ctx->stream, which, (jb_debug_step *)s.d, (const double *)t.d, ntape, (int *)n.d);
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  JB_HIP(s.get(st, sizeof(*st)));
+  JB_HIP(n.get(ndraws, sizeof(int)));
+  return JB_COMPLETE;
+}
+extern "C" jb_status jb_debug_sample_call(jb_context *ctx, int which, const double *a,
+                                          const int32_t *i, const double *tape, int ntape,
+                                          double out[4], int32_t iout[2], int *ndraws) {
+  if (!ctx || !a || !i || !tape || ntape < 1 || !ndraws) return fail(JB_ERR_INVALID, "bad argument");
+  DbgBuf da, di, t, o, io, n;
+  JB_HIP(da.put(a, sizeof(double) * 8));
+  JB_HIP(di.put(i, sizeof(int) * 4));
+  JB_HIP(t.put(tape, sizeof(double) * ntape));
+  JB_HIP(o.put(nullptr, sizeof(double) * 4));
+  JB_HIP(io.put(nullptr, sizeof(int) * 2));
+  JB_HIP(n.put(nullptr, sizeof(int)));
+  JB_HIP(hipMemset(o.d, 0, sizeof(double) * 4));
+  JB_HIP(hipMemset(io.d, 0, sizeof(int) * 2));
+  hipLaunchKernelGGL(k_dbg_sample, dim3(1), dim3(1), 0, ctx->stream, which, (const double *)da.d,
+                     (const int *)di.d, (const double *)t.d, ntape, (double *)o.d, (int *)io.d, (int *)n.d);
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  JB_HIP(o.get(out, sizeof(double) * 4));
+  JB_HIP(io.get(iout, sizeof(int) * 2));
+  JB_HIP(n.get(ndraws, sizeof(int)));
+  return JB_COMPLETE;
+}

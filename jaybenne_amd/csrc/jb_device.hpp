@@ -1,0 +1,262 @@
+// jb_device.hpp -- device-side views of the mesh / swarm and the geometry helpers that stand in
+// for Parthenon's SparsePack coordinates and SwarmDeviceContext (absent from the reference tree;
+// semantics restated from the call sites).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jb_physics.hpp"
+
+namespace jb {
+
+// ---- by-value kernel arguments (land in SGPRs) -------------------------------------------------
+struct DevMesh {
+  int ndim, ng, nblocks, nblocks_total, rank;
+  int nx[3], nleaf[3], bc[6];
+  int is, js, ks, ie, je, ke, ni, nj, nk;
+  int ncell;          // interior cells per block
+  long long ntot;     // cells per block incl. ghosts
+  double gmin[3], gmax[3];
+  const int *leaf_map, *owner, *local_index, *gid;
+  const double *blk_xmin, *blk_xmax, *blk_dx;
+  const int *blk_level, *blk_nbr_lev;
+  double *const *rho, *const *sie, *const *u, *const *fleck, *const *tally, *const *edelta,
+      *const *src_ew, *const *src_num, *const *P1, *const *P2, *const *P3;
+};
+
+struct DevParams {
+  uint32_t key0;      // Philox key word 0 = deck seed (unadjusted, quirk 1)
+  int use_ddmc, do_feedback;
+  double tau_ddmc;
+  double c, sb;       // speed of light, Stefan-Boltzmann
+  double cv;          // IdealGas
+  double kappa_a;     // Gray
+  double kappa_s, apm;  // GrayS
+};
+
+struct DevSwarm {
+  double *x, *y, *z, *vx, *vy, *vz, *t, *w, *e;
+  int *ip, *jp, *kp, *blk, *status;
+  uint64_t *id;
+  uint32_t *ctr;
+};
+
+enum { ST_ACTIVE = 0, ST_ABSORBED = 1, ST_ESCAPED = 2, ST_OUTGOING = 3 };
+enum { BC_PERIODIC = 0, BC_REFLECT = 1, BC_OUTFLOW = 2 };
+
+// ---- EOS / opacity evaluated per event, device side (singularity IdealGas / Gray / GrayS;
+// reference mcblock.cpp:78-145, call sites transport.cpp:122-127) -----------------------------
+__device__ __forceinline__ double eos_temperature(const DevParams &P, double rho, double sie) {
+  (void)rho;
+  const double t = sie / P.cv;
+  return t > 0.0 ? t : 0.0;
+}
+__device__ __forceinline__ double opac_absorption(const DevParams &P, double rho, double temp,
+                                                  double nu) {
+  (void)temp; (void)nu;
+  return rho * P.kappa_a;
+}
+__device__ __forceinline__ double opac_emissivity(const DevParams &P, double rho, double temp) {
+  const double t2 = temp * temp;
+  return (rho * P.kappa_a) * ((4.0 * P.sb) * (t2 * t2));
+}
+__device__ __forceinline__ double opac_scattering(const DevParams &P, double rho, double temp,
+                                                  double nu) {
+  (void)temp; (void)nu;
+  return (rho / P.apm) * P.kappa_s;
+}
+
+// ---- per-lane copy of the current block's geometry ---------------------------------------------
+struct Blk {
+  double xmin[3], dx[3], x0[3];  // x0 = coordinate of index 0 (first ghost) per dimension
+  double dx_push;                // min(dx1, dx2, dx3)  (transport.cpp:75-78)
+};
+
+__device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
+  const int first[3] = {M.is, M.js, M.ks};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    B.xmin[d] = M.blk_xmin[3 * b + d];
+    B.dx[d] = M.blk_dx[3 * b + d];
+    B.x0[d] = B.xmin[d] - (double)first[d] * B.dx[d];
+  }
+  B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));
+}
+
+// Parthenon UniformCartesian: Xc(idx) = x0 + (idx + 0.5) dx
+__device__ __forceinline__ double xc(const Blk &B, int d, int idx) {
+  return B.x0[d] + ((double)idx + 0.5) * B.dx[d];
+}
+
+// SwarmDeviceContext::Xtoijk (transport.cpp:96,146)
+template <int NDIM>
+__device__ __forceinline__ void xtoijk(const DevMesh &M, const Blk &B, double x, double y, double z,
+                                       int &i, int &j, int &k) {
+  i = (int)floor((x - B.xmin[0]) / B.dx[0]) + M.is;
+  j = (NDIM >= 2) ? (int)floor((y - B.xmin[1]) / B.dx[1]) + M.js : M.js;
+  k = (NDIM >= 3) ? (int)floor((z - B.xmin[2]) / B.dx[2]) + M.ks : M.ks;
+}
+
+__device__ __forceinline__ bool on_block(const DevMesh &M, int i, int j, int k) {
+  return i >= M.is && i <= M.ie && j >= M.js && j <= M.je && k >= M.ks && k <= M.ke;
+}
+
+__device__ __forceinline__ long long cidx(const DevMesh &M, int k, int j, int i) {
+  return ((long long)k * M.nj + j) * M.ni + i;
+}
+
+// ---- comm phase applied to one particle in flight ----------------------------------------------
+// PhotonReflectBC (boundaries.hpp:46-82) + Parthenon's periodic / outflow swarm boundaries.
+// Returns false when the particle leaves through an outflow face.
+template <int NDIM>
+__device__ __forceinline__ bool apply_swarm_bcs(const DevMesh &M, double &x, double &y, double &z,
+                                                double &vx, double &vy, double &vz) {
+  double *p[3] = {&x, &y, &z};
+  double *v[3] = {&vx, &vy, &vz};
+#pragma unroll
+  for (int d = 0; d < NDIM; ++d) {
+    if (*p[d] < M.gmin[d]) {
+      const int bc = M.bc[2 * d];
+      if (bc == BC_REFLECT) {
+        *p[d] = M.gmin[d] + (M.gmin[d] - *p[d]);
+        *v[d] = -*v[d];
+      } else if (bc == BC_PERIODIC) {
+        *p[d] = M.gmax[d] - (M.gmin[d] - *p[d]);
+      } else {
+        return false;
+      }
+    }
+    if (*p[d] > M.gmax[d]) {
+      const int bc = M.bc[2 * d + 1];
+      if (bc == BC_REFLECT) {
+        *p[d] = M.gmax[d] - (*p[d] - M.gmax[d]);
+        *v[d] = -*v[d];
+      } else if (bc == BC_PERIODIC) {
+        *p[d] = M.gmin[d] + (*p[d] - M.gmax[d]);
+      } else {
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+// destination block = leaf that contains the point (GetNeighborBlockIndex + Swarm::Send)
+template <int NDIM>
+__device__ __forceinline__ int find_block(const DevMesh &M, double x, double y, double z) {
+  const double p[3] = {x, y, z};
+  int l[3] = {0, 0, 0};
+#pragma unroll
+  for (int d = 0; d < NDIM; ++d) {
+    const double len = (M.gmax[d] - M.gmin[d]) / (double)M.nleaf[d];
+    int q = (int)floor((p[d] - M.gmin[d]) / len);
+    q = q < 0 ? 0 : q;
+    q = q > M.nleaf[d] - 1 ? M.nleaf[d] - 1 : q;
+    l[d] = q;
+  }
+  return M.leaf_map[((long long)l[2] * M.nleaf[1] + l[1]) * M.nleaf[0] + l[0]];
+}
+
+template <int D>
+__device__ __forceinline__ double &pick(double &a, double &b, double &c) {
+  if constexpr (D == 0) return a;
+  else if constexpr (D == 1) return b;
+  else return c;
+}
+template <int D>
+__device__ __forceinline__ int &picki(int &a, int &b, int &c) {
+  if constexpr (D == 0) return a;
+  else if constexpr (D == 1) return b;
+  else return c;
+}
+
+// One face-normal axis A of SampleDDMCBlockFace (sample_ddmc_bface.cpp:167-222 in 2-D,
+// :294-410 in 3-D).  Returns true if the particle sat at a block face normal to A.
+template <int NDIM, int A, class Rng>
+__device__ __forceinline__ bool bface_axis(const DevMesh &M, const Blk &B, int b,
+                                           const double *F, Rng &rng, double vv, double &x,
+                                           double &y, double &z, double &vx, double &vy, double &vz,
+                                           int &ip, int &jp, int &kp) {
+  constexpr int A1 = (A + 1) % 3, A2 = (A + 2) % 3;
+  const double eps = kEps;
+  const double da = B.dx[A];
+  const double pa = pick<A>(x, y, z);
+  const bool at_min = fuzzy_equal(pa, M.blk_xmin[3 * b + A] + 2.0 * kEpsDdmc * da, da, eps);
+  const bool at_max = fuzzy_equal(pa, M.blk_xmax[3 * b + A] - 2.0 * kEpsDdmc * da, da, eps);
+  if (!(at_min || at_max)) return false;
+
+  const double dir_sgn = at_min ? 1.0 : -1.0;
+  sample_face_iso_dir(dir_sgn * vv, rng, pick<A>(vx, vy, vz), pick<A1>(vx, vy, vz),
+                      pick<A2>(vx, vy, vz));
+  int f[3] = {ip, jp, kp};
+  f[A] = at_min ? f[A] : f[A] + 1;
+
+  if constexpr (NDIM == 2) {
+    constexpr int T = (A == 0) ? 1 : 0;
+    const double dt_ = B.dx[T];
+    int &it = picki<T>(ip, jp, kp);
+    double &pt = pick<T>(x, y, z);
+    const double lo = xc(B, T, it) - 0.5 * dt_;
+    const bool edge_u = fuzzy_equal(pt, lo, dt_, eps);
+    const bool edge_l = fuzzy_equal(pt, lo + dt_, dt_, eps);
+    if (edge_u || edge_l) {
+      const int t_u = edge_u ? it : it + 1;
+      const int t_l = edge_u ? it - 1 : it;
+      int iu[3] = {f[0], f[1], f[2]}, il[3] = {f[0], f[1], f[2]};
+      iu[T] = t_u;
+      il[T] = t_l;
+      const double P_u = F[cidx(M, iu[2], iu[1], iu[0])];
+      const double P_l = F[cidx(M, il[2], il[1], il[0])];
+      sample_face_2d(t_l, dt_, P_l, P_u, rng, it, pt);
+    }
+  } else if constexpr (NDIM == 3) {
+    constexpr int T1 = (A == 0) ? 1 : 0;
+    constexpr int T2 = (A == 2) ? 1 : 2;
+    const double d1 = B.dx[T1], d2 = B.dx[T2];
+    int &i1 = picki<T1>(ip, jp, kp);
+    int &i2 = picki<T2>(ip, jp, kp);
+    double &p1 = pick<T1>(x, y, z);
+    double &p2 = pick<T2>(x, y, z);
+    const double lo1 = xc(B, T1, i1) - 0.5 * d1;
+    const double lo2 = xc(B, T2, i2) - 0.5 * d2;
+    const bool e1u = fuzzy_equal(p1, lo1, d1, eps), e1l = fuzzy_equal(p1, lo1 + d1, d1, eps);
+    const bool e2u = fuzzy_equal(p2, lo2, d2, eps), e2l = fuzzy_equal(p2, lo2 + d2, d2, eps);
+    if ((e1u || e1l) && (e2u || e2l)) {
+      const int t1_u = e1u ? i1 : i1 + 1, t1_l = e1u ? i1 - 1 : i1;
+      const int t2_u = e2u ? i2 : i2 + 1, t2_l = e2u ? i2 - 1 : i2;
+      double Pq[2][2];  // [T2 lower/upper][T1 lower/upper]
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+        for (int q1 = 0; q1 < 2; ++q1) {
+          int id[3] = {f[0], f[1], f[2]};
+          id[T1] = q1 ? t1_u : t1_l;
+          id[T2] = q2 ? t2_u : t2_l;
+          Pq[q2][q1] = F[cidx(M, id[2], id[1], id[0])];
+        }
+      sample_face_3d(t1_l, t2_l, d1, d2, Pq[0][0], Pq[0][1], Pq[1][0], Pq[1][1], rng, i1, i2, p1,
+                     p2);
+    }
+  }
+  return true;
+}
+
+// SampleDDMCBlockFace for one particle (sample_ddmc_bface.cpp:119-424).
+template <int NDIM, class Rng>
+__device__ __forceinline__ void sample_block_face(const DevMesh &M, const DevParams &P,
+                                                  const Blk &B, int b, Rng &rng, double &x,
+                                                  double &y, double &z, double &vx, double &vy,
+                                                  double &vz, int &ip, int &jp, int &kp) {
+  if constexpr (NDIM >= 2) {
+    const double vv = P.c;
+    if (!(vx * vx + vy * vy + vz * vz < kEps * vv * vv)) return;
+    xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);
+    if (bface_axis<NDIM, 0>(M, B, b, M.P1[b], rng, vv, x, y, z, vx, vy, vz, ip, jp, kp)) return;
+    if (bface_axis<NDIM, 1>(M, B, b, M.P2[b], rng, vv, x, y, z, vx, vy, vz, ip, jp, kp)) return;
+    if constexpr (NDIM == 3)
+      bface_axis<NDIM, 2>(M, B, b, M.P3[b], rng, vv, x, y, z, vx, vy, vz, ip, jp, kp);
+  }
+}
+
+}  // namespace jb

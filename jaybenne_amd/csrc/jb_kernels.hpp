@@ -1,0 +1,601 @@
+// jb_kernels.hpp -- HIP kernels of the history loop for gfx950 (wave64).
+//
+// Kernel              reference launch site it replaces
+// k_fleck             "UpdateDerivedTransportFields::Fleck-Factor"   jaybenne.cpp:304-316
+// k_face_prob<D>      "...::X{1,2,3}-DDMC-Prob"                      jaybenne.cpp:336-487
+// k_source_count      "SourcePhotons1"                               sourcing.cpp:73-119
+// k_source_fill       "SourcePhotons2"                               sourcing.cpp:141-205
+// k_transport         "TransportPhotons" / "TransportPhotons_DDMC"   transport.cpp:67-174,
+//                     + PhotonReflectBC, swarm send/receive to local  transport_ddmc.cpp:69-230,
+//                     blocks, SampleDDMCBlockFace, CheckCompletion    boundaries.hpp:36-83,
+//                     and (optionally) FillEnergyTally, fused         jaybenne.cpp:547-561
+// k_block_face        "SampleDDMCBlockFace::2D/3D"                   sample_ddmc_bface.cpp:120-423
+// k_check_completion  "CheckCompletion"                              transport.cpp:198-209
+// k_zero_tally/k_tally "ZeroEnergyTally"/"FillEnergyTally"           jaybenne.cpp:540-561
+// k_update_fluid      "UpdateFluid"                                  jaybenne.cpp:603-612
+// k_reflect_bc        PhotonReflectBC<BFACE>                         boundaries.hpp:36-83
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "jb_device.hpp"
+
+namespace jb {
+
+constexpr int kBlock = 256;  // 4 waves per workgroup
+
+// counters[]: 0 census, 1 absorbed, 2 escaped, 3 outgoing, 4 events, 5 unfinished
+enum { CNT_CENSUS = 0, CNT_ABSORBED, CNT_ESCAPED, CNT_OUTGOING, CNT_EVENTS, CNT_UNFINISHED, CNT_N };
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// interior cell (b, k, j, i) of flat index c over nblocks * ncell
+__device__ __forceinline__ void decode_cell(const DevMesh &M, long long c, int &b, int &k, int &j,
+                                            int &i, int &cell) {
+  b = (int)(c / M.ncell);
+  cell = (int)(c - (long long)b * M.ncell);
+  k = cell / (M.nx[0] * M.nx[1]);
+  const int r = cell - k * (M.nx[0] * M.nx[1]);
+  j = r / M.nx[0];
+  i = r - j * M.nx[0];
+  k += M.ks;
+  j += M.js;
+  i += M.is;
+}
+
+// -------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_fleck(DevMesh M, DevParams P, double dt) {
+  const long long total = (long long)M.nblocks * M.ncell;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+       c += (long long)gridDim.x * blockDim.x) {
+    int b, k, j, i, cell;
+    decode_cell(M, c, b, k, j, i, cell);
+    const long long q = cidx(M, k, j, i);
+    const double rho = M.rho[b][q];
+    const double temp = eos_temperature(P, rho, M.sie[b][q]);
+    const double emis = opac_emissivity(P, rho, temp);
+    M.fleck[b][q] = 1.0 / (1.0 + (4.0 * emis / (rho * P.cv * temp)) * dt);
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(kBlock) k_face_prob(DevMesh M, DevParams P) {
+  // faces normal to D: interior cells plus one extra layer in D
+  const int n0 = M.nx[0] + (D == 0), n1 = M.nx[1] + (D == 1), n2 = M.nx[2] + (D == 2);
+  const long long per_block = (long long)n0 * n1 * n2;
+  const long long total = per_block * M.nblocks;
+  double *const *F = (D == 0) ? M.P1 : (D == 1 ? M.P2 : M.P3);
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+       c += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(c / per_block);
+    long long r = c - (long long)b * per_block;
+    const int k = (int)(r / ((long long)n0 * n1)) + M.ks;
+    r -= (long long)(k - M.ks) * n0 * n1;
+    const int j = (int)(r / n0) + M.js;
+    const int i = (int)(r - (long long)(j - M.js) * n0) + M.is;
+    const double dxd = M.blk_dx[3 * b + D];
+    const double rlev = (double)M.blk_level[b];
+    const double rlev_l = (double)M.blk_nbr_lev[6 * b + 2 * D];
+    const double rlev_u = (double)M.blk_nbr_lev[6 * b + 2 * D + 1];
+    const int f = (D == 0) ? i : (D == 1 ? j : k);
+    const int fs = (D == 0) ? M.is : (D == 1 ? M.js : M.ks);
+    const int fu = ((D == 0) ? M.ie : (D == 1 ? M.je : M.ke)) + 1;
+    // std::pow(2.0, integer difference) is exact: ldexp
+    const double dx_l = (f == fs) ? ldexp(1.0, (int)(rlev - rlev_l)) * dxd : dxd;
+    const double dx_u = (f == fu) ? ldexp(1.0, (int)(rlev - rlev_u)) * dxd : dxd;
+    const long long cl = cidx(M, k - (D == 2), j - (D == 1), i - (D == 0));
+    const long long cu = cidx(M, k, j, i);
+    const double rho_l = M.rho[b][cl], rho_u = M.rho[b][cu];
+    const double temp_l = eos_temperature(P, rho_l, M.sie[b][cl]);
+    const double temp_u = eos_temperature(P, rho_u, M.sie[b][cu]);
+    const double ss_l = opac_scattering(P, rho_l, temp_l, 1.0);
+    const double aa_l = opac_absorption(P, rho_l, temp_l, 1.0);
+    const double ss_u = opac_scattering(P, rho_u, temp_u, 1.0);
+    const double aa_u = opac_absorption(P, rho_u, temp_u, 1.0);
+    double tau_l = dx_l * (ss_l + aa_l);
+    double tau_u = dx_u * (ss_u + aa_u);
+    tau_l = tau_l > P.tau_ddmc ? tau_l : 2.0 * kLamExt;
+    tau_u = tau_u > P.tau_ddmc ? tau_u : 2.0 * kLamExt;
+    F[b][cu] = 2.0 / (3.0 * (tau_l + tau_u));
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// SourcePhotons phase 1: one workgroup per block.  Per cell: energy to source, stochastically
+// rounded particle count (1 draw from the cell's own stream), energy weight; then an exclusive
+// scan over the block's cells in (k,j,i) order (wave scan + LDS across the 4 waves + running
+// carry over chunks of 256 cells).
+__device__ __forceinline__ uint64_t cell_stream_id(uint32_t epoch, int gblock, int cell) {
+  return ((uint64_t)epoch << 44) | ((uint64_t)(uint32_t)gblock << 24) | (uint64_t)(uint32_t)cell;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_source_count(DevMesh M, DevParams P, int source_type, double dt, double npc, uint32_t epoch,
+                   int *nper_block, int *prefix) {
+  __shared__ int wave_tot[kBlock / 64];
+  __shared__ int carry_s;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double dv = M.blk_dx[3 * b] * M.blk_dx[3 * b + 1] * M.blk_dx[3 * b + 2];
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < M.ncell; base += kBlock) {
+    const int cell = base + threadIdx.x;
+    int cnt = 0;
+    if (cell < M.ncell) {
+      int k = cell / (M.nx[0] * M.nx[1]);
+      const int r = cell - k * (M.nx[0] * M.nx[1]);
+      int j = r / M.nx[0];
+      int i = r - j * M.nx[0];
+      k += M.ks; j += M.js; i += M.is;
+      const long long q = cidx(M, k, j, i);
+      PhiloxRng rng(P.key0, 1u, cell_stream_id(epoch, M.gid[b], cell), 0u);
+      const double rho = M.rho[b][q];
+      const double temp = eos_temperature(P, rho, M.sie[b][q]);
+      double erad;
+      if (source_type == 0) {  // thermal: (4 sb / c) T^4 dV   (sourcing.cpp:93)
+        const double t2 = temp * temp;
+        erad = (4.0 * P.sb / P.c) * (t2 * t2) * dv;
+      } else {  // emission: f j dV dt   (sourcing.cpp:95-96)
+        erad = M.fleck[b][q] * opac_emissivity(P, rho, temp) * dv * dt;
+      }
+      double snpc = floor(npc);
+      snpc += (double)((npc - snpc) > rng.drand());
+      M.src_num[b][q] = snpc;
+      M.src_ew[b][q] = erad / snpc;
+      cnt = (int)rint(snpc);
+    }
+    // inclusive scan within the wave
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < wv; ++w) wave_off += wave_tot[w];
+    const int carry = carry_s;
+    if (cell < M.ncell) prefix[(long long)b * M.ncell + cell] = carry + wave_off + incl - cnt;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) carry_s = carry + wave_off + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) nper_block[b] = carry_s;
+}
+
+// SourcePhotons phase 2: one thread per NEW PARTICLE (the reference runs one thread per cell with
+// a serial loop over that cell's particles, sourcing.cpp:167-202).  blk_first[b] = number of new
+// particles in blocks < b; the cell is found by bisection in the block's prefix array.
+__global__ void __launch_bounds__(kBlock)
+    k_source_fill(DevMesh M, DevParams P, DevSwarm S, int source_type, double t_start, double dt,
+                  const int *prefix, const long long *blk_first, const long long *slot_base,
+                  const unsigned long long *id_base, long long total) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+       g += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = M.nblocks - 1;  // last b with blk_first[b] <= g
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (blk_first[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    const int b = lo;
+    const int np = (int)(g - blk_first[b]);
+    const int *pf = prefix + (long long)b * M.ncell;
+    lo = 0; hi = M.ncell - 1;  // last cell with pf[cell] <= np (empty cells share a prefix value:
+                               // the LAST of them that still satisfies <= is the non-empty one)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pf[mid] <= np) lo = mid; else hi = mid - 1;
+    }
+    const int cell = lo;
+    int k = cell / (M.nx[0] * M.nx[1]);
+    const int r = cell - k * (M.nx[0] * M.nx[1]);
+    int j = r / M.nx[0];
+    int i = r - j * M.nx[0];
+    k += M.ks; j += M.js; i += M.is;
+    const long long q = cidx(M, k, j, i);
+    Blk B;
+    load_block(M, b, B);
+    const long long n = slot_base[b] + np;
+    const uint64_t id = id_base[b] + (uint64_t)np;
+    PhiloxRng rng(P.key0, 0u, id, 0u);
+    S.ip[n] = i; S.jp[n] = j; S.kp[n] = k;
+    S.blk[n] = b;
+    S.status[n] = ST_ACTIVE;
+    // draw order of sourcing.cpp:175-198: x, y, z; theta, phi; Planck (5); emission: time
+    S.x[n] = xc(B, 0, i) + B.dx[0] * (rng.drand() - 0.5);
+    S.y[n] = xc(B, 1, j) + B.dx[1] * (rng.drand() - 0.5);
+    S.z[n] = xc(B, 2, k) + B.dx[2] * (rng.drand() - 0.5);
+    const double theta = m_acos(2.0 * rng.drand() - 1.0);
+    const double phi = kTwoPi * rng.drand();
+    double sth, cth, sph, cph;
+    m_sincos(theta, sth, cth);
+    m_sincos(phi, sph, cph);
+    S.vx[n] = P.c * sth * cph;
+    S.vy[n] = P.c * sth * sph;
+    S.vz[n] = P.c * cth;
+    const double rho = M.rho[b][q];
+    const double temp = eos_temperature(P, rho, M.sie[b][q]);
+    S.e[n] = sample_planck_energy(rng, P.sb, temp);
+    S.w[n] = M.src_ew[b][q];
+    if (source_type == 1) {
+      S.t[n] = t_start + rng.drand() * dt;
+    } else {
+      S.t[n] = 0.0;
+    }
+    S.id[n] = id;
+    S.ctr[n] = rng.ctr;
+  }
+}
+
+// energy_delta = -(sum of the cell's new weights), subtracting one weight at a time like the
+// reference's serial loop (sourcing.cpp:165-166,196); zero for the thermal source.
+__global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_type) {
+  const long long total = (long long)M.nblocks * M.ncell;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+       c += (long long)gridDim.x * blockDim.x) {
+    int b, k, j, i, cell;
+    decode_cell(M, c, b, k, j, i, cell);
+    const long long q = cidx(M, k, j, i);
+    double dej = 0.0;
+    if (source_type == 1) {
+      const int n = (int)rint(M.src_num[b][q]);
+      const double ew = M.src_ew[b][q];
+      for (int p = 0; p < n; ++p) dej -= ew;
+    }
+    M.edelta[b][q] = dej;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// The history loop.  One lane follows one particle from its state at t_start to census /
+// absorption / escape / departure to another rank; a wave owns 64 consecutive particles and
+// loops until all of them are done, then takes the next batch (grid stride).
+template <int NDIM, bool DDMC, bool TALLY>
+__global__ void __launch_bounds__(kBlock)
+    k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
+                long long last, unsigned long long *counters) {
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  const double vv = P.c;
+  unsigned long long c_census = 0, c_abs = 0, c_esc = 0, c_out = 0, c_ev = 0;
+
+  for (long long n = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; n < last;
+       n += (long long)gridDim.x * blockDim.x) {
+    if (S.status[n] != ST_ACTIVE) continue;
+    PhiloxRng rng(P.key0, 0u, S.id[n], S.ctr[n]);
+    int b = S.blk[n];
+    Blk B;
+    load_block(M, b, B);
+    double t = S.t[n];
+    double x = S.x[n], y = S.y[n], z = S.z[n];
+    double vx = S.vx[n], vy = S.vy[n], vz = S.vz[n];
+    const double ee = S.e[n];
+    int ip, jp, kp;
+    int status = ST_ACTIVE;
+    xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:96
+
+    while (t < t_start + dt) {
+      ++c_ev;
+      Step s;
+      s.t_start = t_start; s.dt = dt; s.vv = vv; s.dx_push = B.dx_push;
+      // cell faces from cell centres (transport.cpp:114-119)
+      s.xl = xc(B, 0, ip) - 0.5 * B.dx[0];
+      s.xu = xc(B, 0, ip) + 0.5 * B.dx[0];
+      s.yl = xc(B, 1, jp) - 0.5 * B.dx[1];
+      s.yu = xc(B, 1, jp) + 0.5 * B.dx[1];
+      s.zl = xc(B, 2, kp) - 0.5 * B.dx[2];
+      s.zu = xc(B, 2, kp) + 0.5 * B.dx[2];
+      const long long q = cidx(M, kp, jp, ip);
+      const double rho = M.rho[b][q];
+      const double temp = eos_temperature(P, rho, M.sie[b][q]);
+      s.ff = M.fleck[b][q];
+      s.ss = opac_scattering(P, rho, temp, ee);
+      s.aa = opac_absorption(P, rho, temp, ee);
+      s.t = t; s.x = x; s.y = y; s.z = z; s.vx = vx; s.vy = vy; s.vz = vz;
+      s.ip = ip; s.jp = jp; s.kp = kp;
+      s.is_absorbed = false; s.is_scattered = false; s.is_rejected = false;
+
+      bool is_ddmc_step = false;
+      if constexpr (DDMC) is_ddmc_step = B.dx_push * (s.ss + s.aa) > P.tau_ddmc;
+      if (DDMC && is_ddmc_step) {
+        // transport_ddmc.cpp:137-179
+        s.Px_l = M.P1[b][q];
+        s.Px_u = M.P1[b][cidx(M, kp, jp, ip + 1)];
+        s.Py_l = multi_d ? M.P2[b][q] : 0.0;
+        s.Py_u = multi_d ? M.P2[b][cidx(M, kp, jp + 1, ip)] : 0.0;
+        s.Pz_l = three_d ? M.P3[b][q] : 0.0;
+        s.Pz_u = three_d ? M.P3[b][cidx(M, kp + 1, jp, ip)] : 0.0;
+        ptcl_ddmc_albedo<NDIM>(s, rng);
+        if (!s.is_rejected) ptcl_ddmc_step<NDIM>(s, rng);
+      } else {
+        ptcl_transport_step<NDIM>(s, rng);
+      }
+      t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
+
+      xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:146
+
+      if (!on_block(M, ip, jp, kp)) {
+        if constexpr (DDMC) {  // transport_ddmc.cpp:203-211: zero velocity flags a DDMC leak
+          const double vmask = (is_ddmc_step && multi_d && !s.is_rejected) ? 0.0 : 1.0;
+          vx *= vmask; vy *= vmask; vz *= vmask;
+        }
+        // ---- comm phase, in flight ----
+        if (!apply_swarm_bcs<NDIM>(M, x, y, z, vx, vy, vz)) {
+          status = ST_ESCAPED;
+          break;
+        }
+        const int g = find_block<NDIM>(M, x, y, z);
+        if (M.owner[g] != M.rank) {
+          status = ST_OUTGOING;
+          b = g;  // global id travels in blk
+          break;
+        }
+        b = M.local_index[g];
+        load_block(M, b, B);
+        if constexpr (DDMC && multi_d)
+          sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
+        xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // next launch's transport.cpp:96
+        continue;
+      }
+      if (s.is_absorbed) {  // transport.cpp:157-163
+        atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
+        status = ST_ABSORBED;
+        break;
+      }
+      if (s.is_scattered) scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
+    }
+
+    S.blk[n] = b;
+    S.t[n] = t;
+    S.x[n] = x; S.y[n] = y; S.z[n] = z;
+    S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+    S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
+    S.status[n] = status;
+    S.ctr[n] = rng.ctr;
+
+    if (status == ST_ACTIVE) {
+      ++c_census;
+      if constexpr (TALLY) {  // jaybenne.cpp:547-561
+        const double dv = B.dx[0] * B.dx[1] * B.dx[2];
+        atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
+      }
+    } else if (status == ST_ABSORBED) {
+      ++c_abs;
+    } else if (status == ST_ESCAPED) {
+      ++c_esc;
+    } else {
+      ++c_out;
+    }
+  }
+
+  c_census = wave_sum(c_census);
+  c_abs = wave_sum(c_abs);
+  c_esc = wave_sum(c_esc);
+  c_out = wave_sum(c_out);
+  c_ev = wave_sum(c_ev);
+  if ((threadIdx.x & 63) == 0) {
+    if (c_census) atomicAdd(&counters[CNT_CENSUS], c_census);
+    if (c_abs) atomicAdd(&counters[CNT_ABSORBED], c_abs);
+    if (c_esc) atomicAdd(&counters[CNT_ESCAPED], c_esc);
+    if (c_out) atomicAdd(&counters[CNT_OUTGOING], c_out);
+    if (c_ev) atomicAdd(&counters[CNT_EVENTS], c_ev);
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+template <int NDIM>
+__global__ void __launch_bounds__(kBlock)
+    k_block_face(DevMesh M, DevParams P, DevSwarm S, long long first, long long last) {
+  for (long long n = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; n < last;
+       n += (long long)gridDim.x * blockDim.x) {
+    if (S.status[n] != ST_ACTIVE) continue;
+    const int b = S.blk[n];
+    Blk B;
+    load_block(M, b, B);
+    PhiloxRng rng(P.key0, 0u, S.id[n], S.ctr[n]);
+    double x = S.x[n], y = S.y[n], z = S.z[n];
+    double vx = S.vx[n], vy = S.vy[n], vz = S.vz[n];
+    int ip = S.ip[n], jp = S.jp[n], kp = S.kp[n];
+    sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
+    S.x[n] = x; S.y[n] = y; S.z[n] = z;
+    S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+    S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
+    S.ctr[n] = rng.ctr;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_check_completion(DevSwarm S, long long n_total, double t_end, unsigned long long *counters) {
+  unsigned long long c = 0;
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
+       n += (long long)gridDim.x * blockDim.x)
+    if (S.status[n] == ST_ACTIVE && S.t[n] < t_end) ++c;
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counters[CNT_UNFINISHED], c);
+}
+
+__global__ void __launch_bounds__(kBlock) k_zero_tally(DevMesh M) {
+  const long long total = (long long)M.nblocks * M.ncell;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+       c += (long long)gridDim.x * blockDim.x) {
+    int b, k, j, i, cell;
+    decode_cell(M, c, b, k, j, i, cell);
+    M.tally[b][cidx(M, k, j, i)] = 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_tally(DevMesh M, DevSwarm S, long long n_total) {
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
+       n += (long long)gridDim.x * blockDim.x) {
+    if (S.status[n] != ST_ACTIVE) continue;
+    const int b = S.blk[n];
+    const double dv = M.blk_dx[3 * b] * M.blk_dx[3 * b + 1] * M.blk_dx[3 * b + 2];
+    atomicAdd(&M.tally[b][cidx(M, S.kp[n], S.jp[n], S.ip[n])], S.w[n] / dv);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_update_fluid(DevMesh M) {
+  const long long total = (long long)M.nblocks * M.ncell;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+       c += (long long)gridDim.x * blockDim.x) {
+    int b, k, j, i, cell;
+    decode_cell(M, c, b, k, j, i, cell);
+    const long long q = cidx(M, k, j, i);
+    const double dv = M.blk_dx[3 * b] * M.blk_dx[3 * b + 1] * M.blk_dx[3 * b + 2];
+    const double delta = M.edelta[b][q] / dv;
+    M.u[b][q] += delta;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_reflect_bc(DevMesh M, DevSwarm S, long long n_total, int face) {
+  const int d = face >> 1, outer = face & 1;
+  double *pos = (d == 0) ? S.x : (d == 1 ? S.y : S.z);
+  double *vel = (d == 0) ? S.vx : (d == 1 ? S.vy : S.vz);
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
+       n += (long long)gridDim.x * blockDim.x) {
+    if (S.status[n] != ST_ACTIVE) continue;
+    double q = pos[n];
+    bool hit = false;
+    if (!outer && q < M.gmin[d]) {
+      q = M.gmin[d] + (M.gmin[d] - q);
+      hit = true;
+    } else if (outer && q > M.gmax[d]) {
+      q = M.gmax[d] - (q - M.gmax[d]);
+      hit = true;
+    }
+    if (hit) {
+      pos[n] = q;
+      vel[n] = -vel[n];
+      Blk B;
+      load_block(M, S.blk[n], B);
+      int i, j, k;
+      if (M.ndim == 1) xtoijk<1>(M, B, S.x[n], S.y[n], S.z[n], i, j, k);
+      else if (M.ndim == 2) xtoijk<2>(M, B, S.x[n], S.y[n], S.z[n], i, j, k);
+      else xtoijk<3>(M, B, S.x[n], S.y[n], S.z[n], i, j, k);
+      S.ip[n] = i; S.jp[n] = j; S.kp[n] = k;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// RemoveMarkedParticles: survivors S = #ACTIVE in [0,n).  Holes (non-ACTIVE slots below S) are
+// filled by movers (ACTIVE slots at or above S); both lists are built with wave-aggregated
+// atomics (ballot + popcount prefix), so which mover fills which hole is unordered -- harmless,
+// every particle carries its own random stream.
+__device__ __forceinline__ long long wave_slot(bool pred, unsigned long long *cursor) {
+  const unsigned long long mask = __ballot(pred);
+  const int lane = threadIdx.x & 63;
+  long long base = 0;
+  if (mask) {
+    const int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = (long long)atomicAdd(cursor, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader, 64);
+  }
+  return base + __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_count_active(DevSwarm S, long long n_total, unsigned long long *cursor) {
+  unsigned long long c = 0;
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
+       n += (long long)gridDim.x * blockDim.x)
+    if (S.status[n] == ST_ACTIVE) ++c;
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(cursor, c);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_list_holes_movers(DevSwarm S, long long n_total, long long survivors, long long *holes,
+                        long long *movers, unsigned long long *cursors) {
+  const long long span = ((n_total + kBlock - 1) / kBlock) * kBlock;  // keep waves converged
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < span;
+       n += (long long)gridDim.x * blockDim.x) {
+    const bool valid = n < n_total;
+    const bool active = valid && S.status[n] == ST_ACTIVE;
+    const bool hole = valid && !active && n < survivors;
+    const bool mover = active && n >= survivors;
+    const long long hs = wave_slot(hole, &cursors[0]);
+    if (hole) holes[hs] = n;
+    const long long ms = wave_slot(mover, &cursors[1]);
+    if (mover) movers[ms] = n;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_fill_holes(DevSwarm S, const long long *holes, const long long *movers, long long count) {
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < count;
+       q += (long long)gridDim.x * blockDim.x) {
+    const long long d = holes[q], s = movers[q];
+    S.x[d] = S.x[s]; S.y[d] = S.y[s]; S.z[d] = S.z[s];
+    S.vx[d] = S.vx[s]; S.vy[d] = S.vy[s]; S.vz[d] = S.vz[s];
+    S.t[d] = S.t[s]; S.w[d] = S.w[s]; S.e[d] = S.e[s];
+    S.ip[d] = S.ip[s]; S.jp[d] = S.jp[s]; S.kp[d] = S.kp[s];
+    S.blk[d] = S.blk[s]; S.status[d] = ST_ACTIVE;
+    S.id[d] = S.id[s]; S.ctr[d] = S.ctr[s];
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// Inter-rank hand-off records: 13 x 8 bytes
+//   0..8  x y z vx vy vz t w e   9 id   10 (ip | jp << 32)   11 (kp | gblock << 32)   12 ctr
+constexpr int kRecWords = 13;
+
+__global__ void __launch_bounds__(kBlock)
+    k_count_outgoing(DevMesh M, DevSwarm S, long long n_total, unsigned long long *per_rank) {
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
+       n += (long long)gridDim.x * blockDim.x)
+    if (S.status[n] == ST_OUTGOING) atomicAdd(&per_rank[M.owner[S.blk[n]]], 1ull);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_pack_outgoing(DevMesh M, DevSwarm S, long long n_total, const long long *rank_first,
+                    unsigned long long *rank_cursor, long long *rec) {
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
+       n += (long long)gridDim.x * blockDim.x) {
+    if (S.status[n] != ST_OUTGOING) continue;
+    const int g = S.blk[n];
+    const int r = M.owner[g];
+    const long long slot = rank_first[r] + (long long)atomicAdd(&rank_cursor[r], 1ull);
+    long long *o = rec + slot * kRecWords;
+    o[0] = __double_as_longlong(S.x[n]); o[1] = __double_as_longlong(S.y[n]);
+    o[2] = __double_as_longlong(S.z[n]); o[3] = __double_as_longlong(S.vx[n]);
+    o[4] = __double_as_longlong(S.vy[n]); o[5] = __double_as_longlong(S.vz[n]);
+    o[6] = __double_as_longlong(S.t[n]); o[7] = __double_as_longlong(S.w[n]);
+    o[8] = __double_as_longlong(S.e[n]);
+    o[9] = (long long)S.id[n];
+    o[10] = (long long)(((unsigned long long)(unsigned)S.jp[n] << 32) | (unsigned)S.ip[n]);
+    o[11] = (long long)(((unsigned long long)(unsigned)g << 32) | (unsigned)S.kp[n]);
+    o[12] = (long long)S.ctr[n];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_unpack_incoming(DevMesh M, DevSwarm S, long long first_slot, const long long *rec,
+                      long long nrec) {
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nrec;
+       q += (long long)gridDim.x * blockDim.x) {
+    const long long *o = rec + q * kRecWords;
+    const long long n = first_slot + q;
+    S.x[n] = __longlong_as_double(o[0]); S.y[n] = __longlong_as_double(o[1]);
+    S.z[n] = __longlong_as_double(o[2]); S.vx[n] = __longlong_as_double(o[3]);
+    S.vy[n] = __longlong_as_double(o[4]); S.vz[n] = __longlong_as_double(o[5]);
+    S.t[n] = __longlong_as_double(o[6]); S.w[n] = __longlong_as_double(o[7]);
+    S.e[n] = __longlong_as_double(o[8]);
+    S.id[n] = (uint64_t)o[9];
+    S.ip[n] = (int)(unsigned)(o[10] & 0xffffffffll);
+    S.jp[n] = (int)(unsigned)((unsigned long long)o[10] >> 32);
+    S.kp[n] = (int)(unsigned)(o[11] & 0xffffffffll);
+    const int g = (int)(unsigned)((unsigned long long)o[11] >> 32);
+    S.blk[n] = M.local_index[g];
+    S.status[n] = ST_ACTIVE;
+    S.ctr[n] = (uint32_t)o[12];
+  }
+}
+
+}  // namespace jb

@@ -1,0 +1,313 @@
+// jb_physics.hpp -- per-event device functions of the IMC / DDMC history loop.
+//
+// What each function computes, the order of its floating-point operations and the order of its
+// random draws follow the reference (file:line given per function); they are templated on the
+// dimensionality so that the multi_d / three_d gates of the reference fold at compile time, and
+// on the random source (PhiloxRng in the product kernels, TapeRng in the debug entry points).
+#pragma once
+
+#include <float.h>
+#include <hip/hip_runtime.h>
+
+#include "jb_math.hpp"
+#include "jb_rng.hpp"
+
+namespace jb {
+
+// parthenon::robust::EPS() (un-vendored; 10 * machine epsilon assumed)
+constexpr double kEps = 10.0 * DBL_EPSILON;
+// reference transport_utils.hpp:24-25
+constexpr double kEpsImc = 1.0e6 * kEps;
+constexpr double kEpsDdmc = 1.0e8 * kEps;
+// reference transport_utils.hpp:282, jaybenne.cpp:326 (Habetler & Matkowski 1975)
+constexpr double kLamExt = 0.7104;
+constexpr double kTwoPi = 2.0 * 3.14159265358979323846;
+
+__device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }  // std::min
+
+// reference jaybenne_utils.hpp:44-49
+__device__ __forceinline__ bool fuzzy_equal(double a, double b, double c, double eps) {
+  return fabs(a - b) < c * eps;
+}
+
+// reference transport_utils.hpp:27-39 -- 2 draws
+template <class Rng>
+__device__ __forceinline__ void sample_face_iso_dir(double vv, Rng &rng, double &v1, double &v2,
+                                                    double &v3) {
+  const double mu = sqrt(rng.drand());
+  const double nu = sqrt(1.0 - mu * mu);
+  const double phi = kTwoPi * rng.drand();
+  double sn, cs;
+  m_sincos(phi, sn, cs);
+  v1 = vv * mu;
+  v2 = vv * nu * cs;
+  v3 = vv * nu * sn;
+}
+
+// reference scattering.hpp:21-29 -- 2 draws
+template <class Rng>
+__device__ __forceinline__ void scatter(Rng &rng, double vv, double &vx, double &vy, double &vz) {
+  const double mu = 2.0 * rng.drand() - 1.0;
+  const double phi = kTwoPi * rng.drand();
+  const double st = sqrt(1.0 - mu * mu);
+  double sn, cs;
+  m_sincos(phi, sn, cs);
+  vx = vv * st * cs;
+  vy = vv * st * sn;
+  vz = vv * mu;
+}
+
+// reference planck.hpp:26-50 (Everett & Cashwell 1972) -- 5 draws.  `sb` really is the
+// Stefan-Boltzmann constant there.
+template <class Rng>
+__device__ __forceinline__ double sample_planck_energy(Rng &rng, double sb, double temp) {
+  constexpr double kPi = 3.14159265358979323846;
+  const double xi0 = rng.drand();
+  const double rhs = xi0 * ((kPi * kPi) * (kPi * kPi)) / 90.0;
+  double ll = 1.0;
+  for (int l = 1; l < 100; ++l) {
+    double lhs = 0.0;
+    for (int j = 1; j <= l; ++j) {
+      const double dj = (double)j;
+      lhs += 1.0 / ((dj * dj) * (dj * dj));
+    }
+    if (lhs >= rhs) {
+      ll = (double)l;
+      break;
+    }
+  }
+  const double xi1 = rng.drand();
+  const double xi2 = rng.drand();
+  const double xi3 = rng.drand();
+  const double xi4 = rng.drand();
+  return -(1.0 / ll) * m_log(xi1 * xi2 * xi3 * xi4) * sb * temp;
+}
+
+// What one step reads and updates for one particle in one cell (kept in registers).
+struct Step {
+  double t_start, dt;
+  double ff, aa, ss, vv, dx_push;
+  double xl, yl, zl, xu, yu, zu;
+  double Px_l, Py_l, Pz_l, Px_u, Py_u, Pz_u;
+  double t, x, y, z, vx, vy, vz;
+  int ip, jp, kp;
+  bool is_absorbed, is_scattered, is_rejected;
+};
+
+// reference transport_utils.hpp:111-160 -- one IMC tracking step, 2 draws
+template <int NDIM, class Rng>
+__device__ __forceinline__ void ptcl_transport_step(Step &s, Rng &rng) {
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  const double rmin = DBL_MIN;
+  const double lam_abs = 1.0 / (s.ff * s.aa + rmin);
+  const double lam_sc = 1.0 / (s.ss + (1.0 - s.ff) * s.aa + rmin);
+  const double dx_abs = -lam_abs * m_log(rng.drand());
+  const double dx_sc = -lam_sc * m_log(rng.drand());
+  const double dx_end = s.vv * ((s.t_start + s.dt) - s.t);
+  double dx_push = dmin(s.dx_push, dx_end);
+  if (s.vx > 0.0)
+    dx_push = dmin(dx_push, s.vv * (s.xu - s.x) / s.vx);
+  else if (s.vx < 0.0)
+    dx_push = dmin(dx_push, s.vv * (s.xl - s.x) / s.vx);
+  if (multi_d) {
+    if (s.vy > 0.0)
+      dx_push = dmin(dx_push, s.vv * (s.yu - s.y) / s.vy);
+    else if (s.vy < 0.0)
+      dx_push = dmin(dx_push, s.vv * (s.yl - s.y) / s.vy);
+  }
+  if (three_d) {
+    if (s.vz > 0.0)
+      dx_push = dmin(dx_push, s.vv * (s.zu - s.z) / s.vz);
+    else if (s.vz < 0.0)
+      dx_push = dmin(dx_push, s.vv * (s.zl - s.z) / s.vz);
+  }
+
+  s.is_absorbed = (dx_abs < dx_push) && (dx_abs < dx_sc);
+  s.is_scattered = !s.is_absorbed && (dx_sc < dx_push);
+
+  const double dt_push = (s.is_absorbed ? dx_abs : (s.is_scattered ? dx_sc : dx_push)) / s.vv;
+
+  s.t += dt_push;
+  s.x += s.vx * dt_push;
+  s.y += (multi_d ? 1.0 : 0.0) * s.vy * dt_push;
+  s.z += (three_d ? 1.0 : 0.0) * s.vz * dt_push;
+
+  const double fdx = kEpsImc * (s.xu - s.xl);
+  const double fdy = kEpsImc * (s.yu - s.yl);
+  const double fdz = kEpsImc * (s.zu - s.zl);
+  if (fabs(s.x - s.xl) < fdx) s.x = s.xl - fdx;
+  if (fabs(s.x - s.xu) < fdx) s.x = s.xu + fdx;
+  if (multi_d && fabs(s.y - s.yl) < fdy) s.y = s.yl - fdy;
+  if (multi_d && fabs(s.y - s.yu) < fdy) s.y = s.yu + fdy;
+  if (three_d && fabs(s.z - s.zl) < fdz) s.z = s.zl - fdz;
+  if (three_d && fabs(s.z - s.zu) < fdz) s.z = s.zu + fdz;
+}
+
+// reference transport_utils.hpp:163-277 -- one DDMC step
+// draws: 1 (time); event: +1 (channel), leak: +2 (direction); census: +5
+template <int NDIM, class Rng>
+__device__ __forceinline__ void ptcl_ddmc_step(Step &s, Rng &rng) {
+  constexpr int multi_d = NDIM >= 2 ? 1 : 0, three_d = NDIM == 3 ? 1 : 0;
+  const double rmin = DBL_MIN;
+  const double eps = kEpsDdmc;
+  const double dx = s.xu - s.xl;
+  const double dy = s.yu - s.yl;
+  const double dz = s.zu - s.zl;
+
+  const double leakx_l = s.Px_l / dx;
+  const double leakx_u = s.Px_u / dx;
+  const double leaky_l = s.Py_l / dy;
+  const double leaky_u = s.Py_u / dy;
+  const double leakz_l = s.Pz_l / dz;
+  const double leakz_u = s.Pz_u / dz;
+  const double leak_tot = leakx_l + leakx_u + leaky_l + leaky_u + leakz_l + leakz_u;
+
+  const double cdf_ddmc = s.ff * s.aa + leak_tot + rmin;
+  const double dt_ddmc = -m_log(rng.drand()) / (s.vv * cdf_ddmc);
+  const double dt_end = (s.t_start + s.dt) - s.t;
+  const bool is_ddmc_event = dt_ddmc < dt_end;
+
+  s.t += dmin(dt_ddmc, dt_end);
+
+  if (is_ddmc_event) {
+    const double xi = cdf_ddmc * rng.drand();
+    if (xi < s.ff * s.aa) {
+      s.is_absorbed = true;
+    } else if (xi < s.ff * s.aa + leak_tot) {
+      const double xim = xi - s.ff * s.aa;
+      if (xim < leakx_l) {  // -x
+        s.ip -= 1;
+        s.x = s.xl - eps * dx;
+        s.y = s.yl + 0.5 * dy;
+        s.z = s.zl + 0.5 * dz;
+        sample_face_iso_dir(-s.vv, rng, s.vx, s.vy, s.vz);
+      } else if (xim < leakx_l + leakx_u) {  // +x
+        s.ip += 1;
+        s.x = s.xu + eps * dx;
+        s.y = s.yl + 0.5 * dy;
+        s.z = s.zl + 0.5 * dz;
+        sample_face_iso_dir(s.vv, rng, s.vx, s.vy, s.vz);
+      } else if (xim < leakx_l + leakx_u + leaky_l) {  // -y
+        s.jp -= multi_d;
+        s.y = s.yl - eps * dy;
+        s.z = s.zl + 0.5 * dz;
+        s.x = s.xl + 0.5 * dx;
+        sample_face_iso_dir(-s.vv, rng, s.vy, s.vz, s.vx);
+      } else if (xim < leakx_l + leakx_u + leaky_l + leaky_u) {  // +y
+        s.jp += multi_d;
+        s.y = s.yu + eps * dy;
+        s.z = s.zl + 0.5 * dz;
+        s.x = s.xl + 0.5 * dx;
+        sample_face_iso_dir(s.vv, rng, s.vy, s.vz, s.vx);
+      } else if (xim < leakx_l + leakx_u + leaky_l + leaky_u + leakz_l) {  // -z
+        s.kp -= three_d;
+        s.z = s.zl - eps * dz;
+        s.x = s.xl + 0.5 * dx;
+        s.y = s.yl + 0.5 * dy;
+        sample_face_iso_dir(-s.vv, rng, s.vz, s.vx, s.vy);
+      } else if (xim <= leak_tot) {  // +z
+        s.kp += three_d;
+        s.z = s.zu + eps * dz;
+        s.x = s.xl + 0.5 * dx;
+        s.y = s.yl + 0.5 * dy;
+        sample_face_iso_dir(s.vv, rng, s.vz, s.vx, s.vy);
+      }
+    }
+  } else {
+    // census: uniform position in the cell (draw order z, x, y), isotropic direction with the
+    // polar axis along z (lines 267-275)
+    s.z = s.zl + rng.drand() * dz;
+    s.x = s.xl + rng.drand() * dx;
+    s.y = s.yl + rng.drand() * dy;
+    const double mu = 1.0 - 2.0 * rng.drand();
+    const double nu = sqrt(1.0 - mu * mu);
+    const double phi = kTwoPi * rng.drand();
+    double sn, cs;
+    m_sincos(phi, sn, cs);
+    s.vz = s.vv * mu;
+    s.vx = s.vv * nu * cs;
+    s.vy = s.vv * nu * sn;
+  }
+}
+
+// One face of the IMC -> DDMC albedo test (the six branches of transport_utils.hpp:288-389);
+// sgn = +1 lower face, -1 upper face.
+template <class Rng>
+__device__ __forceinline__ void albedo_face(Step &s, Rng &rng, double dcell, double sgn,
+                                            double &vn, double &va, double &vb, double &xn,
+                                            double face) {
+  const double Pf = (2.0 / 3.0) / ((s.aa + s.ss) * dcell + 2.0 * kLamExt);
+  const double P = 2.0 * Pf * (1.0 + sgn * 1.5 * vn / s.vv);
+  if (rng.drand() > P) {
+    sample_face_iso_dir(-sgn * s.vv, rng, vn, va, vb);
+    xn = face - sgn * kEpsImc * dcell;
+    s.is_rejected = true;
+  }
+}
+
+// reference transport_utils.hpp:279-397 -- 0..3 draws
+template <int NDIM, class Rng>
+__device__ __forceinline__ void ptcl_ddmc_albedo(Step &s, Rng &rng) {
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  const double dx = s.xu - s.xl;
+  const double dy = s.yu - s.yl;
+  const double dz = s.zu - s.zl;
+  const double tol = 2.5 * kEpsImc;
+
+  if (fuzzy_equal(s.x, s.xl, dx, tol)) {
+    albedo_face(s, rng, dx, 1.0, s.vx, s.vy, s.vz, s.x, s.xl);
+  } else if (fuzzy_equal(s.x, s.xu, dx, tol)) {
+    albedo_face(s, rng, dx, -1.0, s.vx, s.vy, s.vz, s.x, s.xu);
+  } else if (multi_d && fuzzy_equal(s.y, s.yl, dy, tol)) {
+    albedo_face(s, rng, dy, 1.0, s.vy, s.vz, s.vx, s.y, s.yl);
+  } else if (multi_d && fuzzy_equal(s.y, s.yu, dy, tol)) {
+    albedo_face(s, rng, dy, -1.0, s.vy, s.vz, s.vx, s.y, s.yu);
+  } else if (three_d && fuzzy_equal(s.z, s.zl, dz, tol)) {
+    albedo_face(s, rng, dz, 1.0, s.vz, s.vx, s.vy, s.z, s.zl);
+  } else if (three_d && fuzzy_equal(s.z, s.zu, dz, tol)) {
+    albedo_face(s, rng, dz, -1.0, s.vz, s.vx, s.vy, s.z, s.zu);
+  }
+
+  if (!s.is_rejected) {
+    s.x = 0.5 * (s.xl + s.xu);
+    s.y = 0.5 * (s.yl + s.yu);
+    s.z = 0.5 * (s.zl + s.zu);
+  }
+}
+
+// reference sample_ddmc_bface.cpp:24-41 -- 2 draws
+template <class Rng>
+__device__ __forceinline__ void sample_face_2d(int i_l, double dx, double P_l, double P_u, Rng &rng,
+                                               int &i, double &x) {
+  const double xi = (P_l + P_u) * rng.drand();
+  if (xi < P_l) {
+    x -= dx * rng.drand();
+    i = i_l;
+  } else {
+    x += dx * rng.drand();
+    i = i_l + 1;
+  }
+}
+
+// reference sample_ddmc_bface.cpp:43-78 -- 3 draws
+template <class Rng>
+__device__ __forceinline__ void sample_face_3d(int i1_l, int i2_l, double dx1, double dx2,
+                                               double P_ll, double P_lu, double P_ul, double P_uu,
+                                               Rng &rng, int &i1, int &i2, double &x1, double &x2) {
+  const double xi = (P_ll + P_lu + P_ul + P_uu) * rng.drand();
+  if (xi < P_ll) {
+    x1 -= dx1 * rng.drand(); i1 = i1_l;
+    x2 -= dx2 * rng.drand(); i2 = i2_l;
+  } else if (xi < P_ll + P_lu) {
+    x1 += dx1 * rng.drand(); i1 = i1_l + 1;
+    x2 -= dx2 * rng.drand(); i2 = i2_l;
+  } else if (xi < P_ll + P_lu + P_ul) {
+    x1 -= dx1 * rng.drand(); i1 = i1_l;
+    x2 += dx2 * rng.drand(); i2 = i2_l + 1;
+  } else {
+    x1 += dx1 * rng.drand(); i1 = i1_l + 1;
+    x2 += dx2 * rng.drand(); i2 = i2_l + 1;
+  }
+}
+
+}  // namespace jb

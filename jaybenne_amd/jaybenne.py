@@ -1,0 +1,457 @@
+"""Host-side mirror of the reference's package interface (reference src/jaybenne/jaybenne.hpp:48-78)
+over the C ABI of ``libjaybenne_amd.so``.
+
+Same task names, same argument meaning (``md, t_start, dt``), same return convention
+(``TaskStatus``) and the same failure conditions as the reference (PARTHENON_REQUIRE /
+PARTHENON_FAIL become exceptions).  PyTorch appears only as the owner of device memory, the
+stream and ``torch.distributed``; every field / particle update runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import sys
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .deck import ParameterInput
+from .mesh import Mesh
+
+photons_swarm_name = "photons"           # jaybenne_variables.hpp:23
+
+
+class TaskStatus(enum.IntEnum):
+    complete = _lib.JB_COMPLETE
+    iterate = _lib.JB_ITERATE
+    incomplete = _lib.JB_INCOMPLETE
+
+
+class SourceType(enum.IntEnum):           # jaybenne.hpp:56
+    thermal = _lib.JB_SOURCE_THERMAL
+    emission = _lib.JB_SOURCE_EMISSION
+
+
+class SourceStrategy(enum.IntEnum):       # jaybenne.hpp:55
+    uniform = _lib.JB_STRATEGY_UNIFORM
+    energy = _lib.JB_STRATEGY_ENERGY
+
+
+# ------------------------------------------------------------------------------------------------
+class StateDescriptor:
+    """What ``jaybenne::Initialize`` returns: the package's parameters (``Param``) plus, here,
+    the library context that owns the device-side copies of them."""
+
+    def __init__(self, params: Dict[str, object], ctx: C.c_void_p, device: torch.device):
+        self._params = dict(params)
+        self.ctx = ctx
+        self.device = device
+        self.lib = _lib.load()
+
+    def Param(self, name: str):
+        return self._params[name]
+
+    def AllParams(self) -> Dict[str, object]:
+        return dict(self._params)
+
+    def close(self) -> None:
+        if self.ctx is not None:
+            self.lib.jb_finalize(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def Initialize(pin: ParameterInput, opacity, scattering, eos, device: Optional[torch.device] = None,
+               my_rank: int = 0) -> StateDescriptor:
+    """``jaybenne::Initialize(pin, opacity, scattering, eos)`` -- reference jaybenne.cpp:158-266:
+    same keys, defaults and failure conditions."""
+    lib = _lib.load()
+    num_particles = pin.GetInteger("jaybenne", "num_particles")
+    dt = pin.GetOrAddReal("jaybenne", "dt", sys.float_info.max)
+    min_occ = pin.GetOrAddReal("jaybenne", "min_swarm_occupancy", 0.0)
+    if not (0.0 <= min_occ < 1.0):
+        raise ValueError("Minimum allowable swarm occupancy must be >= 0 and less than 1")
+    numin = pin.GetOrAddReal("jaybenne", "numin", sys.float_info.min)
+    numax = pin.GetOrAddReal("jaybenne", "numax", sys.float_info.max)
+    units = opacity.GetRuntimePhysicalConstants()
+    unique_rank_seeds = pin.GetOrAddBoolean("jaybenne", "unique_rank_seeds", True)
+    seed = pin.GetOrAddInteger("jaybenne", "seed", 123)
+    max_iter = pin.GetOrAddInteger("jaybenne", "max_transport_iterations", 10000)
+    use_ddmc = pin.GetOrAddBoolean("jaybenne", "use_ddmc", False)
+    tau_ddmc = pin.GetOrAddReal("jaybenne", "tau_ddmc", 5.0)
+    strategy = pin.GetOrAddString("jaybenne", "source_strategy", "uniform")
+    if strategy == "uniform":
+        source_strategy = SourceStrategy.uniform
+    elif strategy == "energy":
+        source_strategy = SourceStrategy.energy
+    else:
+        raise ValueError("Only uniform or energy source strategies supported!")
+    do_emission = pin.GetOrAddBoolean("jaybenne", "do_emission", True)
+    do_feedback = pin.GetOrAddBoolean("jaybenne", "do_feedback", True)
+
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    p = _lib.Params(num_particles=num_particles, dt=dt, min_swarm_occupancy=min_occ, numin=numin,
+                    numax=numax, tau_ddmc=tau_ddmc, unique_rank_seeds=int(unique_rank_seeds),
+                    seed=seed, max_transport_iterations=max_iter, use_ddmc=int(use_ddmc),
+                    source_strategy=int(source_strategy), do_emission=int(do_emission),
+                    do_feedback=int(do_feedback), rank=my_rank)
+    e = _lib.Eos(model=eos.model, gm1=eos.gm1, cv=eos.cv)
+    o = _lib.Opacity(model=opacity.model, kappa=opacity.kappa, c=units.c, sb=units.sb)
+    s = _lib.Scattering(model=scattering.model, kappa_s=scattering.kappa_s, apm=scattering.apm)
+    ctx = C.c_void_p()
+    _lib.check(lib.jb_initialize(C.byref(p), C.byref(e), C.byref(o), C.byref(s),
+                                 device.index or 0, C.byref(ctx)))
+    params = dict(num_particles=num_particles, dt=dt, min_swarm_occupancy=min_occ, numin=numin,
+                  numax=numax, speed_of_light=units.c, stefan_boltzmann=units.sb,
+                  unique_rank_seeds=unique_rank_seeds, seed=int(lib.jb_param_seed(ctx)),
+                  max_transport_iterations=max_iter, use_ddmc=use_ddmc, tau_ddmc=tau_ddmc,
+                  source_strategy=source_strategy, do_emission=do_emission,
+                  do_feedback=do_feedback, eos_d=eos, opacity_d=opacity, scattering_d=scattering)
+    return StateDescriptor(params, ctx, device)
+
+
+# ------------------------------------------------------------------------------------------------
+_F64 = _lib.SWARM_F64
+_I32 = _lib.SWARM_I32
+
+
+class MeshData:
+    """The blocks of one rank with their fields and photon swarm in HBM (the role of
+    Parthenon's ``MeshData<Real>`` + ``SwarmContainer`` for this package).
+
+    Layout in HBM: each field is one ``[nblocks_local, nk, nj, ni]`` float64 tensor (ghosts
+    included; the C ABI receives one device pointer per block); the swarm is a structure of
+    arrays with ``capacity`` slots, particles ``0..n-1`` valid.
+    """
+
+    def __init__(self, pkg: StateDescriptor, mesh: Mesh, capacity: int, rank: int = 0,
+                 nranks: int = 1, comm=None):
+        self.pkg = pkg
+        self.mesh = mesh
+        self.rank, self.nranks = rank, nranks
+        self.comm = comm
+        self.lib = pkg.lib
+        dev = pkg.device
+        self.device = dev
+        owner = np.ascontiguousarray(mesh.owner, dtype=np.int32)
+        if owner.max() >= nranks:
+            raise ValueError("mesh.owner names a rank >= nranks")
+        self.gids = np.nonzero(owner == rank)[0].astype(np.int32)
+        if len(self.gids) == 0:
+            raise ValueError(f"rank {rank} owns no blocks")
+        self.nblocks = len(self.gids)
+        local_index = np.full(mesh.nblocks, -1, dtype=np.int32)
+        local_index[self.gids] = np.arange(self.nblocks, dtype=np.int32)
+        self.local_index = local_index
+        shape = (self.nblocks,) + tuple(mesh.field_shape[1:])
+        names = list(_lib.FIELD_NAMES)
+        use_ddmc = bool(pkg.Param("use_ddmc"))
+        self.fields: Dict[str, torch.Tensor] = {}
+        for n in names:
+            if n in ("P1", "P2", "P3") and not use_ddmc:
+                continue
+            self.fields[n] = torch.zeros(shape, dtype=torch.float64, device=dev)
+        # swarm
+        self.capacity = int(capacity)
+        self.swarm: Dict[str, torch.Tensor] = {}
+        for n in _F64:
+            self.swarm[n] = torch.zeros(self.capacity, dtype=torch.float64, device=dev)
+        for n in _I32:
+            self.swarm[n] = torch.zeros(self.capacity, dtype=torch.int32, device=dev)
+        self.swarm["id"] = torch.zeros(self.capacity, dtype=torch.int64, device=dev)   # uint64 bits
+        self.swarm["ctr"] = torch.zeros(self.capacity, dtype=torch.int32, device=dev)  # uint32 bits
+        self.sv = _lib.SwarmView(n=0, capacity=self.capacity)
+        for n in _F64 + _I32 + ("id", "ctr"):
+            setattr(self.sv, n, self.swarm[n].data_ptr())
+        self.prefix = torch.zeros(self.nblocks * mesh.ncell, dtype=torch.int32, device=dev)
+        self.records: Optional[torch.Tensor] = None
+        self.next_id = 0     # first unused stream id (global, kept in step on every rank)
+        self.epoch = 0       # source-call counter (keys the per-cell rounding streams)
+        self.events = 0
+        self._make_mesh_handle(owner)
+
+    # ---- C views
+    def _make_mesh_handle(self, owner: np.ndarray) -> None:
+        m = self.mesh
+        g = self.gids
+        keep = dict(
+            leaf_map=np.ascontiguousarray(m.leaf_map, dtype=np.int32), owner=owner,
+            local_index=self.local_index, gid=np.ascontiguousarray(g, dtype=np.int32),
+            blk_xmin=np.ascontiguousarray(m.blk_xmin[g]), blk_xmax=np.ascontiguousarray(m.blk_xmax[g]),
+            blk_dx=np.ascontiguousarray(m.blk_dx[g]),
+            blk_level=np.ascontiguousarray(m.blk_level[g], dtype=np.int32),
+            blk_nbr_lev=np.ascontiguousarray(m.blk_nbr_lev[g], dtype=np.int32))
+        v = _lib.MeshView(ndim=m.ndim, ng=m.ng, nblocks=self.nblocks, nblocks_total=m.nblocks,
+                          rank=self.rank)
+        v.nx = (C.c_int32 * 3)(*m.nx)
+        v.nleaf = (C.c_int32 * 3)(*m.nleaf)
+        v.bc = (C.c_int32 * 6)(*m.swarm_bc)
+        v.gmin = (C.c_double * 3)(*m.gmin)
+        v.gmax = (C.c_double * 3)(*m.gmax)
+        for k, a in keep.items():
+            setattr(v, k, a.ctypes.data)
+        ptr_tables = {}
+        for n, t in self.fields.items():
+            stride = t.stride(0) * t.element_size()
+            tab = np.array([t.data_ptr() + b * stride for b in range(self.nblocks)], dtype=np.uint64)
+            ptr_tables[n] = tab
+            setattr(v, n, tab.ctypes.data)
+        handle = C.c_void_p()
+        self._sync_stream()
+        _lib.check(self.lib.jb_mesh_create(self.pkg.ctx, C.byref(v), C.byref(handle)))
+        self.handle = handle
+
+    def _sync_stream(self) -> None:
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.lib.jb_set_stream(self.pkg.ctx, C.c_void_p(stream))
+
+    @property
+    def n(self) -> int:
+        return int(self.sv.n)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None) is not None:
+            self.lib.jb_mesh_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host <-> device helpers for the harness
+    def set_field(self, name: str, host: np.ndarray) -> None:
+        """host: [nblocks_total, nk, nj, ni] (whole mesh) -> this rank's blocks."""
+        self.fields[name].copy_(torch.from_numpy(np.ascontiguousarray(host[self.gids])))
+
+    def get_field(self, name: str) -> np.ndarray:
+        return self.fields[name].cpu().numpy()
+
+    def get_swarm(self) -> Dict[str, np.ndarray]:
+        n = self.n
+        out = {k: v[:n].cpu().numpy() for k, v in self.swarm.items()}
+        out["id"] = out["id"].view(np.uint64)
+        out["ctr"] = out["ctr"].view(np.uint32)
+        return out
+
+    def stats(self, reset: bool = False) -> Dict[str, int]:
+        st = _lib.TransportStats()
+        _lib.check(self.lib.jb_get_transport_stats(self.pkg.ctx, C.byref(st), int(reset)))
+        return {k: int(getattr(st, k)) for k, _ in st._fields_}
+
+
+# ------------------------------------------------------------------------------------------------
+# tasks (reference jaybenne.hpp:59-76)
+def UpdateDerivedTransportFields(md: MeshData, dt: float) -> TaskStatus:
+    md._sync_stream()
+    _lib.check(md.lib.jb_update_derived_transport_fields(md.pkg.ctx, md.handle, dt))
+    return TaskStatus.complete
+
+
+def _global_block_counts(md: MeshData, nper_local: np.ndarray) -> np.ndarray:
+    counts = np.zeros(md.mesh.nblocks, dtype=np.int64)
+    counts[md.gids] = nper_local
+    if md.comm is not None and md.nranks > 1:
+        counts = md.comm.allreduce_sum_int64(counts)
+    return counts
+
+
+def SourcePhotons(md: MeshData, source_type: SourceType, t_start: float, dt: float,
+                  per_block: bool = False) -> TaskStatus:
+    """``SourcePhotons<T, ST>(md, t_start, dt)`` -- reference sourcing.cpp:25-208.
+    ``per_block=True`` is the ``MeshBlockData`` instantiation used at initialisation (one call
+    per block, so the ``nblocks`` of sourcing.cpp:68-69 is 1)."""
+    pkg = md.pkg
+    if pkg.Param("source_strategy") == SourceStrategy.energy:
+        raise NotImplementedError("Energy source strategy not implemented!")
+    if source_type == SourceType.emission and not pkg.Param("do_emission"):
+        return TaskStatus.complete
+    md._sync_stream()
+    nper = np.zeros(md.nblocks, dtype=np.int32)
+    blocks_in_call = 1 if per_block else md.nblocks
+    _lib.check(md.lib.jb_source_photons_count(pkg.ctx, md.handle, int(source_type), dt,
+                                              blocks_in_call, md.epoch, nper.ctypes.data,
+                                              md.prefix.data_ptr()))
+    md.epoch += 1
+    counts = _global_block_counts(md, nper)
+    excl = np.concatenate(([0], np.cumsum(counts)[:-1]))
+    id_base = np.ascontiguousarray(md.next_id + excl[md.gids], dtype=np.uint64)
+    local_excl = np.concatenate(([0], np.cumsum(nper.astype(np.int64))[:-1]))
+    slot_base = np.ascontiguousarray(md.n + local_excl, dtype=np.int64)
+    tot = int(nper.sum())
+    if md.n + tot > md.capacity:
+        raise MemoryError(f"swarm capacity {md.capacity} too small for {md.n} + {tot} particles")
+    _lib.check(md.lib.jb_source_photons_fill(pkg.ctx, md.handle, C.byref(md.sv), int(source_type),
+                                             t_start, dt, nper.ctypes.data, md.prefix.data_ptr(),
+                                             slot_base.ctypes.data, id_base.ctypes.data))
+    md.sv.n += tot
+    md.next_id += int(counts.sum())
+    return TaskStatus.complete
+
+
+def _transport(md: MeshData, t_start: float, dt: float, first: int, last: Optional[int],
+               fuse_census_tally: bool, ddmc: bool) -> TaskStatus:
+    md._sync_stream()
+    last = md.n if last is None else last
+    fn = md.lib.jb_transport_photons_ddmc if ddmc else md.lib.jb_transport_photons
+    _lib.check(fn(md.pkg.ctx, md.handle, C.byref(md.sv), t_start, dt, first, last,
+                  int(fuse_census_tally)))
+    return TaskStatus.complete
+
+
+def TransportPhotons(md: MeshData, t_start: float, dt: float, first: int = 0,
+                     last: Optional[int] = None, fuse_census_tally: bool = False) -> TaskStatus:
+    """reference transport.cpp:28-181"""
+    return _transport(md, t_start, dt, first, last, fuse_census_tally, False)
+
+
+def TransportPhotons_DDMC(md: MeshData, t_start: float, dt: float, first: int = 0,
+                          last: Optional[int] = None, fuse_census_tally: bool = False) -> TaskStatus:
+    """reference transport_ddmc.cpp:28-237"""
+    return _transport(md, t_start, dt, first, last, fuse_census_tally, True)
+
+
+def SampleDDMCBlockFace(md: MeshData, first: int = 0, last: Optional[int] = None) -> TaskStatus:
+    """reference sample_ddmc_bface.cpp:81-427"""
+    md._sync_stream()
+    last = md.n if last is None else last
+    _lib.check(md.lib.jb_sample_ddmc_block_face(md.pkg.ctx, md.handle, C.byref(md.sv), first, last))
+    return TaskStatus.complete
+
+
+def CheckCompletion(md: MeshData, t_end: float) -> TaskStatus:
+    """reference transport.cpp:187-216 (local part; the global_sync of jaybenne.cpp:130-131 is
+    the all-reduce in RadiationStep)"""
+    md._sync_stream()
+    unfinished = C.c_int64(0)
+    st = _lib.check(md.lib.jb_check_completion(md.pkg.ctx, C.byref(md.sv), t_end,
+                                               C.byref(unfinished)))
+    md.num_unfinished = int(unfinished.value)
+    return TaskStatus(st)
+
+
+def EvaluateRadiationEnergy(md: MeshData) -> TaskStatus:
+    """reference jaybenne.cpp:514-564"""
+    md._sync_stream()
+    _lib.check(md.lib.jb_evaluate_radiation_energy(md.pkg.ctx, md.handle, C.byref(md.sv)))
+    return TaskStatus.complete
+
+
+def UpdateFluid(md: MeshData) -> TaskStatus:
+    """reference jaybenne.cpp:583-615"""
+    md._sync_stream()
+    _lib.check(md.lib.jb_update_fluid(md.pkg.ctx, md.handle))
+    return TaskStatus.complete
+
+
+def PhotonReflectBC(md: MeshData, face: int) -> None:
+    """reference boundaries.hpp:24-84; face 0..5 = inner_x1, outer_x1, inner_x2, ..."""
+    md._sync_stream()
+    _lib.check(md.lib.jb_photon_reflect_bc(md.pkg.ctx, md.handle, C.byref(md.sv), face))
+
+
+def RemoveMarkedParticles(md: MeshData) -> int:
+    md._sync_stream()
+    _lib.check(md.lib.jb_remove_marked_particles(md.pkg.ctx, C.byref(md.sv)))
+    return md.n
+
+
+def DefragParticles(md: MeshData) -> TaskStatus:
+    """reference jaybenne.cpp:499-509 (never scheduled by the reference either); the swarm here
+    is always compact after RemoveMarkedParticles, so there is nothing to defragment."""
+    return TaskStatus.complete
+
+
+def EstimateTimestepMesh(md: MeshData) -> float:
+    """reference jaybenne.cpp:271-275"""
+    return float(md.lib.jb_estimate_timestep(md.pkg.ctx))
+
+
+def InitializeRadiation(md: MeshData, is_thermal: bool) -> None:
+    """reference jaybenne.cpp:570-578 (called per block by mcblock's ProblemGenerator)"""
+    if is_thermal:
+        SourcePhotons(md, SourceType.thermal, 0.0, 0.0, per_block=True)
+    EvaluateRadiationEnergy(md)
+
+
+# ------------------------------------------------------------------------------------------------
+def _exchange(md: MeshData) -> int:
+    """MeshResetCommunication -> MeshSend -> MeshReceive (reference jaybenne.cpp:26-61) for the
+    particles whose destination block lives on another rank.  Returns the number received."""
+    lib, ctx = md.lib, md.pkg.ctx
+    n_out = md.stats()["n_outgoing"] - md._outgoing_seen
+    md._outgoing_seen += n_out
+    counts = np.zeros(md.nranks, dtype=np.int64)
+    send = None
+    if n_out > 0:
+        if md.records is None or md.records.shape[0] < n_out:
+            md.records = torch.empty((int(n_out * 1.5) + 1024, _lib.JB_RECORD_WORDS),
+                                     dtype=torch.int64, device=md.device)
+        _lib.check(lib.jb_pack_outgoing(ctx, md.handle, C.byref(md.sv), md.nranks,
+                                        md.records.data_ptr(), md.records.shape[0],
+                                        counts.ctypes.data))
+        send = md.records[:int(counts.sum())]
+        RemoveMarkedParticles(md)     # drops the OUTGOING (and absorbed / escaped) slots
+    recv = md.comm.exchange_records(send, counts, md.device)
+    nrecv = 0 if recv is None else int(recv.shape[0])
+    if nrecv:
+        if md.n + nrecv > md.capacity:
+            raise MemoryError(f"swarm capacity {md.capacity} too small for {nrecv} arrivals")
+        md._sync_stream()
+        _lib.check(lib.jb_unpack_incoming(ctx, md.handle, C.byref(md.sv), recv.data_ptr(), nrecv))
+    return nrecv
+
+
+def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
+    """One radiation cycle: the task list of ``jaybenne::RadiationStep`` (reference
+    jaybenne.cpp:68-151) for this rank's blocks.
+
+    Single rank: one transport launch resolves every block crossing in flight.  Several ranks:
+    the iterate-sublist of jaybenne.cpp:113-131 -- transport, hand-off of the particles that left
+    for another rank's blocks, SampleDDMCBlockFace on the arrivals, and the global completion
+    test (one all-reduced integer) -- repeated until no particle is in flight anywhere.
+    """
+    pkg = md.pkg
+    use_ddmc = bool(pkg.Param("use_ddmc"))
+    transport = TransportPhotons_DDMC if use_ddmc else TransportPhotons
+    UpdateDerivedTransportFields(md, dt)
+    SourcePhotons(md, SourceType.emission, t_start, dt)
+    # (the ddmc_face_prob ghost exchange of jaybenne.cpp:108-110 has no consumer: every face the
+    # transport and resampling kernels read belongs to the block itself)
+    md._sync_stream()
+    _lib.check(md.lib.jb_zero_energy_tally(pkg.ctx, md.handle))
+    before = md.stats()
+    md._outgoing_seen = before["n_outgoing"]
+    first = 0
+    for it in range(int(pkg.Param("max_transport_iterations"))):
+        transport(md, t_start, dt, first, md.n, fuse_census_tally=True)
+        if md.nranks == 1:
+            break
+        n_before = md.n
+        nrecv = _exchange(md)
+        first = md.n - nrecv
+        if use_ddmc and nrecv:
+            SampleDDMCBlockFace(md, first, md.n)
+        if md.comm.allreduce_sum_int64(np.array([nrecv], dtype=np.int64))[0] == 0:
+            break
+    else:
+        return TaskStatus.iterate
+    after = md.stats()
+    if md.nranks == 1:
+        if after["n_outgoing"] != before["n_outgoing"]:
+            raise RuntimeError("particles left for another rank in a single-rank step")
+        if (after["n_absorbed"] != before["n_absorbed"] or after["n_escaped"] != before["n_escaped"]):
+            RemoveMarkedParticles(md)
+    md.events += after["n_events"] - before["n_events"]
+    UpdateFluid(md)
+    return TaskStatus.complete

@@ -130,3 +130,66 @@ def ProblemGenerator(mesh: Mesh, pkg: McblockPackage) -> Dict[str, np.ndarray]:
 def UpdateDerived(rho: np.ndarray, u: np.ndarray) -> np.ndarray:
     """sie = u / rho over the entire block incl. ghosts (reference mcblock.cpp:208-232)."""
     return u / rho
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side driver (needs the HIP library; imported lazily so that the host-only helpers above
+# stay usable without a GPU)
+class McblockDriver:
+    """The cycle loop of the reference application: ``Step()`` = ``jaybenne::RadiationStep`` then
+    ``HostUpdateTasks`` (ghost exchange, FillDerived -> UpdateDerived, EstimateTimestep);
+    reference src/mcblock/mcblock_driver.cpp:38-74."""
+
+    def __init__(self, pin: ParameterInput, rank: int = 0, nranks: int = 1, comm=None,
+                 device=None, capacity_factor: float = 1.3, mesh: Mesh = None):
+        from . import jaybenne as jb
+        self.jb = jb
+        self.pin = pin
+        self.mesh = mesh if mesh is not None else Mesh.from_deck(pin)
+        if nranks > 1:
+            self.mesh.partition(nranks)
+        self.mcb = Initialize(pin)
+        self.pkg = jb.Initialize(pin, self.mcb.opacity, self.mcb.scattering, self.mcb.eos,
+                                 device=device, my_rank=rank)
+        n_local_blocks = int((self.mesh.owner == rank).sum())
+        share = self.pkg.Param("num_particles") * n_local_blocks / self.mesh.nblocks
+        capacity = int(share * capacity_factor) + 4096
+        self.md = jb.MeshData(self.pkg, self.mesh, capacity, rank, nranks, comm)
+        self.tlim = pin.GetReal("parthenon/time", "tlim")
+        self.nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1)
+        self.time = 0.0
+        self.ncycle = 0
+        self.dt = jb.EstimateTimestepMesh(self.md)
+        # ProblemGenerator + PostInitialization + initial ghost fill / FillDerived
+        ic = ProblemGenerator(self.mesh, self.mcb)
+        for name in ("rho", "sie", "u"):
+            self.md.set_field(name, ic[name])
+        jb.InitializeRadiation(self.md, self.mcb.initial_radiation == "thermal")
+
+    def HostUpdateTasks(self) -> None:
+        """Ghost exchange of density / internal energy, sie = u / rho, new dt."""
+        md = self.md
+        if self.pkg.Param("do_feedback"):
+            if md.nranks > 1:
+                raise NotImplementedError("material feedback with several ranks needs a field "
+                                          "halo exchange, which is not built")
+            u = md.get_field("u")
+            self.mesh.fill_ghosts(u)
+            md.set_field("u", u)
+        md.fields["sie"].copy_(md.fields["u"] / md.fields["rho"])
+        self.dt = self.jb.EstimateTimestepMesh(md)
+
+    def Step(self):
+        st = self.jb.RadiationStep(self.md, self.time, self.dt)
+        if st != self.jb.TaskStatus.complete:
+            return st
+        self.HostUpdateTasks()
+        self.time += self.dt
+        self.ncycle += 1
+        return st
+
+    def Execute(self) -> None:
+        while self.time < self.tlim and (self.nlim < 0 or self.ncycle < self.nlim):
+            st = self.Step()
+            if st != self.jb.TaskStatus.complete:
+                raise RuntimeError(f"radiation step did not complete: {st!r}")

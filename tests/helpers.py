@@ -1,0 +1,65 @@
+"""Shared test plumbing: build the same problem for the CPU oracle and for the HIP product.
+
+The decks are the reference's own (inputs/*.in), transcribed as text below because
+/root/reference does not exist on the GPU box.  Only keys the reference reads are kept.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from jaybenne_amd import constants, mcblock  # noqa: E402
+from jaybenne_amd.deck import ParameterInput  # noqa: E402
+from jaybenne_amd.mesh import Mesh  # noqa: E402
+
+DECK_DIR = os.path.join(ROOT, "tests", "golden", "decks")
+
+
+def load_deck(name: str, overrides=None) -> ParameterInput:
+    pin = ParameterInput.from_file(os.path.join(DECK_DIR, name + ".in"))
+    if overrides:
+        pin.modify(overrides)
+    return pin
+
+
+def oracle_params(pin: ParameterInput, pkg) -> dict:
+    return dict(num_particles=pin.GetInteger("jaybenne", "num_particles"),
+                dt=pin.GetReal("jaybenne", "dt"),
+                tau_ddmc=pin.GetOrAddReal("jaybenne", "tau_ddmc", 5.0),
+                c=constants.SPEED_OF_LIGHT, sb=constants.STEFAN_BOLTZMANN, cv=pkg.eos.cv,
+                kappa_a=pkg.opacity.kappa, kappa_s=pkg.scattering.kappa_s, apm=pkg.scattering.apm,
+                seed=pin.GetOrAddInteger("jaybenne", "seed", 123),
+                use_ddmc=int(pin.GetOrAddBoolean("jaybenne", "use_ddmc", False)),
+                do_emission=int(pin.GetOrAddBoolean("jaybenne", "do_emission", True)),
+                do_feedback=int(pin.GetOrAddBoolean("jaybenne", "do_feedback", True)))
+
+
+def make_oracle(pin: ParameterInput, math_mode: int, threads: int = 8, mesh: Mesh = None):
+    from oracle import orc
+    mesh = mesh if mesh is not None else Mesh.from_deck(pin)
+    pkg = mcblock.Initialize(pin)
+    ic = mcblock.ProblemGenerator(mesh, pkg)
+    par = oracle_params(pin, pkg)
+    O = orc.Oracle(mesh, par, capacity=int(par["num_particles"] * 1.3) + 4096,
+                   math_mode=math_mode, threads=threads)
+    for k in ("rho", "sie", "u"):
+        O.fields[k][...] = ic[k]
+    O.InitializeRadiation(pkg.initial_radiation == "thermal")
+    return O, mesh, pkg
+
+
+def run_oracle_cycles(O, pin, ncycles: int):
+    dt = pin.GetReal("jaybenne", "dt")
+    t = 0.0
+    for _ in range(ncycles):
+        O.RadiationStep(t, dt)
+        # HostUpdateTasks: sie = u / rho (u only changes with do_feedback)
+        O.fields["sie"][...] = O.fields["u"] / O.fields["rho"]
+        t += dt
+    return t

@@ -1,0 +1,344 @@
+"""Parity of the HIP history loop with the CPU oracle, through the C ABI, on a real MI355X.
+
+Bar: random words and indices bit-exact; every floating-point particle attribute bit-exact against
+the oracle in its portable-math flavour (the HIP code implements the same IEEE sequence); cell
+tallies to 1e-12 relative (atomic accumulation order).  The oracle's libm flavour -- the
+reference's own arithmetic -- is tied to the portable one in tests/test_oracle_math.py.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import load_deck, make_oracle, run_oracle_cycles
+
+pytestmark = pytest.mark.gpu
+
+SMR_OVERRIDES = {"parthenon/mesh/nx1": 64, "parthenon/mesh/nx2": 32,
+                 "parthenon/meshblock/nx1": 16, "parthenon/meshblock/nx2": 16}
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_device):
+    """A bare package context for the debug entry points."""
+    from jaybenne_amd import jaybenne as jb, mcblock
+    pin = load_deck("stepdiff")
+    mcb = mcblock.Initialize(pin)
+    pkg = jb.Initialize(pin, mcb.opacity, mcb.scattering, mcb.eos, device=gpu_device)
+    yield pkg
+    pkg.close()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_philox_known_answers_on_device(ctx):
+    from jaybenne_amd import _lib
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        out = (C.c_uint32 * 4)()
+        _lib.check(ctx.lib.jb_debug_philox(ctx.ctx, (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out))
+        assert tuple(out) == want
+
+
+def test_stream_layout_matches_rocrand(ctx):
+    """key = seed, counter = {block, 0, id_lo, id_hi} is rocrand_init(seed, subsequence=id, 0)."""
+    from jaybenne_amd import _lib
+    seed, sub = 349857, (7 << 32) | 123456789
+    ref = (C.c_uint32 * 8)()
+    _lib.check(ctx.lib.jb_debug_rocrand_philox(ctx.ctx, seed, sub, ref))
+    for blk in (0, 1):
+        out = (C.c_uint32 * 4)()
+        ctr = (C.c_uint32 * 4)(blk, 0, sub & 0xffffffff, sub >> 32)
+        key = (C.c_uint32 * 2)(seed, 0)
+        _lib.check(ctx.lib.jb_debug_philox(ctx.ctx, ctr, key, out))
+        assert list(out) == list(ref[4 * blk:4 * blk + 4])
+
+
+def test_uniform_stream_bit_exact(ctx):
+    from jaybenne_amd import _lib
+    from oracle import orc
+    for first in (0, 1, 7):
+        out = np.empty(257)
+        _lib.check(ctx.lib.jb_debug_draw_stream(ctx.ctx, 349857, 0, 0x1234567890, first, out.size,
+                                                out.ctypes.data))
+        want = orc.draw_stream(349857, 0, 0x1234567890, first, out.size)
+        assert np.array_equal(out, want)
+        assert out.min() > 0.0 and out.max() < 1.0
+
+
+def _dev_math(ctx, which, x):
+    from jaybenne_amd import _lib
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    _lib.check(ctx.lib.jb_debug_math(ctx.ctx, which, x.ctypes.data, x.size, out.ctypes.data))
+    return out
+
+
+def test_device_math_bit_exact(ctx):
+    from oracle import orc
+    rng = np.random.default_rng(1)
+    orc.set_math_mode(orc.MATH_PORTABLE)
+    u = np.concatenate([rng.random(200000), 2.0 ** -rng.integers(1, 53, 1000) * rng.random(1000),
+                        [2.0 ** -53, 1 - 2.0 ** -53, 0.5, 0.70710678, 0.75]])
+    u = u[(u > 0) & (u < 1)]
+    assert np.array_equal(_dev_math(ctx, 0, u), orc.math_log(u))
+    prod = u[:50000] * u[50000:100000] * u[100000:150000] * u[150000:200000]   # Planck argument
+    assert np.array_equal(_dev_math(ctx, 0, prod), orc.math_log(prod))
+    phi = 2.0 * np.pi * u
+    s, c = orc.math_sincos(phi)
+    assert np.array_equal(_dev_math(ctx, 1, phi), s)
+    assert np.array_equal(_dev_math(ctx, 2, phi), c)
+    mu = 2.0 * u - 1.0
+    assert np.array_equal(_dev_math(ctx, 3, mu), orc.math_acos(mu))
+    # IEEE sqrt and divide on the device are correctly rounded (the host's are)
+    assert np.array_equal(_dev_math(ctx, 4, u), np.sqrt(u))
+    assert np.array_equal(_dev_math(ctx, 5, u), 1.0 / u)
+
+
+# ------------------------------------------------------------------------------------------------
+def _step_cases():
+    """Inputs that reach every branch of the three step functions (tape = uniforms replayed)."""
+    from oracle import orc
+    c = 2.99792458e10
+    base = dict(t_start=0.0, dt=3.335641e-11, ff=1.0, aa=0.0, ss=1.0e3, vv=c, dx_push=1 / 128,
+                xl=-0.5, xu=-0.5 + 1 / 128, yl=-0.5, yu=0.5, zl=-0.5, zu=0.5,
+                t=1e-12, x=-0.497, y=0.1, z=-0.2, vx=0.6 * c, vy=0.8 * c, vz=0.0, ip=2, jp=0, kp=0)
+    cases = []
+    tapes = [[0.3, 0.7, 0.11, 0.93], [0.999999, 0.2, 0.5, 0.5], [1e-9, 0.5], [0.5, 1e-9],
+             [0.9, 0.9999999], [0.5, 0.3]]
+    for nd in (1, 2, 3):
+        for tape in tapes:
+            for mods in ({}, dict(vx=-0.6 * c), dict(aa=2.0e3, ff=0.4), dict(ss=0.0, aa=0.0),
+                         dict(yl=0.09, yu=0.11, zl=-0.21, zu=-0.19, vz=0.3 * c, vy=0.5 * c),
+                         dict(t=3.335641e-11 - 1e-16), dict(x=-0.5 + 1 / 128 - 1e-12, vx=c)):
+                d = dict(base, multi_d=int(nd >= 2), three_d=int(nd == 3), **mods)
+                cases.append(("transport", d, tape))
+    # DDMC step: absorption, the six leak directions, census
+    P = dict(Px_l=0.04, Px_u=0.05, Py_l=0.03, Py_u=0.02, Pz_l=0.06, Pz_u=0.01)
+    for nd in (1, 2, 3):
+        gate = {k: (v if (k[1] == "x" or (k[1] == "y" and nd >= 2) or nd == 3) else 0.0)
+                for k, v in P.items()}
+        for xi2 in (0.0005, 0.05, 0.2, 0.4, 0.55, 0.7, 0.9, 0.999):
+            for aa in (0.0, 50.0):
+                d = dict(base, multi_d=int(nd >= 2), three_d=int(nd == 3), aa=aa, ff=0.8, **gate)
+                cases.append(("ddmc", d, [0.5, xi2, 0.3, 0.6, 0.1, 0.2]))
+        d = dict(base, multi_d=int(nd >= 2), three_d=int(nd == 3), **gate)
+        cases.append(("ddmc", d, [1e-300 + 1e-12, 0.2, 0.3, 0.6, 0.1, 0.8]))   # far event
+        cases.append(("ddmc", d, [1 - 1e-12, 0.25, 0.35, 0.65, 0.15, 0.85]))   # immediate event
+        d2 = dict(d, t=3.335641e-11 - 1e-18)
+        cases.append(("ddmc", d2, [0.5, 0.25, 0.35, 0.65, 0.15, 0.85]))        # census
+    # albedo: at each face (accept / reject), not at a face
+    eps_imc = 1e6 * 10 * np.finfo(float).eps
+    dx = 1 / 128
+    for nd in (1, 2, 3):
+        geo = dict(base, multi_d=int(nd >= 2), three_d=int(nd == 3), yl=0.09, yu=0.11, zl=-0.21,
+                   zu=-0.19, y=0.1, z=-0.2)
+        spots = [dict(x=-0.5 + eps_imc * dx, vx=0.7 * c), dict(x=-0.5 + dx - eps_imc * dx, vx=-0.7 * c),
+                 dict(y=0.09 + eps_imc * 0.02, vy=0.7 * c), dict(y=0.11 - eps_imc * 0.02, vy=-0.7 * c),
+                 dict(z=-0.21 + eps_imc * 0.02, vz=0.7 * c), dict(z=-0.19 - eps_imc * 0.02, vz=-0.7 * c),
+                 dict()]
+        for sp in spots:
+            for xi in (0.01, 0.99):
+                cases.append(("albedo", dict(geo, **sp), [xi, 0.4, 0.8]))
+    return cases
+
+
+def test_step_functions_bit_exact(ctx):
+    from jaybenne_amd import _lib
+    from oracle import orc
+    orc.set_math_mode(orc.MATH_PORTABLE)
+    which = {"transport": 0, "ddmc": 1, "albedo": 2}
+    names = [n for n, _ in orc.Step._fields_]
+    seen = set()
+    for kind, d, tape in _step_cases():
+        so, sd = orc.Step(), _lib.DebugStep()
+        for k, v in d.items():
+            setattr(so, k, v)
+            setattr(sd, k, v)
+        n_o = orc.call_step(kind, so, tape)
+        tp = np.ascontiguousarray(tape, dtype=np.float64)
+        nd = C.c_int(0)
+        _lib.check(ctx.lib.jb_debug_step_call(ctx.ctx, which[kind], C.byref(sd), tp.ctypes.data,
+                                              tp.size, C.byref(nd)))
+        assert nd.value == n_o, (kind, d, tape)
+        for nm in names:
+            a, b = getattr(so, nm), getattr(sd, nm)
+            assert (a == b) or (a != a and b != b), (kind, nm, a, b, d, tape)
+        seen.add((kind, so.is_absorbed, so.is_scattered, so.is_rejected, n_o))
+    assert len(seen) >= 9         # the cases really do spread over the branches
+
+
+def test_sampling_functions_bit_exact(ctx):
+    from jaybenne_amd import _lib
+    from oracle import orc
+    orc.set_math_mode(orc.MATH_PORTABLE)
+    c = 2.99792458e10
+    rng = np.random.default_rng(5)
+
+    def dev(which, a, iv, tape):
+        a8 = np.zeros(8); a8[:len(a)] = a
+        i4 = np.zeros(4, dtype=np.int32); i4[:len(iv)] = iv
+        tp = np.ascontiguousarray(tape, dtype=np.float64)
+        out = np.zeros(4); io = np.zeros(2, dtype=np.int32); nd = C.c_int(0)
+        _lib.check(ctx.lib.jb_debug_sample_call(ctx.ctx, which, a8.ctypes.data, i4.ctypes.data,
+                                                tp.ctypes.data, tp.size, out.ctypes.data,
+                                                io.ctypes.data, C.byref(nd)))
+        return out, io, nd.value
+
+    for _ in range(50):
+        tape = rng.random(6)
+        v, n = orc.call_scatter(c, tape)
+        out, _, nd = dev(0, [c], [], tape)
+        assert nd == n == 2 and np.array_equal(out[:3], v)
+        for sgn in (1.0, -1.0):
+            v, n = orc.call_face_iso_dir(sgn * c, tape)
+            out, _, nd = dev(1, [sgn * c], [], tape)
+            assert nd == n == 2 and np.array_equal(out[:3], v)
+        e, n = orc.call_planck(5.670373e-5, 1.0e5, tape)
+        out, _, nd = dev(2, [5.670373e-5, 1.0e5], [], tape)
+        assert nd == n == 5 and out[0] == e
+        i, x, n = orc.call_face_2d(7, 0.01, 0.3, 0.5, tape, 8, 0.25)
+        out, io, nd = dev(3, [0.01, 0.3, 0.5, 0.25], [7, 8], tape)
+        assert nd == n == 2 and io[0] == i and out[0] == x
+        P = rng.random(4)
+        ij, x12, n = orc.call_face_3d(3, 9, 0.01, 0.02, P, tape, [4, 10], [0.5, -0.25])
+        out, io, nd = dev(4, [0.01, 0.02, *P, 0.5, -0.25], [3, 9, 4, 10], tape)
+        assert nd == n == 3 and list(io) == ij and np.array_equal(out[:2], x12)
+    # Planck series index > 1 (xi0 close to 1)
+    e, n = orc.call_planck(5.670373e-5, 300.0, [0.9999, 0.5, 0.5, 0.5, 0.5])
+    out, _, nd = dev(2, [5.670373e-5, 300.0], [], [0.9999, 0.5, 0.5, 0.5, 0.5])
+    assert out[0] == e and nd == n
+
+
+# ------------------------------------------------------------------------------------------------
+def _compare_swarm(md, O, exact=True):
+    from oracle import orc
+    g = md.get_swarm()
+    n = O.n
+    assert md.n == n
+    for k in ("id", "ctr", "ip", "jp", "kp", "blk", "status"):
+        assert np.array_equal(g[k], O.sw[k][:n]), k
+    for k in orc.SWARM_F64:
+        a, b = g[k], O.sw[k][:n]
+        if exact:
+            bad = np.nonzero(a != b)[0]
+            assert bad.size == 0, (k, bad[:5], a[bad[:5]], b[bad[:5]])
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=0, err_msg=k)
+
+
+def _compare_fields(md, O, names=("tally", "edelta", "fleck", "src_num", "src_ew")):
+    sl = md.mesh.interior()
+    for k in names:
+        a = md.get_field(k)[sl]
+        b = O.fields[k][md.gids][sl]
+        fin = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), fin), k
+        np.testing.assert_allclose(a[fin], b[fin], rtol=1e-12, atol=0, err_msg=k)
+
+
+def _gpu_problem(pin, gpu_device):
+    from jaybenne_amd import mcblock
+    return mcblock.McblockDriver(pin, device=gpu_device)
+
+
+CASES = [
+    # deck, overrides, cycles
+    ("stepdiff", {"jaybenne/num_particles": 4000}, 2),                       # 1-D, 2 blocks (as shipped)
+    ("stepdiff", {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128,
+                  "jaybenne/num_particles": 4000}, 1),                        # the reference's test shape
+    ("stepdiff_ddmc", {"jaybenne/num_particles": 20000}, 2),                  # 1-D all-DDMC
+    ("stepdiff_smr", dict(SMR_OVERRIDES, **{"jaybenne/num_particles": 6000}), 1),      # 2-D SMR IMC
+    ("stepdiff_smr_ddmc", dict(SMR_OVERRIDES, **{"jaybenne/num_particles": 40000}), 2),  # 2-D SMR DDMC
+    ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 30000}, 1),            # true IMC/DDMC hybrid
+    ("stepdiff", {"parthenon/mesh/nx2": 8, "parthenon/mesh/nx3": 8, "parthenon/mesh/nx1": 16,
+                  "parthenon/meshblock/nx1": 8, "parthenon/meshblock/nx2": 4,
+                  "parthenon/meshblock/nx3": 4, "jaybenne/num_particles": 3000}, 1),   # 3-D, 8 blocks
+    ("stepdiff_ddmc", {"parthenon/mesh/nx2": 16, "parthenon/mesh/nx3": 16, "parthenon/mesh/nx1": 128,
+                       "parthenon/meshblock/nx1": 32, "parthenon/meshblock/nx2": 8,
+                       "parthenon/meshblock/nx3": 8, "jaybenne/num_particles": 40000,
+                       "jaybenne/tau_ddmc": 5.0}, 2),                          # 3-D DDMC, 16 blocks
+]
+
+
+@pytest.mark.parametrize("deck,overrides,cycles", CASES)
+def test_history_loop_bit_exact(gpu_device, deck, overrides, cycles):
+    from oracle import orc
+    pin = load_deck(deck, overrides)
+    drv = _gpu_problem(pin, gpu_device)
+    O, mesh, _ = make_oracle(load_deck(deck, overrides), orc.MATH_PORTABLE)
+    _compare_swarm(drv.md, O)          # sourcing
+    _compare_fields(drv.md, O, ("tally", "src_num"))
+    for _ in range(cycles):
+        drv.Step()
+    run_oracle_cycles(O, pin, cycles)
+    _compare_swarm(drv.md, O)
+    _compare_fields(drv.md, O)
+    assert drv.md.events == O.events
+    # every particle stops exactly at census, |v| = c or 0
+    g = drv.md.get_swarm()
+    assert np.all(g["t"] >= drv.time)
+
+
+def test_absorption_emission_feedback_bit_exact(gpu_device):
+    """Absorbing, emitting material with feedback (the inf.in regime): exercises absorption
+    tallies, removal/compaction, the emission source and UpdateFluid."""
+    from oracle import orc
+    ov = {"parthenon/mesh/nx1": 16, "parthenon/meshblock/nx1": 8, "jaybenne/num_particles": 20000,
+          "jaybenne/do_emission": "true", "jaybenne/do_feedback": "true",
+          "mcblock/opacity_model": "constant", "mcblock/opacity_constant_value": 40.0,
+          "mcblock/scattering_constant_value": 20.0, "mcblock/initial_temperature": 1.0e6}
+    pin = load_deck("stepdiff", ov)
+    drv = _gpu_problem(pin, gpu_device)
+    O, _, _ = make_oracle(load_deck("stepdiff", ov), orc.MATH_PORTABLE)
+    for _ in range(3):
+        drv.Step()
+    run_oracle_cycles(O, pin, 3)
+    st = drv.md.stats()
+    assert st["n_absorbed"] > 1000
+    # compaction reorders the survivors: compare as sets keyed by stream id
+    g = drv.md.get_swarm()
+    order_g = np.argsort(g["id"])
+    order_o = np.argsort(O.sw["id"][:O.n])
+    assert drv.md.n == O.n
+    for k in ("id", "ctr", "ip", "blk") + orc.SWARM_F64:
+        assert np.array_equal(g[k][order_g], O.sw[k][:O.n][order_o]), k
+    _compare_fields(drv.md, O, ("tally", "edelta", "fleck", "u"))
+
+
+def test_erf_gate_on_gpu(gpu_device):
+    """The reference's own acceptance test (tst/stepdiff.py): 128 cells, 1 block, 1e5 particles,
+    10 cycles, solution-weighted mean fractional error of energy_tally <= 0.05."""
+    from jaybenne_amd import analysis
+    pin = load_deck("stepdiff", {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128})
+    drv = _gpu_problem(pin, gpu_device)
+    drv.Execute()
+    assert drv.ncycle == 10
+    tally = np.zeros(drv.mesh.field_shape)
+    tally[drv.md.gids] = drv.md.get_field("tally")
+    err = analysis.analytic_errors(drv.mesh, tally, drv.time)
+    assert err["mean_frac_error_weighted"] <= 0.05, err
+
+
+def test_separate_tasks_match_fused_step(gpu_device):
+    """TransportPhotons + CheckCompletion + EvaluateRadiationEnergy as separate tasks give the
+    same tally as the fused census tally of RadiationStep."""
+    from jaybenne_amd import jaybenne as jb
+    pin = load_deck("stepdiff", {"jaybenne/num_particles": 5000})
+    a = _gpu_problem(pin, gpu_device)
+    b = _gpu_problem(load_deck("stepdiff", {"jaybenne/num_particles": 5000}), gpu_device)
+    a.Step()
+    dt = b.dt
+    jb.UpdateDerivedTransportFields(b.md, dt)
+    jb.TransportPhotons(b.md, 0.0, dt)
+    assert jb.CheckCompletion(b.md, dt) == jb.TaskStatus.complete
+    assert b.md.num_unfinished == 0
+    assert jb.CheckCompletion(b.md, 2 * dt) == jb.TaskStatus.iterate
+    assert b.md.num_unfinished == b.md.n
+    jb.EvaluateRadiationEnergy(b.md)
+    np.testing.assert_allclose(a.md.get_field("tally"), b.md.get_field("tally"), rtol=1e-12)
+    ga, gb = a.md.get_swarm(), b.md.get_swarm()
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
