@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-histories/s of one radiation cycle on `stepdiff`
+(BASELINE.json metric), on N GPUs of one node.
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): inputs/stepdiff.in as a pure-IMC
+uniform 3-D mesh, 64 meshblocks of 64^3 cells (256^3 cells) and 1e7 particles PER GPU; for N > 1
+the block grid grows to (8,4,4), (8,8,4), (8,8,8) blocks at fixed cell size, blocks are dealt to
+ranks in Z-order (one octant each at N = 8) and particles that cross into another rank's blocks
+are handed over through RCCL -- weak scaling.  A step = one RadiationStep (reference
+jaybenne.cpp:68-151): derived fields, transport of every photon to census incl. hand-off and the
+completion test, census tally.  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TF = 78.6     # vector FP64, 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+BYTES_PER_HISTORY = 168.0    # 84 B read + 68 B write-back + 16 B census tally RMW
+BYTES_PER_EVENT_IMC = 24.0   # rho, sie, fleck gathered per event (not LDS-staged)
+FLOPS_PER_EVENT = 200.0      # FP64 flop-equivalents per IMC event
+
+
+def block_grid(ngpus: int):
+    return {1: (4, 4, 4), 2: (8, 4, 4), 4: (8, 8, 4), 8: (8, 8, 8)}.get(ngpus) or (4 * ngpus, 4, 4)
+
+
+def make_deck(ngpus: int, particles_per_gpu: int, block_nx: int = 64):
+    from helpers import load_deck
+    nb = block_grid(ngpus)
+    ov = {"jaybenne/num_particles": particles_per_gpu * ngpus}
+    for d in range(3):
+        ext = nb[d] / 4.0                      # dx = 1/256 for every N (with 64^3 blocks)
+        ov[f"parthenon/mesh/nx{d + 1}"] = nb[d] * block_nx
+        ov[f"parthenon/meshblock/nx{d + 1}"] = block_nx
+        ov[f"parthenon/mesh/x{d + 1}min"] = -0.5 * ext
+        ov[f"parthenon/mesh/x{d + 1}max"] = 0.5 * ext
+    return load_deck("stepdiff", ov)
+
+
+def cpu_baseline(sample_particles: int, block_nx: int):
+    """The oracle (CPU port of the reference algorithm, libm arithmetic) on the same workload with
+    a bounded number of particles, on this box's host cores."""
+    from helpers import make_oracle
+    from oracle import orc
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(avail, 16)   # the GPU box grants a 16-core share per GPU
+    pin = make_deck(1, sample_particles, block_nx)
+    O, _, _ = make_oracle(pin, orc.MATH_LIBM, threads=threads)
+    dt = pin.GetReal("jaybenne", "dt")
+    n0 = O.n
+    t0 = time.perf_counter()
+    O.RadiationStep(0.0, dt)
+    wall = time.perf_counter() - t0
+    return {"value": n0 / wall, "unit": "particle-histories/s", "cores": threads, "kind": "port",
+            "sample": f"1 cycle of the same mesh with {n0} particles (OpenMP over particles, "
+                      f"{O.events / wall:.3e} events/s, {wall:.1f} s)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--particles-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--block-nx", type=int, default=64)
+    ap.add_argument("--cpu-sample", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from jaybenne_amd import mcblock
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    comm = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        from jaybenne_amd.comm import Comm
+        comm = Comm(device=device)
+
+    pin = make_deck(args.gpus, args.particles_per_gpu, args.block_nx)
+    drv = mcblock.McblockDriver(pin, rank=rank, nranks=world, comm=comm, device=device,
+                                capacity_factor=1.5)
+    md = drv.md
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if comm is not None:
+            comm.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        drv.Step()
+    sync_all()
+    ev0 = md.events
+    md.kernel_events = []
+    histories = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        histories += md.n          # photons alive at the start of the cycle, this rank
+        drv.Step()
+    sync_all()
+    wall = time.perf_counter() - t0
+    events = md.events - ev0
+    if comm is not None:
+        wall = comm.allreduce_max_float(wall)
+        histories, events = (int(v) for v in comm.allreduce_sum_int64(np.array([histories, events])))
+
+    if rank == 0:
+        # dominant kernel: k_transport, timed with HIP events on its stream (rank 0's launches)
+        kt = [(a.elapsed_time(b) * 1e-3, n) for a, b, n in md.kernel_events]
+        k_time = sum(t for t, _ in kt)
+        k_hist = sum(n for _, n in kt)
+        ev_per_hist = events / max(histories, 1)
+        k_bytes = k_hist * (BYTES_PER_HISTORY + BYTES_PER_EVENT_IMC * ev_per_hist)
+        achieved = k_bytes / k_time / 1e9 if k_time > 0 else 0.0
+        fp64 = k_hist * ev_per_hist * FLOPS_PER_EVENT / k_time / 1e12 if k_time > 0 else 0.0
+        out = {
+            "metric": "particle-histories/s (whole node) on stepdiff",
+            "value": histories / wall,
+            "unit": "particle-histories/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "stepdiff pure-IMC, uniform 3-D mesh, "
+                                   f"{md.mesh.nblocks} meshblocks of {args.block_nx}^3 cells, "
+                                   f"{args.particles_per_gpu * args.gpus:.3g} particles, 1 cycle per step "
+                                   "(BASELINE.json configs[1] per GPU)",
+                       "blocks_per_gpu": md.nblocks, "particles_per_gpu": args.particles_per_gpu,
+                       "parallelism": f"meshblocks over {args.gpus} rank(s), RCCL particle hand-off"},
+            "events_per_s": events / wall,
+            "events_per_history": ev_per_hist,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_transport<3,false,true>",
+                         "kernel_ms_avg": 1e3 * k_time / max(len(kt), 1),
+                         "launches": len(kt),
+                         "algorithmic_bytes_per_history": BYTES_PER_HISTORY + BYTES_PER_EVENT_IMC * ev_per_hist,
+                         "fp64_valu": {"achieved_tflops": fp64, "peak_tflops": FP64_VALU_PEAK_TF,
+                                       "frac": fp64 / FP64_VALU_PEAK_TF,
+                                       "note": "IMC regime is FP64-VALU bound, not HBM bound (SURVEY 8d)"}},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.block_nx)
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

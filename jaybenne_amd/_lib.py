@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjaybenne_amd.so")
+# JAYBENNE_AMD_LIB selects another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("JAYBENNE_AMD_LIB") or os.path.join(_HERE, "libjaybenne_amd.so")
 
 JB_COMPLETE, JB_ITERATE, JB_INCOMPLETE = 0, 1, 2
 JB_ERR_INVALID, JB_ERR_HIP, JB_ERR_CAPACITY, JB_ERR_UNSUPPORTED = -1, -2, -3, -4

@@ -94,13 +94,20 @@ struct Step {
   bool is_absorbed, is_scattered, is_rejected;
 };
 
-// reference transport_utils.hpp:111-160 -- one IMC tracking step, 2 draws
-template <int NDIM, class Rng>
-__device__ __forceinline__ void ptcl_transport_step(Step &s, Rng &rng) {
-  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+// reference transport_utils.hpp:115-117: mean free paths of a cell.  They depend on the cell
+// only, so the tracking kernel keeps them while a particle stays in its cell (two FP64 divisions
+// saved per scatter); same operations, same bits.
+__device__ __forceinline__ void imc_cell_mfp(double ff, double aa, double ss, double &lam_abs,
+                                             double &lam_sc) {
   const double rmin = DBL_MIN;
-  const double lam_abs = 1.0 / (s.ff * s.aa + rmin);
-  const double lam_sc = 1.0 / (s.ss + (1.0 - s.ff) * s.aa + rmin);
+  lam_abs = 1.0 / (ff * aa + rmin);
+  lam_sc = 1.0 / (ss + (1.0 - ff) * aa + rmin);
+}
+
+// reference transport_utils.hpp:118-159 -- the rest of one IMC tracking step, 2 draws
+template <int NDIM, class Rng>
+__device__ __forceinline__ void imc_step_core(Step &s, double lam_abs, double lam_sc, Rng &rng) {
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   const double dx_abs = -lam_abs * m_log(rng.drand());
   const double dx_sc = -lam_sc * m_log(rng.drand());
   const double dx_end = s.vv * ((s.t_start + s.dt) - s.t);
@@ -141,6 +148,14 @@ __device__ __forceinline__ void ptcl_transport_step(Step &s, Rng &rng) {
   if (multi_d && fabs(s.y - s.yu) < fdy) s.y = s.yu + fdy;
   if (three_d && fabs(s.z - s.zl) < fdz) s.z = s.zl - fdz;
   if (three_d && fabs(s.z - s.zu) < fdz) s.z = s.zu + fdz;
+}
+
+// reference transport_utils.hpp:111-160 -- one IMC tracking step, 2 draws
+template <int NDIM, class Rng>
+__device__ __forceinline__ void ptcl_transport_step(Step &s, Rng &rng) {
+  double lam_abs, lam_sc;
+  imc_cell_mfp(s.ff, s.aa, s.ss, lam_abs, lam_sc);
+  imc_step_core<NDIM>(s, lam_abs, lam_sc, rng);
 }
 
 // reference transport_utils.hpp:163-277 -- one DDMC step

@@ -177,6 +177,7 @@ class MeshData:
         self.next_id = 0     # first unused stream id (global, kept in step on every rank)
         self.epoch = 0       # source-call counter (keys the per-cell rounding streams)
         self.events = 0
+        self.kernel_events = None   # set to [] to time every transport launch with HIP events
         self._make_mesh_handle(owner)
 
     # ---- C views
@@ -230,9 +231,11 @@ class MeshData:
             pass
 
     # ---- host <-> device helpers for the harness
-    def set_field(self, name: str, host: np.ndarray) -> None:
-        """host: [nblocks_total, nk, nj, ni] (whole mesh) -> this rank's blocks."""
-        self.fields[name].copy_(torch.from_numpy(np.ascontiguousarray(host[self.gids])))
+    def set_field(self, name: str, host: np.ndarray, local: bool = False) -> None:
+        """host: [nblocks_total, nk, nj, ni] (whole mesh; this rank's blocks are picked out) or,
+        with ``local=True``, [nblocks_local, nk, nj, ni]."""
+        src = host if local else host[self.gids]
+        self.fields[name].copy_(torch.from_numpy(np.ascontiguousarray(src)))
 
     def get_field(self, name: str) -> np.ndarray:
         return self.fields[name].cpu().numpy()
@@ -304,8 +307,15 @@ def _transport(md: MeshData, t_start: float, dt: float, first: int, last: Option
     md._sync_stream()
     last = md.n if last is None else last
     fn = md.lib.jb_transport_photons_ddmc if ddmc else md.lib.jb_transport_photons
+    timed = md.kernel_events is not None and last > first
+    if timed:   # HIP events on the stream the kernel is launched on (bench.py roofline)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(md.device))
     _lib.check(fn(md.pkg.ctx, md.handle, C.byref(md.sv), t_start, dt, first, last,
                   int(fuse_census_tally)))
+    if timed:
+        ev1.record(torch.cuda.current_stream(md.device))
+        md.kernel_events.append((ev0, ev1, last - first))
     return TaskStatus.complete
 
 

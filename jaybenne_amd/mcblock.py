@@ -108,21 +108,40 @@ def Initialize(pin: ParameterInput) -> McblockPackage:
     return McblockPackage(problem_id, t0, rho0, initial_radiation, eos, opacity, scattering)
 
 
-def ProblemGenerator(mesh: Mesh, pkg: McblockPackage) -> Dict[str, np.ndarray]:
-    """Initial material state on the host: returns rho, sie, u with ghost zones filled
-    (reference mcblock.cpp:155-203, 237-262 followed by the ghost exchange + FillDerived that
-    Parthenon runs at the end of initialisation)."""
-    rho = mesh.new_field(pkg.initial_density)
+def ProblemGenerator(mesh: Mesh, pkg: McblockPackage, gids=None,
+                     analytic_ghosts: bool = True) -> Dict[str, np.ndarray]:
+    """Initial material state on the host for the blocks ``gids`` (default: all): returns rho,
+    sie, u as ``[len(gids), nk, nj, ni]`` arrays with ghost zones filled (reference
+    mcblock.cpp:155-203, 237-262 followed by the ghost exchange + FillDerived that Parthenon runs
+    at the end of initialisation).
+
+    The stepdiff state is a function of x1 alone with its step on a block boundary, so the ghost
+    exchange has a closed form: evaluate the same function at the ghost-cell centre, clamped
+    into the domain in x1 (outflow copies the edge cell), periodic in x2/x3.
+    ``analytic_ghosts=False`` runs the general by-position exchange of ``Mesh.fill_ghosts``
+    instead (whole mesh only); tests check that both agree."""
     cv = pkg.eos.SpecificHeatFromDensityInternalEnergy(pkg.initial_density, 1.0)
-    sie = mesh.new_field(cv * pkg.initial_temperature)
-    if pkg.problem_id == "stepdiff":
+    if gids is None:
+        gids = np.arange(mesh.nblocks)
+    gids = np.asarray(gids)
+    shape = (len(gids),) + tuple(mesh.field_shape[1:])
+    rho = np.full(shape, pkg.initial_density, dtype=np.float64)
+    sie = np.full(shape, cv * pkg.initial_temperature, dtype=np.float64)
+    stepdiff = pkg.problem_id == "stepdiff"
+    if stepdiff:
         ttlow = 1.0e-5 * pkg.initial_temperature
-        for b in range(mesh.nblocks):
-            x1v = mesh.cell_centers(b, 0)
-            sie[b][:, :, x1v >= 0.0] = cv * ttlow
+        for n, b in enumerate(gids):
+            x1v = mesh.cell_centers(int(b), 0)
+            if analytic_ghosts:
+                half = 0.5 * mesh.blk_dx[int(b), 0]
+                x1v = np.clip(x1v, mesh.gmin[0] + half, mesh.gmax[0] - half)
+            sie[n][:, :, x1v >= 0.0] = cv * ttlow
     u = rho * sie                       # PostInitialization
-    mesh.fill_ghosts(rho)
-    mesh.fill_ghosts(u)
+    if not analytic_ghosts:
+        if len(gids) != mesh.nblocks:
+            raise ValueError("the by-position ghost exchange needs the whole mesh")
+        mesh.fill_ghosts(rho)
+        mesh.fill_ghosts(u)
     sie = UpdateDerived(rho, u)
     return {"rho": rho, "sie": sie, "u": u}
 
@@ -161,9 +180,9 @@ class McblockDriver:
         self.ncycle = 0
         self.dt = jb.EstimateTimestepMesh(self.md)
         # ProblemGenerator + PostInitialization + initial ghost fill / FillDerived
-        ic = ProblemGenerator(self.mesh, self.mcb)
+        ic = ProblemGenerator(self.mesh, self.mcb, gids=self.md.gids)
         for name in ("rho", "sie", "u"):
-            self.md.set_field(name, ic[name])
+            self.md.set_field(name, ic[name], local=True)
         jb.InitializeRadiation(self.md, self.mcb.initial_radiation == "thermal")
 
     def HostUpdateTasks(self) -> None:

@@ -290,7 +290,7 @@ class Mesh:
                 continue
             kk, jj, ii = K[ghost], J[ghost], I[ghost]
             base = np.stack([xs[0][ii], xs[1][jj], xs[2][kk]], axis=1)
-            acc = np.zeros(len(ii))
+            samples = []
             for o in offs:
                 p = base + np.asarray(o) * self.blk_dx[b]
                 for d in range(self.ndim):
@@ -312,8 +312,11 @@ class Mesh:
                     else:
                         c = np.zeros(len(ii), dtype=np.int64)
                     cidx.append(c)
-                acc += src[nbk, cidx[2], cidx[1], cidx[0]]
-            f[b][ghost] = acc / len(offs)
+                samples.append(src[nbk, cidx[2], cidx[1], cidx[0]])
+            # pairwise sum: exact when the samples are equal (same-level or coarser neighbour)
+            while len(samples) > 1:
+                samples = [samples[q] + samples[q + 1] for q in range(0, len(samples), 2)]
+            f[b][ghost] = samples[0] / len(offs)
 
     # ------------------------------------------------------------------ partition
     def partition(self, nranks: int) -> np.ndarray:

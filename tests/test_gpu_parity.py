@@ -229,14 +229,18 @@ def _compare_swarm(md, O, exact=True):
             np.testing.assert_allclose(a, b, rtol=1e-9, atol=0, err_msg=k)
 
 
-def _compare_fields(md, O, names=("tally", "edelta", "fleck", "src_num", "src_ew")):
+def _compare_fields(md, O, names=("tally", "edelta", "fleck", "src_num", "src_ew"), scale=None):
+    """1e-12 relative; `scale` (per cell) is the magnitude of the terms summed into a cell when
+    the sum itself cancels (energy_delta = absorbed - emitted)."""
     sl = md.mesh.interior()
     for k in names:
         a = md.get_field(k)[sl]
         b = O.fields[k][md.gids][sl]
         fin = np.isfinite(b)
         assert np.array_equal(np.isfinite(a), fin), k
-        np.testing.assert_allclose(a[fin], b[fin], rtol=1e-12, atol=0, err_msg=k)
+        ref = np.abs(b) if scale is None else np.maximum(np.abs(b), scale)
+        bad = np.abs(a - b)[fin] > 1e-12 * ref[fin]
+        assert not bad.any(), (k, a[fin][bad][:4], b[fin][bad][:4])
 
 
 def _gpu_problem(pin, gpu_device):
@@ -293,19 +297,39 @@ def test_absorption_emission_feedback_bit_exact(gpu_device):
     pin = load_deck("stepdiff", ov)
     drv = _gpu_problem(pin, gpu_device)
     O, _, _ = make_oracle(load_deck("stepdiff", ov), orc.MATH_PORTABLE)
-    for _ in range(3):
+    def compare(exact):
+        # compaction reorders the survivors: compare as sets keyed by stream id
+        g = drv.md.get_swarm()
+        order_g = np.argsort(g["id"])
+        order_o = np.argsort(O.sw["id"][:O.n])
+        assert drv.md.n == O.n
+        for k in ("id", "ctr", "ip", "blk"):
+            assert np.array_equal(g[k][order_g], O.sw[k][:O.n][order_o]), k
+        for k in orc.SWARM_F64:
+            a, b = g[k][order_g], O.sw[k][:O.n][order_o]
+            if exact:
+                assert np.array_equal(a, b), k
+            else:
+                np.testing.assert_allclose(a, b, rtol=1e-11, atol=0, err_msg=k)
+        sl = drv.mesh.interior()
+        emitted = np.where(O.fields["src_num"][sl] > 0,
+                           O.fields["src_num"][sl] * O.fields["src_ew"][sl], 0.0)
+        _compare_fields(drv.md, O, ("tally", "fleck", "u"))
+        _compare_fields(drv.md, O, ("edelta",), scale=emitted)
+
+    # cycle 1: nothing depends on the order of the absorption atomics yet -> bit-exact particles
+    drv.Step()
+    run_oracle_cycles(O, pin, 1)
+    assert drv.md.stats()["n_absorbed"] > 1000
+    compare(exact=True)
+    # later cycles: u (hence T, the Fleck factor and the emission weights) carries the
+    # summation order of energy_delta in its last bits -> 1e-11 relative on the attributes
+    dt = pin.GetReal("jaybenne", "dt")
+    for cyc in (1, 2):
         drv.Step()
-    run_oracle_cycles(O, pin, 3)
-    st = drv.md.stats()
-    assert st["n_absorbed"] > 1000
-    # compaction reorders the survivors: compare as sets keyed by stream id
-    g = drv.md.get_swarm()
-    order_g = np.argsort(g["id"])
-    order_o = np.argsort(O.sw["id"][:O.n])
-    assert drv.md.n == O.n
-    for k in ("id", "ctr", "ip", "blk") + orc.SWARM_F64:
-        assert np.array_equal(g[k][order_g], O.sw[k][:O.n][order_o]), k
-    _compare_fields(drv.md, O, ("tally", "edelta", "fleck", "u"))
+        O.RadiationStep(cyc * dt, dt)
+        O.fields["sie"][...] = O.fields["u"] / O.fields["rho"]
+    compare(exact=False)
 
 
 def test_erf_gate_on_gpu(gpu_device):
