@@ -113,7 +113,8 @@ typedef struct jb_mesh_view {
 } jb_mesh_view;
 
 /* The photons swarm (jaybenne.cpp:236-245): structure of arrays, DEVICE pointers, particles
- * 0..n-1 valid.  id/ctr carry each particle's random stream (see csrc/jb_rng.hpp). */
+ * 0..n-1 valid.  rng is the state of each particle's own random stream (csrc/jb_rng.hpp); id is
+ * the particle's creation index, which seeded that stream. */
 typedef struct jb_swarm_view {
   int64_t n, capacity;
   double *x, *y, *z;      /* swarm_position::x,y,z */
@@ -123,7 +124,7 @@ typedef struct jb_swarm_view {
   int32_t *blk;           /* local block index (global id when status == JB_ST_OUTGOING) */
   int32_t *status;
   uint64_t *id;
-  uint32_t *ctr;
+  uint64_t *rng;
 } jb_swarm_view;
 
 typedef struct jb_transport_stats {
@@ -237,8 +238,10 @@ jb_status jb_debug_philox(jb_context *ctx, const uint32_t ctr[4], const uint32_t
                           uint32_t out[4]);
 jb_status jb_debug_rocrand_philox(jb_context *ctx, uint64_t seed, uint64_t subsequence,
                                   uint32_t out[8]);
-jb_status jb_debug_draw_stream(jb_context *ctx, uint32_t key0, uint32_t key1, uint64_t id,
-                               uint32_t first, int n, double *out_host);
+jb_status jb_debug_seed_state(jb_context *ctx, uint32_t seed, uint32_t domain, uint64_t id,
+                              uint64_t *state);
+jb_status jb_debug_draw_stream(jb_context *ctx, uint64_t state, int n, double *out_host,
+                               uint64_t *final_state);
 /* which: 0 log, 1 sin, 2 cos, 3 acos, 4 sqrt, 5 reciprocal */
 jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n, double *out_host);
 /* step functions on a tape of uniforms.  st: jb_debug_step record (see below); which:

@@ -67,7 +67,7 @@ SWARM_I32 = ("ip", "jp", "kp", "blk", "status")
 class SwarmView(C.Structure):
     _fields_ = ([("n", C.c_int64), ("capacity", C.c_int64)] +
                 [(n, C.c_void_p) for n in SWARM_F64 + SWARM_I32] +
-                [("id", C.c_void_p), ("ctr", C.c_void_p)])
+                [("id", C.c_void_p), ("rng", C.c_void_p)])
 
 
 class TransportStats(C.Structure):
@@ -121,7 +121,8 @@ PROTOTYPES = {
     "jb_debug_philox": (_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                C.POINTER(C.c_uint32)]),
     "jb_debug_rocrand_philox": (_int, [_vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),
-    "jb_debug_draw_stream": (_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _int, _vp]),
+    "jb_debug_seed_state": (_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "jb_debug_draw_stream": (_int, [_vp, C.c_uint64, _int, _vp, C.POINTER(C.c_uint64)]),
     "jb_debug_math": (_int, [_vp, _int, _vp, _int, _vp]),
     "jb_debug_step_call": (_int, [_vp, _int, C.POINTER(DebugStep), _vp, _int, C.POINTER(_int)]),
     "jb_debug_sample_call": (_int, [_vp, _int, _vp, _vp, _vp, _int, _vp, _vp, C.POINTER(_int)]),

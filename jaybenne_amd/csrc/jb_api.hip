@@ -242,6 +242,16 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   UP(blk_xmin, 3 * v->nblocks);
   UP(blk_xmax, 3 * v->nblocks);
   UP(blk_dx, 3 * v->nblocks);
+  {
+    std::vector<double> inv(3 * (size_t)v->nblocks);
+    for (size_t q = 0; q < inv.size(); ++q) inv[q] = 1.0 / v->blk_dx[q];
+    if ((st = upload(m, inv.data(), inv.size(), &D.blk_inv_dx)) != JB_COMPLETE) {
+      jb_mesh_destroy(m);
+      return st;
+    }
+    for (int d = 0; d < 3; ++d)
+      D.inv_leaf_len[d] = 1.0 / ((v->gmax[d] - v->gmin[d]) / (double)v->nleaf[d]);
+  }
   UP(blk_level, v->nblocks);
   UP(blk_nbr_lev, 6 * v->nblocks);
 #undef UP
@@ -261,6 +271,26 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   UPF(rho) UPF(sie) UPF(u) UPF(fleck) UPF(tally) UPF(edelta) UPF(src_ew) UPF(src_num)
   UPF(P1) UPF(P2) UPF(P3)
 #undef UPF
+  // gray (frequency-independent) opacities: library-owned per-cell mean-free-path arrays
+  D.lam_abs = nullptr;
+  D.lam_sc = nullptr;
+  if (ctx->opac.model == JB_OPAC_GRAY && ctx->scat.model == JB_SCAT_GRAY) {
+    const size_t per = (size_t)D.ntot;
+    double *base = nullptr;
+    hipError_t e = hipMalloc(&base, sizeof(double) * per * 2 * (size_t)v->nblocks);
+    if (e != hipSuccess) { jb_mesh_destroy(m); return fail(JB_ERR_HIP, "hipMalloc of the mean-free-path arrays failed: %s", hipGetErrorString(e)); }
+    m->owned.push_back(base);
+    std::vector<const double *> pa(v->nblocks), ps(v->nblocks);
+    for (int b = 0; b < v->nblocks; ++b) {
+      pa[b] = base + (size_t)(2 * b) * per;
+      ps[b] = base + (size_t)(2 * b + 1) * per;
+    }
+    const double *const *tmp = nullptr;
+    if ((st = upload(m, (const double *const *)pa.data(), (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
+    D.lam_abs = (double *const *)tmp;
+    if ((st = upload(m, (const double *const *)ps.data(), (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
+    D.lam_sc = (double *const *)tmp;
+  }
   *out = m;
   return JB_COMPLETE;
 }
@@ -277,7 +307,7 @@ static DevSwarm dev_swarm(const jb_swarm_view *s) {
   S.x = s->x; S.y = s->y; S.z = s->z; S.vx = s->vx; S.vy = s->vy; S.vz = s->vz;
   S.t = s->t; S.w = s->w; S.e = s->e;
   S.ip = s->ip; S.jp = s->jp; S.kp = s->kp; S.blk = s->blk; S.status = s->status;
-  S.id = (uint64_t *)s->id; S.ctr = s->ctr;
+  S.id = (uint64_t *)s->id; S.rng = (uint64_t *)s->rng;
   return S;
 }
 
@@ -286,7 +316,7 @@ static jb_status check_swarm(const jb_swarm_view *s, const char *who) {
   if (s->n < 0 || s->n > s->capacity) return fail(JB_ERR_INVALID, "%s: swarm n outside [0, capacity]", who);
   if (s->capacity > 0 && (!s->x || !s->y || !s->z || !s->vx || !s->vy || !s->vz || !s->t || !s->w ||
                           !s->e || !s->ip || !s->jp || !s->kp || !s->blk || !s->status || !s->id ||
-                          !s->ctr))
+                          !s->rng))
     return fail(JB_ERR_INVALID, "%s: null swarm array", who);
   return JB_COMPLETE;
 }
@@ -383,12 +413,15 @@ template <int NDIM, bool DDMC>
 static void launch_transport(jb_context *ctx, const DevMesh &M, const DevSwarm &S, double t_start,
                              double dt, long long first, long long last, bool tally) {
   const int g = grid_for(ctx, last - first, 8);
-  if (tally)
-    hipLaunchKernelGGL((k_transport<NDIM, DDMC, true>), dim3(g), dim3(kBlock), 0, ctx->stream, M,
-                       ctx->dp, S, t_start, dt, first, last, ctx->counters_d);
-  else
-    hipLaunchKernelGGL((k_transport<NDIM, DDMC, false>), dim3(g), dim3(kBlock), 0, ctx->stream, M,
-                       ctx->dp, S, t_start, dt, first, last, ctx->counters_d);
+  const bool gray = M.lam_abs != nullptr;
+#define JB_LAUNCH(T, G)                                                                            \
+  hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G>), dim3(g), dim3(kBlock), 0, ctx->stream, M,    \
+                     ctx->dp, S, t_start, dt, first, last, ctx->counters_d)
+  if (tally && gray) JB_LAUNCH(true, true);
+  else if (tally) JB_LAUNCH(true, false);
+  else if (gray) JB_LAUNCH(false, true);
+  else JB_LAUNCH(false, false);
+#undef JB_LAUNCH
 }
 
 static jb_status transport_impl(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
@@ -697,10 +730,14 @@ __global__ void k_dbg_rocrand(unsigned long long seed, unsigned long long subseq
   out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
   out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
 }
-__global__ void k_dbg_draw(uint32_t k0, uint32_t k1, unsigned long long id, uint32_t first, int n,
-                           double *out) {
-  PhiloxRng rng(k0, k1, id, first);
+__global__ void k_dbg_draw(unsigned long long state, int n, double *out, unsigned long long *fin) {
+  XorShiftRng rng(state);
   for (int i = 0; i < n; ++i) out[i] = rng.drand();
+  *fin = rng.s;
+}
+__global__ void k_dbg_seed(uint32_t seed, uint32_t domain, unsigned long long id,
+                           unsigned long long *out) {
+  *out = rng_seed_state(seed, domain, id);
 }
 __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -799,14 +836,26 @@ extern "C" jb_status jb_debug_rocrand_philox(jb_context *ctx, uint64_t seed, uin
   JB_HIP(o.get(out, 32));
   return JB_COMPLETE;
 }
-extern "C" jb_status jb_debug_draw_stream(jb_context *ctx, uint32_t key0, uint32_t key1, uint64_t id,
-                                          uint32_t first, int n, double *out_host) {
-  if (!ctx || n < 0) return fail(JB_ERR_INVALID, "bad argument");
+extern "C" jb_status jb_debug_seed_state(jb_context *ctx, uint32_t seed, uint32_t domain,
+                                         uint64_t id, uint64_t *state) {
+  if (!ctx || !state) return fail(JB_ERR_INVALID, "bad argument");
   DbgBuf o;
+  JB_HIP(o.put(nullptr, 8));
+  hipLaunchKernelGGL(k_dbg_seed, dim3(1), dim3(1), 0, ctx->stream, seed, domain, (unsigned long long)id, (unsigned long long *)o.d);
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  JB_HIP(o.get(state, 8));
+  return JB_COMPLETE;
+}
+extern "C" jb_status jb_debug_draw_stream(jb_context *ctx, uint64_t state, int n, double *out_host,
+                                          uint64_t *final_state) {
+  if (!ctx || n < 0 || !final_state) return fail(JB_ERR_INVALID, "bad argument");
+  DbgBuf o, f;
   JB_HIP(o.put(nullptr, sizeof(double) * n));
-  hipLaunchKernelGGL(k_dbg_draw, dim3(1), dim3(1), 0, ctx->stream, key0, key1, (unsigned long long)id, first, n, (double *)o.d);
+  JB_HIP(f.put(nullptr, 8));
+  hipLaunchKernelGGL(k_dbg_draw, dim3(1), dim3(1), 0, ctx->stream, (unsigned long long)state, n, (double *)o.d, (unsigned long long *)f.d);
   JB_HIP(hipStreamSynchronize(ctx->stream));
   JB_HIP(o.get(out_host, sizeof(double) * n));
+  JB_HIP(f.get(final_state, 8));
   return JB_COMPLETE;
 }
 extern "C" jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n,

@@ -20,9 +20,14 @@ struct DevMesh {
   double gmin[3], gmax[3];
   const int *leaf_map, *owner, *local_index, *gid;
   const double *blk_xmin, *blk_xmax, *blk_dx;
+  const double *blk_inv_dx;  // [nblocks][3]: 1.0 / dx, computed once on the host
+  double inv_leaf_len[3];    // 1.0 / ((gmax - gmin) / nleaf)
   const int *blk_level, *blk_nbr_lev;
   double *const *rho, *const *sie, *const *u, *const *fleck, *const *tally, *const *edelta,
       *const *src_ew, *const *src_num, *const *P1, *const *P2, *const *P3;
+  // library-owned per-cell mean free paths 1/(f sigma_a), 1/(sigma_s + (1-f) sigma_a), filled by
+  // UpdateDerivedTransportFields for frequency-independent (gray) opacities
+  double *const *lam_abs, *const *lam_sc;
 };
 
 struct DevParams {
@@ -38,8 +43,8 @@ struct DevParams {
 struct DevSwarm {
   double *x, *y, *z, *vx, *vy, *vz, *t, *w, *e;
   int *ip, *jp, *kp, *blk, *status;
-  uint64_t *id;
-  uint32_t *ctr;
+  uint64_t *id;   // creation index (diagnostic key, never read by the tracking kernel)
+  uint64_t *rng;  // xorshift64* state of the particle's stream
 };
 
 enum { ST_ACTIVE = 0, ST_ABSORBED = 1, ST_ESCAPED = 2, ST_OUTGOING = 3 };
@@ -70,6 +75,7 @@ __device__ __forceinline__ double opac_scattering(const DevParams &P, double rho
 // ---- per-lane copy of the current block's geometry ---------------------------------------------
 struct Blk {
   double xmin[3], dx[3], x0[3];  // x0 = coordinate of index 0 (first ghost) per dimension
+  double inv_dx[3];
   double dx_push;                // min(dx1, dx2, dx3)  (transport.cpp:75-78)
 };
 
@@ -80,6 +86,7 @@ __device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
     B.xmin[d] = M.blk_xmin[3 * b + d];
     B.dx[d] = M.blk_dx[3 * b + d];
     B.x0[d] = B.xmin[d] - (double)first[d] * B.dx[d];
+    B.inv_dx[d] = M.blk_inv_dx[3 * b + d];
   }
   B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));
 }
@@ -89,13 +96,16 @@ __device__ __forceinline__ double xc(const Blk &B, int d, int idx) {
   return B.x0[d] + ((double)idx + 0.5) * B.dx[d];
 }
 
-// SwarmDeviceContext::Xtoijk (transport.cpp:96,146)
+// SwarmDeviceContext::Xtoijk (transport.cpp:96,146): (x - x_min) * (1 / dx) with the reciprocal a
+// per-block constant.  Parthenon's own arithmetic is un-vendored; the step functions keep
+// particles >= 2e-9 dx away from cell faces, so the index cannot depend on the rounding of the
+// quotient.  Saves three FP64 divisions per event.
 template <int NDIM>
 __device__ __forceinline__ void xtoijk(const DevMesh &M, const Blk &B, double x, double y, double z,
                                        int &i, int &j, int &k) {
-  i = (int)floor((x - B.xmin[0]) / B.dx[0]) + M.is;
-  j = (NDIM >= 2) ? (int)floor((y - B.xmin[1]) / B.dx[1]) + M.js : M.js;
-  k = (NDIM >= 3) ? (int)floor((z - B.xmin[2]) / B.dx[2]) + M.ks : M.ks;
+  i = (int)floor((x - B.xmin[0]) * B.inv_dx[0]) + M.is;
+  j = (NDIM >= 2) ? (int)floor((y - B.xmin[1]) * B.inv_dx[1]) + M.js : M.js;
+  k = (NDIM >= 3) ? (int)floor((z - B.xmin[2]) * B.inv_dx[2]) + M.ks : M.ks;
 }
 
 __device__ __forceinline__ bool on_block(const DevMesh &M, int i, int j, int k) {
@@ -149,8 +159,7 @@ __device__ __forceinline__ int find_block(const DevMesh &M, double x, double y, 
   int l[3] = {0, 0, 0};
 #pragma unroll
   for (int d = 0; d < NDIM; ++d) {
-    const double len = (M.gmax[d] - M.gmin[d]) / (double)M.nleaf[d];
-    int q = (int)floor((p[d] - M.gmin[d]) / len);
+    int q = (int)floor((p[d] - M.gmin[d]) * M.inv_leaf_len[d]);
     q = q < 0 ? 0 : q;
     q = q > M.nleaf[d] - 1 ? M.nleaf[d] - 1 : q;
     l[d] = q;

@@ -58,7 +58,15 @@ __global__ void __launch_bounds__(kBlock) k_fleck(DevMesh M, DevParams P, double
     const double rho = M.rho[b][q];
     const double temp = eos_temperature(P, rho, M.sie[b][q]);
     const double emis = opac_emissivity(P, rho, temp);
-    M.fleck[b][q] = 1.0 / (1.0 + (4.0 * emis / (rho * P.cv * temp)) * dt);
+    const double ff = 1.0 / (1.0 + (4.0 * emis / (rho * P.cv * temp)) * dt);
+    M.fleck[b][q] = ff;
+    if (M.lam_abs) {  // gray opacities: the IMC mean free paths are per-cell constants
+      double la, ls;
+      imc_cell_mfp(ff, opac_absorption(P, rho, temp, 1.0), opac_scattering(P, rho, temp, 1.0), la,
+                   ls);
+      M.lam_abs[b][q] = la;
+      M.lam_sc[b][q] = ls;
+    }
   }
 }
 
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(kBlock)
       int i = r - j * M.nx[0];
       k += M.ks; j += M.js; i += M.is;
       const long long q = cidx(M, k, j, i);
-      PhiloxRng rng(P.key0, 1u, cell_stream_id(epoch, M.gid[b], cell), 0u);
+      XorShiftRng rng(rng_seed_state(P.key0, kRngDomainCell, cell_stream_id(epoch, M.gid[b], cell)));
       const double rho = M.rho[b][q];
       const double temp = eos_temperature(P, rho, M.sie[b][q]);
       double erad;
@@ -203,7 +211,7 @@ __global__ void __launch_bounds__(kBlock)
     load_block(M, b, B);
     const long long n = slot_base[b] + np;
     const uint64_t id = id_base[b] + (uint64_t)np;
-    PhiloxRng rng(P.key0, 0u, id, 0u);
+    XorShiftRng rng(rng_seed_state(P.key0, kRngDomainParticle, id));
     S.ip[n] = i; S.jp[n] = j; S.kp[n] = k;
     S.blk[n] = b;
     S.status[n] = ST_ACTIVE;
@@ -229,7 +237,7 @@ __global__ void __launch_bounds__(kBlock)
       S.t[n] = 0.0;
     }
     S.id[n] = id;
-    S.ctr[n] = rng.ctr;
+    S.rng[n] = rng.s;
   }
 }
 
@@ -256,8 +264,11 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 // The history loop.  One lane follows one particle from its state at t_start to census /
 // absorption / escape / departure to another rank; a wave owns 64 consecutive particles and
 // loops until all of them are done, then takes the next batch (grid stride).
-template <int NDIM, bool DDMC, bool TALLY>
-__global__ void __launch_bounds__(kBlock)
+#ifndef JB_TRANSPORT_WAVES_PER_SIMD
+#define JB_TRANSPORT_WAVES_PER_SIMD 1
+#endif
+template <int NDIM, bool DDMC, bool TALLY, bool GRAY>
+__global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
     k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
                 long long last, unsigned long long *counters) {
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
@@ -267,7 +278,7 @@ __global__ void __launch_bounds__(kBlock)
   for (long long n = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; n < last;
        n += (long long)gridDim.x * blockDim.x) {
     if (S.status[n] != ST_ACTIVE) continue;
-    PhiloxRng rng(P.key0, 0u, S.id[n], S.ctr[n]);
+    XorShiftRng rng(S.rng[n]);
     int b = S.blk[n];
     Blk B;
     load_block(M, b, B);
@@ -291,11 +302,21 @@ __global__ void __launch_bounds__(kBlock)
       s.zl = xc(B, 2, kp) - 0.5 * B.dx[2];
       s.zu = xc(B, 2, kp) + 0.5 * B.dx[2];
       const long long q = cidx(M, kp, jp, ip);
-      const double rho = M.rho[b][q];
-      const double temp = eos_temperature(P, rho, M.sie[b][q]);
-      s.ff = M.fleck[b][q];
-      s.ss = opac_scattering(P, rho, temp, ee);
-      s.aa = opac_absorption(P, rho, temp, ee);
+      double lam_abs, lam_sc;
+      if constexpr (GRAY && !DDMC) {
+        // per-cell mean free paths precomputed by k_fleck: two gathers instead of three, and no
+        // division (same values: same operations on the same operands)
+        lam_abs = M.lam_abs[b][q];
+        lam_sc = M.lam_sc[b][q];
+        s.ff = 0.0; s.ss = 0.0; s.aa = 0.0;
+      } else {
+        const double rho = M.rho[b][q];
+        const double temp = eos_temperature(P, rho, M.sie[b][q]);
+        s.ff = M.fleck[b][q];
+        s.ss = opac_scattering(P, rho, temp, ee);
+        s.aa = opac_absorption(P, rho, temp, ee);
+        imc_cell_mfp(s.ff, s.aa, s.ss, lam_abs, lam_sc);
+      }
       s.t = t; s.x = x; s.y = y; s.z = z; s.vx = vx; s.vy = vy; s.vz = vz;
       s.ip = ip; s.jp = jp; s.kp = kp;
       s.is_absorbed = false; s.is_scattered = false; s.is_rejected = false;
@@ -313,7 +334,7 @@ __global__ void __launch_bounds__(kBlock)
         ptcl_ddmc_albedo<NDIM>(s, rng);
         if (!s.is_rejected) ptcl_ddmc_step<NDIM>(s, rng);
       } else {
-        ptcl_transport_step<NDIM>(s, rng);
+        imc_step_core<NDIM>(s, lam_abs, lam_sc, rng);
       }
       t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
 
@@ -356,7 +377,7 @@ __global__ void __launch_bounds__(kBlock)
     S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
     S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
     S.status[n] = status;
-    S.ctr[n] = rng.ctr;
+    S.rng[n] = rng.s;
 
     if (status == ST_ACTIVE) {
       ++c_census;
@@ -397,7 +418,7 @@ __global__ void __launch_bounds__(kBlock)
     const int b = S.blk[n];
     Blk B;
     load_block(M, b, B);
-    PhiloxRng rng(P.key0, 0u, S.id[n], S.ctr[n]);
+    XorShiftRng rng(S.rng[n]);
     double x = S.x[n], y = S.y[n], z = S.z[n];
     double vx = S.vx[n], vy = S.vy[n], vz = S.vz[n];
     int ip = S.ip[n], jp = S.jp[n], kp = S.kp[n];
@@ -405,7 +426,7 @@ __global__ void __launch_bounds__(kBlock)
     S.x[n] = x; S.y[n] = y; S.z[n] = z;
     S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
     S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
-    S.ctr[n] = rng.ctr;
+    S.rng[n] = rng.s;
   }
 }
 
@@ -537,13 +558,13 @@ __global__ void __launch_bounds__(kBlock)
     S.t[d] = S.t[s]; S.w[d] = S.w[s]; S.e[d] = S.e[s];
     S.ip[d] = S.ip[s]; S.jp[d] = S.jp[s]; S.kp[d] = S.kp[s];
     S.blk[d] = S.blk[s]; S.status[d] = ST_ACTIVE;
-    S.id[d] = S.id[s]; S.ctr[d] = S.ctr[s];
+    S.id[d] = S.id[s]; S.rng[d] = S.rng[s];
   }
 }
 
 // -------------------------------------------------------------------------------------------
 // Inter-rank hand-off records: 13 x 8 bytes
-//   0..8  x y z vx vy vz t w e   9 id   10 (ip | jp << 32)   11 (kp | gblock << 32)   12 ctr
+//   0..8  x y z vx vy vz t w e   9 id   10 (ip | jp << 32)   11 (kp | gblock << 32)   12 rng state
 constexpr int kRecWords = 13;
 
 __global__ void __launch_bounds__(kBlock)
@@ -571,7 +592,7 @@ __global__ void __launch_bounds__(kBlock)
     o[9] = (long long)S.id[n];
     o[10] = (long long)(((unsigned long long)(unsigned)S.jp[n] << 32) | (unsigned)S.ip[n]);
     o[11] = (long long)(((unsigned long long)(unsigned)g << 32) | (unsigned)S.kp[n]);
-    o[12] = (long long)S.ctr[n];
+    o[12] = (long long)S.rng[n];
   }
 }
 
@@ -594,7 +615,7 @@ __global__ void __launch_bounds__(kBlock)
     const int g = (int)(unsigned)((unsigned long long)o[11] >> 32);
     S.blk[n] = M.local_index[g];
     S.status[n] = ST_ACTIVE;
-    S.ctr[n] = (uint32_t)o[12];
+    S.rng[n] = (uint64_t)o[12];
   }
 }
 

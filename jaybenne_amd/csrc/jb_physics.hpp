@@ -112,21 +112,19 @@ __device__ __forceinline__ void imc_step_core(Step &s, double lam_abs, double la
   const double dx_sc = -lam_sc * m_log(rng.drand());
   const double dx_end = s.vv * ((s.t_start + s.dt) - s.t);
   double dx_push = dmin(s.dx_push, dx_end);
-  if (s.vx > 0.0)
-    dx_push = dmin(dx_push, s.vv * (s.xu - s.x) / s.vx);
-  else if (s.vx < 0.0)
-    dx_push = dmin(dx_push, s.vv * (s.xl - s.x) / s.vx);
+  // distance to the face the velocity points at (transport_utils.hpp:123-133): one division per
+  // axis, selected operands instead of two divergent branches
+  {
+    const double d = s.vv * ((s.vx > 0.0 ? s.xu : s.xl) - s.x) / s.vx;
+    dx_push = (s.vx != 0.0) ? dmin(dx_push, d) : dx_push;
+  }
   if (multi_d) {
-    if (s.vy > 0.0)
-      dx_push = dmin(dx_push, s.vv * (s.yu - s.y) / s.vy);
-    else if (s.vy < 0.0)
-      dx_push = dmin(dx_push, s.vv * (s.yl - s.y) / s.vy);
+    const double d = s.vv * ((s.vy > 0.0 ? s.yu : s.yl) - s.y) / s.vy;
+    dx_push = (s.vy != 0.0) ? dmin(dx_push, d) : dx_push;
   }
   if (three_d) {
-    if (s.vz > 0.0)
-      dx_push = dmin(dx_push, s.vv * (s.zu - s.z) / s.vz);
-    else if (s.vz < 0.0)
-      dx_push = dmin(dx_push, s.vv * (s.zl - s.z) / s.vz);
+    const double d = s.vv * ((s.vz > 0.0 ? s.zu : s.zl) - s.z) / s.vz;
+    dx_push = (s.vz != 0.0) ? dmin(dx_push, d) : dx_push;
   }
 
   s.is_absorbed = (dx_abs < dx_push) && (dx_abs < dx_sc);

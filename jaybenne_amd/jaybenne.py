@@ -168,9 +168,9 @@ class MeshData:
         for n in _I32:
             self.swarm[n] = torch.zeros(self.capacity, dtype=torch.int32, device=dev)
         self.swarm["id"] = torch.zeros(self.capacity, dtype=torch.int64, device=dev)   # uint64 bits
-        self.swarm["ctr"] = torch.zeros(self.capacity, dtype=torch.int32, device=dev)  # uint32 bits
+        self.swarm["rng"] = torch.zeros(self.capacity, dtype=torch.int64, device=dev)  # uint64 bits
         self.sv = _lib.SwarmView(n=0, capacity=self.capacity)
-        for n in _F64 + _I32 + ("id", "ctr"):
+        for n in _F64 + _I32 + ("id", "rng"):
             setattr(self.sv, n, self.swarm[n].data_ptr())
         self.prefix = torch.zeros(self.nblocks * mesh.ncell, dtype=torch.int32, device=dev)
         self.records: Optional[torch.Tensor] = None
@@ -244,7 +244,7 @@ class MeshData:
         n = self.n
         out = {k: v[:n].cpu().numpy() for k, v in self.swarm.items()}
         out["id"] = out["id"].view(np.uint64)
-        out["ctr"] = out["ctr"].view(np.uint32)
+        out["rng"] = out["rng"].view(np.uint64)
         return out
 
     def stats(self, reset: bool = False) -> Dict[str, int]:

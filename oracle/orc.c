@@ -32,10 +32,13 @@ int orc_get_threads(void) { return orc_threads; }
 void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   orc_philox4x32_10(ctr, key, out);
 }
-void orc_draw_stream(uint32_t key0, uint32_t key1, uint64_t id, uint32_t first, int n,
-                     double *out) {
-  orc_rng r = {key0, key1, id, first, NULL, 0};
+uint64_t orc_seed_state(uint32_t seed, uint32_t domain, uint64_t id) {
+  return orc_rng_seed_state(seed, domain, id);
+}
+uint64_t orc_draw_stream(uint64_t state, int n, double *out) {
+  orc_rng r = orc_rng_from_state(state);
   for (int i = 0; i < n; ++i) out[i] = orc_drand(&r);
+  return r.s;
 }
 void orc_math_log(const double *x, int n, double *out) {
   for (int i = 0; i < n; ++i) out[i] = orc_log(x[i]);
@@ -48,7 +51,7 @@ void orc_math_acos(const double *x, int n, double *out) {
 }
 
 static orc_rng tape_rng(const double *tape, int ntape) {
-  orc_rng r = {0u, 0u, 0ull, 0u, tape, ntape};
+  orc_rng r = {0ull, 0u, tape, ntape};
   return r;
 }
 int orc_sizeof_step(void) { return (int)sizeof(orc_step); }
@@ -135,11 +138,16 @@ static inline double xc(const orc_mesh *M, int b, int d, int first_interior, int
 /* SwarmDeviceContext::Xtoijk: inactive dimensions keep their single index */
 static inline void xtoijk(const orc_mesh *M, const geom *g, int b, double x, double y, double z,
                           int *i, int *j, int *k) {
-  *i = (int)floor((x - M->blk_xmin[3 * b + 0]) / M->blk_dx[3 * b + 0]) + g->is;
-  *j = (M->ndim >= 2) ? (int)floor((y - M->blk_xmin[3 * b + 1]) / M->blk_dx[3 * b + 1]) + g->js
-                      : g->js;
-  *k = (M->ndim >= 3) ? (int)floor((z - M->blk_xmin[3 * b + 2]) / M->blk_dx[3 * b + 2]) + g->ks
-                      : g->ks;
+  /* (x - x_min) * (1 / dx): the reciprocal is a per-block constant.  Parthenon's own Xtoijk is
+   * un-vendored; the step functions keep particles >= 2e-9 dx away from cell faces, so the
+   * index does not depend on how the quotient is rounded. */
+  *i = (int)floor((x - M->blk_xmin[3 * b + 0]) * (1.0 / M->blk_dx[3 * b + 0])) + g->is;
+  *j = (M->ndim >= 2)
+           ? (int)floor((y - M->blk_xmin[3 * b + 1]) * (1.0 / M->blk_dx[3 * b + 1])) + g->js
+           : g->js;
+  *k = (M->ndim >= 3)
+           ? (int)floor((z - M->blk_xmin[3 * b + 2]) * (1.0 / M->blk_dx[3 * b + 2])) + g->ks
+           : g->ks;
 }
 static inline int on_block(const geom *g, int i, int j, int k) {
   return i >= g->is && i <= g->ie && j >= g->js && j <= g->je && k >= g->ks && k <= g->ke;
@@ -239,7 +247,8 @@ void orc_source_count(const orc_mesh *M, const orc_params *P, int source_type, d
       for (int j = g.js; j <= g.je; ++j)
         for (int i = g.is; i <= g.ie; ++i, ++cell) {
           const int64_t c = cidx(&g, b, k, j, i);
-          orc_rng rng = {(uint32_t)P->seed, 1u, cell_stream_id(epoch, b, cell), 0u, NULL, 0};
+          orc_rng rng = orc_rng_from_state(orc_rng_seed_state(
+              (uint32_t)P->seed, ORC_RNG_DOMAIN_CELL, cell_stream_id(epoch, b, cell)));
           const double rho = M->rho[c];
           const double temp = eos_temperature(P, rho, M->sie[c]);
           double erad;
@@ -280,7 +289,8 @@ void orc_source_fill(const orc_mesh *M, const orc_params *P, orc_swarm *S, int s
           double dej = 0.0;
           for (int np = pstart; np < pstart + npart; ++np) {
             const int64_t n = slot_base[b] + np;
-            orc_rng rng = {(uint32_t)P->seed, 0u, id_base[b] + (uint64_t)np, 0u, NULL, 0};
+            orc_rng rng = orc_rng_from_state(orc_rng_seed_state(
+                (uint32_t)P->seed, ORC_RNG_DOMAIN_PARTICLE, id_base[b] + (uint64_t)np));
             S->ip[n] = i; S->jp[n] = j; S->kp[n] = k;
             S->blk[n] = b;
             S->status[n] = ORC_ST_ACTIVE;
@@ -304,7 +314,7 @@ void orc_source_fill(const orc_mesh *M, const orc_params *P, orc_swarm *S, int s
               S->t[n] = 0.0;
             }
             S->id[n] = id_base[b] + (uint64_t)np;
-            S->ctr[n] = rng.ctr;
+            S->rng[n] = rng.s;
           }
           M->edelta[c] = dej;
         }
@@ -349,7 +359,7 @@ static int find_block(const orc_mesh *M, const double p[3]) {
   int l[3] = {0, 0, 0};
   for (int d = 0; d < M->ndim; ++d) {
     const double len = (M->gmax[d] - M->gmin[d]) / (double)M->nleaf[d];
-    int q = (int)floor((p[d] - M->gmin[d]) / len);
+    int q = (int)floor((p[d] - M->gmin[d]) * (1.0 / len));
     if (q < 0) q = 0;
     if (q > M->nleaf[d] - 1) q = M->nleaf[d] - 1;
     l[d] = q;
@@ -438,7 +448,7 @@ static uint64_t history(const orc_mesh *M, const orc_params *P, const geom *g, o
                         int64_t n, double t_start, double dt, int64_t *abs_cell) {
   const int multi_d = (M->ndim >= 2), three_d = (M->ndim == 3);
   const double vv = P->c;
-  orc_rng rng = {(uint32_t)P->seed, 0u, S->id[n], S->ctr[n], NULL, 0};
+  orc_rng rng = orc_rng_from_state(S->rng[n]);
   int b = S->blk[n];
   double t = S->t[n];
   double p[3] = {S->x[n], S->y[n], S->z[n]};
@@ -525,7 +535,7 @@ static uint64_t history(const orc_mesh *M, const orc_params *P, const geom *g, o
   S->vx[n] = v[0]; S->vy[n] = v[1]; S->vz[n] = v[2];
   S->ip[n] = ijk[0]; S->jp[n] = ijk[1]; S->kp[n] = ijk[2];
   S->status[n] = status;
-  S->ctr[n] = rng.ctr;
+  S->rng[n] = rng.s;
   return nev;
 }
 
@@ -620,7 +630,7 @@ void orc_sample_ddmc_block_face(const orc_mesh *M, const orc_params *P, orc_swar
   const geom g = make_geom(M);
   for (int64_t n = 0; n < S->n; ++n) {
     if (S->status[n] != ORC_ST_ACTIVE) continue;
-    orc_rng rng = {(uint32_t)P->seed, 0u, S->id[n], S->ctr[n], NULL, 0};
+    orc_rng rng = orc_rng_from_state(S->rng[n]);
     double p[3] = {S->x[n], S->y[n], S->z[n]};
     double v[3] = {S->vx[n], S->vy[n], S->vz[n]};
     int ijk[3] = {S->ip[n], S->jp[n], S->kp[n]};
@@ -628,7 +638,7 @@ void orc_sample_ddmc_block_face(const orc_mesh *M, const orc_params *P, orc_swar
     S->x[n] = p[0]; S->y[n] = p[1]; S->z[n] = p[2];
     S->vx[n] = v[0]; S->vy[n] = v[1]; S->vz[n] = v[2];
     S->ip[n] = ijk[0]; S->jp[n] = ijk[1]; S->kp[n] = ijk[2];
-    S->ctr[n] = rng.ctr;
+    S->rng[n] = rng.s;
   }
 }
 
@@ -643,7 +653,7 @@ int64_t orc_remove_marked(orc_swarm *S) {
       S->t[m] = S->t[n]; S->w[m] = S->w[n]; S->e[m] = S->e[n];
       S->ip[m] = S->ip[n]; S->jp[m] = S->jp[n]; S->kp[m] = S->kp[n];
       S->blk[m] = S->blk[n]; S->status[m] = S->status[n];
-      S->id[m] = S->id[n]; S->ctr[m] = S->ctr[n];
+      S->id[m] = S->id[n]; S->rng[m] = S->rng[n];
     }
     ++m;
   }

@@ -65,8 +65,8 @@ typedef struct orc_swarm {
   int64_t n, cap;
   double *x, *y, *z, *vx, *vy, *vz, *t, *w, *e;
   int32_t *ip, *jp, *kp, *blk, *status;
-  uint64_t *id;
-  uint32_t *ctr;
+  uint64_t *id;  /* creation index (diagnostic key) */
+  uint64_t *rng; /* xorshift64* state of the particle's stream */
 } orc_swarm;
 
 void orc_set_math_mode(int mode); /* 0 = libm (reference arithmetic), 1 = portable spec */
@@ -76,7 +76,8 @@ int orc_get_threads(void);
 
 /* generator + math, vectorised for tests */
 void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-void orc_draw_stream(uint32_t key0, uint32_t key1, uint64_t id, uint32_t first, int n, double *out);
+uint64_t orc_seed_state(uint32_t seed, uint32_t domain, uint64_t id);
+uint64_t orc_draw_stream(uint64_t state, int n, double *out); /* returns the final state */
 void orc_math_log(const double *x, int n, double *out);
 void orc_math_sincos(const double *x, int n, double *sn, double *cs);
 void orc_math_acos(const double *x, int n, double *out);

@@ -48,7 +48,7 @@ class MeshC(C.Structure):
 class SwarmC(C.Structure):
     _fields_ = ([("n", C.c_int64), ("cap", C.c_int64)] + [(n, _dp) for n in SWARM_F64] +
                 [(n, _ip) for n in SWARM_I32] +
-                [("id", C.POINTER(C.c_uint64)), ("ctr", C.POINTER(C.c_uint32))])
+                [("id", C.POINTER(C.c_uint64)), ("rng", C.POINTER(C.c_uint64))])
 
 
 class Step(C.Structure):
@@ -93,7 +93,10 @@ def lib():
         L.orc_source_fill.argtypes = [C.POINTER(MeshC), C.POINTER(Params), C.POINTER(SwarmC),
                                       C.c_int, C.c_double, C.c_double, _ip,
                                       C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
-        L.orc_draw_stream.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, _dp]
+        L.orc_seed_state.restype = C.c_uint64
+        L.orc_seed_state.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+        L.orc_draw_stream.restype = C.c_uint64
+        L.orc_draw_stream.argtypes = [C.c_uint64, C.c_int, _dp]
         L.orc_call_scatter.argtypes = [C.c_double, _dp, C.c_int, _dp]
         L.orc_call_face_iso_dir.argtypes = [C.c_double, _dp, C.c_int, _dp]
         L.orc_call_planck.argtypes = [C.c_double, C.c_double, _dp, C.c_int, _dp]
@@ -133,10 +136,15 @@ def philox(ctr, key):
     return [int(v) for v in o]
 
 
-def draw_stream(key0: int, key1: int, sid: int, first: int, n: int) -> np.ndarray:
+def seed_state(seed: int, domain: int, sid: int) -> int:
+    return int(lib().orc_seed_state(seed, domain, sid))
+
+
+def draw_stream(state: int, n: int):
+    """n uniforms from a stream that starts in `state`; returns (uniforms, final state)."""
     out = np.empty(n)
-    lib().orc_draw_stream(key0, key1, sid, first, n, _d(out))
-    return out
+    final = lib().orc_draw_stream(state, n, _d(out))
+    return out, int(final)
 
 
 def math_log(x):
@@ -223,7 +231,7 @@ class Oracle:
         self.sw = {n: np.zeros(self.cap) for n in SWARM_F64}
         self.sw.update({n: np.zeros(self.cap, dtype=np.int32) for n in SWARM_I32})
         self.sw["id"] = np.zeros(self.cap, dtype=np.uint64)
-        self.sw["ctr"] = np.zeros(self.cap, dtype=np.uint32)
+        self.sw["rng"] = np.zeros(self.cap, dtype=np.uint64)
         self.n = 0
         self.next_id = 0
         self.epoch = 0
@@ -258,7 +266,7 @@ class Oracle:
         for n in SWARM_I32:
             setattr(S, n, _i(self.sw[n]))
         S.id = self.sw["id"].ctypes.data_as(C.POINTER(C.c_uint64))
-        S.ctr = self.sw["ctr"].ctypes.data_as(C.POINTER(C.c_uint32))
+        S.rng = self.sw["rng"].ctypes.data_as(C.POINTER(C.c_uint64))
         return S
 
     def _enter(self):

@@ -3,21 +3,24 @@
  * Random-number source of the CPU oracle.
  *
  * The reference draws every uniform through Kokkos::Random_XorShift64_Pool
- * (reference src/jaybenne/jaybenne.hpp:24-27; checkout/return at transport.cpp:73,172).
- * Kokkos is an un-vendored dependency (absent from /root/reference, pin unknown) and the
- * reference's tests pin nothing about the generator, so parity at the level of individual
- * uniforms is UNPINNED.  This build replaces the pool by one independent counter-based stream
- * per particle: Philox4x32-10 (Salmon et al., SC'11; the published Random123 algorithm, also
- * rocRAND's rocrand_state_philox4x32_10).  Stream layout (identical to
- * rocrand_init(seed, subsequence = id, offset = 0)):
+ * (reference src/jaybenne/jaybenne.hpp:24-27; checkout/return at transport.cpp:73,172): a pool of
+ * xorshift64* generators shared by whatever threads run, so which uniforms a particle sees depends
+ * on the launch.  Kokkos is an un-vendored dependency (absent from /root/reference, pin unknown) and
+ * the reference's tests pin nothing about the generator, so parity at the level of individual
+ * uniforms is UNPINNED.  This build keeps the reference's generator algorithm (Marsaglia / Vigna
+ * xorshift64*, shifts 12, 25, 27, multiplier 2685821657736338717) but gives every particle its own
+ * generator, whose 64-bit state travels with the particle:
  *
- *     key     = { key0, key1 }                       (seed lo / hi)
- *     counter = { blk_lo, blk_hi, id_lo, id_hi }     (blk = draw_index / 2)
+ *     seeding   state = words (0,1) of Philox4x32-10( counter = {0, 0, id_lo, id_hi},
+ *                                                     key = {seed, domain} )
+ *               (words (2,3) | 1 if that is zero).  Philox4x32-10 is the published Random123
+ *               algorithm (Salmon et al., SC'11), laid out like rocRAND's
+ *               rocrand_init(seed, subsequence = id, offset = 0).
+ *     draw      s ^= s >> 12;  s ^= s << 25;  s ^= s >> 27;  r = s * 2685821657736338717;
+ *               xi = ((r >> 12) + 0.5) * 2^-52      in the OPEN interval (0,1)
  *
- * One Philox block yields two doubles:  draw 2*blk uses words (0,1), draw 2*blk+1 words (2,3).
- *     k52 = (w_hi << 20) | (w_lo >> 12);   xi = (k52 + 0.5) * 2^-52   in the OPEN interval (0,1)
- *
- * The generator is pinned by the Random123 known-answer vectors (tests/test_oracle_rng.py).
+ * Pinned by the Random123 Philox known-answer vectors and by the xorshift64* reference values in
+ * tests/test_oracle_rng.py.
  *
  * A "tape" mode replays a caller-supplied list of uniforms, so that every branch of the step
  * functions can be driven deterministically (golden vectors, tests/golden/).
@@ -51,16 +54,32 @@ static inline void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2
 }
 
 typedef struct orc_rng {
-  uint32_t key0, key1; /* Philox key: (seed, stream domain) */
-  uint64_t id;         /* stream id (particle id / cell id)  */
-  uint32_t ctr;        /* number of uniforms drawn so far    */
+  uint64_t s;          /* xorshift64* state */
+  uint32_t ctr;        /* number of uniforms drawn through this handle (diagnostic) */
   const double *tape;  /* if non-NULL: replay tape[pos++ % ntape] instead */
   int ntape;
 } orc_rng;
 
-static inline double orc_u52_to_double(uint32_t w_lo, uint32_t w_hi) {
-  const uint64_t k = ((uint64_t)w_hi << 20) | (uint64_t)(w_lo >> 12);
-  return ((double)k + 0.5) * 2.220446049250313080847263336181640625e-16; /* 2^-52 */
+#define ORC_RNG_DOMAIN_PARTICLE 0u /* Philox key word 1: particle streams */
+#define ORC_RNG_DOMAIN_CELL 1u     /* per-cell streams of the source's stochastic rounding */
+
+static inline uint64_t orc_rng_seed_state(uint32_t seed, uint32_t domain, uint64_t id) {
+  const uint32_t c[4] = {0u, 0u, (uint32_t)id, (uint32_t)(id >> 32)};
+  const uint32_t k[2] = {seed, domain};
+  uint32_t o[4];
+  orc_philox4x32_10(c, k, o);
+  uint64_t s = ((uint64_t)o[1] << 32) | o[0];
+  if (s == 0) s = (((uint64_t)o[3] << 32) | o[2]) | 1ull;
+  return s;
+}
+
+static inline orc_rng orc_rng_from_state(uint64_t state) {
+  orc_rng r = {state, 0u, NULL, 0};
+  return r;
+}
+
+static inline double orc_u52_to_double(uint64_t k52) {
+  return ((double)k52 + 0.5) * 2.220446049250313080847263336181640625e-16; /* 2^-52 */
 }
 
 static inline double orc_drand(orc_rng *r) {
@@ -69,14 +88,13 @@ static inline double orc_drand(orc_rng *r) {
     r->ctr++;
     return v;
   }
-  const uint32_t blk = r->ctr >> 1;
-  const uint32_t c[4] = {blk, 0u, (uint32_t)r->id, (uint32_t)(r->id >> 32)};
-  const uint32_t k[2] = {r->key0, r->key1};
-  uint32_t o[4];
-  orc_philox4x32_10(c, k, o);
-  const int h = (int)(r->ctr & 1u);
+  uint64_t s = r->s;
+  s ^= s >> 12;
+  s ^= s << 25;
+  s ^= s >> 27;
+  r->s = s;
   r->ctr++;
-  return orc_u52_to_double(o[2 * h], o[2 * h + 1]);
+  return orc_u52_to_double((s * 2685821657736338717ull) >> 12);
 }
 
 #endif /* ORC_RNG_H_ */

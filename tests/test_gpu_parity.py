@@ -57,14 +57,19 @@ def test_stream_layout_matches_rocrand(ctx):
 
 
 def test_uniform_stream_bit_exact(ctx):
+    """Philox seeding of a stream and the xorshift64* draws, device vs oracle."""
     from jaybenne_amd import _lib
     from oracle import orc
-    for first in (0, 1, 7):
+    for domain, sid in ((0, 0), (0, 0x1234567890), (1, (3 << 44) | (17 << 24) | 4095)):
+        st = C.c_uint64(0)
+        _lib.check(ctx.lib.jb_debug_seed_state(ctx.ctx, 349857, domain, sid, C.byref(st)))
+        assert st.value == orc.seed_state(349857, domain, sid) != 0
         out = np.empty(257)
-        _lib.check(ctx.lib.jb_debug_draw_stream(ctx.ctx, 349857, 0, 0x1234567890, first, out.size,
-                                                out.ctypes.data))
-        want = orc.draw_stream(349857, 0, 0x1234567890, first, out.size)
-        assert np.array_equal(out, want)
+        fin = C.c_uint64(0)
+        _lib.check(ctx.lib.jb_debug_draw_stream(ctx.ctx, st.value, out.size, out.ctypes.data,
+                                                C.byref(fin)))
+        want, want_fin = orc.draw_stream(st.value, out.size)
+        assert np.array_equal(out, want) and fin.value == want_fin
         assert out.min() > 0.0 and out.max() < 1.0
 
 
@@ -218,7 +223,7 @@ def _compare_swarm(md, O, exact=True):
     g = md.get_swarm()
     n = O.n
     assert md.n == n
-    for k in ("id", "ctr", "ip", "jp", "kp", "blk", "status"):
+    for k in ("id", "rng", "ip", "jp", "kp", "blk", "status"):
         assert np.array_equal(g[k], O.sw[k][:n]), k
     for k in orc.SWARM_F64:
         a, b = g[k], O.sw[k][:n]
@@ -303,7 +308,7 @@ def test_absorption_emission_feedback_bit_exact(gpu_device):
         order_g = np.argsort(g["id"])
         order_o = np.argsort(O.sw["id"][:O.n])
         assert drv.md.n == O.n
-        for k in ("id", "ctr", "ip", "blk"):
+        for k in ("id", "rng", "ip", "blk"):
             assert np.array_equal(g[k][order_g], O.sw[k][:O.n][order_o]), k
         for k in orc.SWARM_F64:
             a, b = g[k][order_g], O.sw[k][:O.n][order_o]
