@@ -87,6 +87,7 @@ __device__ __forceinline__ double m_acos(double x) {  // |x| <= 1
   constexpr double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
                    pi = 3.14159265358979311600e+00;
   const double ax = fabs(x);
+  if (ax >= 1.0) return x > 0.0 ? 0.0 : pi;  // fdlibm: acos(1) = 0, acos(-1) = pi
   if (ax < 0.5) {
     const double r = m_acos_R(x * x);
     return pio2_hi - (x - (pio2_lo - x * r));

@@ -40,13 +40,14 @@ def oracle_params(pin: ParameterInput, pkg) -> dict:
                 do_feedback=int(pin.GetOrAddBoolean("jaybenne", "do_feedback", True)))
 
 
-def make_oracle(pin: ParameterInput, math_mode: int, threads: int = 8, mesh: Mesh = None):
+def make_oracle(pin: ParameterInput, math_mode: int, threads: int = 8, mesh: Mesh = None,
+                capacity_factor: float = 1.3):
     from oracle import orc
     mesh = mesh if mesh is not None else Mesh.from_deck(pin)
     pkg = mcblock.Initialize(pin)
     ic = mcblock.ProblemGenerator(mesh, pkg)
     par = oracle_params(pin, pkg)
-    O = orc.Oracle(mesh, par, capacity=int(par["num_particles"] * 1.3) + 4096,
+    O = orc.Oracle(mesh, par, capacity=int(par["num_particles"] * capacity_factor) + 4096,
                    math_mode=math_mode, threads=threads)
     for k in ("rho", "sie", "u"):
         O.fields[k][...] = ic[k]

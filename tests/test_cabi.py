@@ -1,0 +1,71 @@
+"""The C-ABI shared library loads on a box without a GPU and exports exactly the entry points
+include/jaybenne_amd.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "jaybenne_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(jb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from jaybenne_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/jaybenne_amd.h but not exported"
+    assert sorted(_lib.PROTOTYPES) == names, "python binding and header disagree"
+    assert lib.jb_version().startswith(b"jaybenne_amd")
+
+
+def test_struct_layouts_match_the_header_sizes():
+    """sizeof of every POD crossing the boundary, as the C compiler sees the header."""
+    import subprocess
+    import tempfile
+    from jaybenne_amd import _lib
+    src = r'''
+#include <stdio.h>
+#include "jaybenne_amd.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(jb_params), sizeof(jb_eos), sizeof(jb_opacity),
+         sizeof(jb_scattering), sizeof(jb_mesh_view), sizeof(jb_swarm_view),
+         sizeof(jb_transport_stats), sizeof(jb_debug_step));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    py = [ctypes.sizeof(t) for t in (_lib.Params, _lib.Eos, _lib.Opacity, _lib.Scattering, _lib.MeshView,
+                                     _lib.SwarmView, _lib.TransportStats, _lib.DebugStep)]
+    assert sizes == py
+
+
+def test_oracle_is_not_reachable_from_the_product():
+    """The product package must not import, link or load anything under oracle/."""
+    pkg = os.path.join(ROOT, "jaybenne_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "liborc" not in text and "import orc" not in text and "oracle/" not in text, f
+                assert "from oracle" not in text, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import importlib
+    from jaybenne_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()

@@ -1,0 +1,94 @@
+"""Pins the oracle to the reference: its own known-answer tests (tst/stepdiff.py, tst/stepdiff_smr.py
+driven by tst/regression_test.py) -- the analytic erf profile of the energy tally after 10 cycles,
+solution-weighted mean fractional error <= 0.05 (stepdiff, stepdiff_ddmc) and <= 0.3 (SMR decks),
+with the reference's own mesh / particle overrides and the reference's arithmetic (libm)."""
+import numpy as np
+import pytest
+
+from helpers import load_deck, make_oracle, run_oracle_cycles
+from jaybenne_amd import analysis
+from oracle import orc
+
+STEPDIFF = {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128}          # tst/stepdiff.py:29-30
+SMR = {"parthenon/mesh/nx1": 64, "parthenon/mesh/nx2": 32,
+       "parthenon/meshblock/nx1": 16, "parthenon/meshblock/nx2": 16}            # tst/stepdiff_smr.py:29-32
+
+
+def _run(deck, overrides, mode=orc.MATH_LIBM):
+    pin = load_deck(deck, overrides)
+    O, mesh, _ = make_oracle(pin, mode, threads=8)
+    n0, e0 = O.n, O.sw["w"][:O.n].sum()
+    tlim = pin.GetReal("parthenon/time", "tlim")
+    dt = pin.GetReal("jaybenne", "dt")
+    t = run_oracle_cycles(O, pin, int(round(tlim / dt)))
+    err = analysis.analytic_errors(mesh, O.fields["tally"], t)
+    return O, mesh, err, n0, e0, t
+
+
+@pytest.mark.parametrize("deck,tol", [("stepdiff", 0.05), ("stepdiff_ddmc", 0.05)])
+def test_reference_gate_1d(deck, tol):
+    O, mesh, err, n0, e0, t = _run(deck, STEPDIFF)
+    assert err["mean_frac_error_weighted"] <= tol, err
+    # invariants: no absorption, reflecting walls -> particles and energy conserved
+    assert O.n == n0
+    assert O.sw["w"][:O.n].sum() == e0
+    assert np.all(O.sw["t"][:O.n] >= t * (1 - 1e-15))
+    v = np.sqrt(O.sw["vx"][:O.n] ** 2 + O.sw["vy"][:O.n] ** 2 + O.sw["vz"][:O.n] ** 2)
+    np.testing.assert_allclose(v, 2.99792458e10, rtol=1e-14)
+    dv = mesh.cell_volume(0)
+    assert O.fields["tally"][mesh.interior()].sum() * dv == pytest.approx(e0, rel=1e-12)
+
+
+@pytest.mark.parametrize("deck", ["stepdiff_smr", "stepdiff_smr_ddmc", "stepdiff_smr_hybrid"])
+def test_reference_gate_smr(deck):
+    O, mesh, err, n0, e0, t = _run(deck, SMR)
+    assert mesh.nblocks == 20 and sorted(set(mesh.blk_level.tolist())) == [0, 1]
+    assert err["mean_frac_error_weighted"] <= 0.3, err
+    assert O.n == n0
+    vol = np.array([mesh.cell_volume(b) for b in range(mesh.nblocks)])
+    tot = (O.fields["tally"][mesh.interior()].reshape(mesh.nblocks, -1).sum(axis=1) * vol).sum()
+    assert tot == pytest.approx(e0, rel=1e-12)
+
+
+def test_portable_arithmetic_passes_the_same_gate_and_agrees_statistically():
+    """Both flavours sample the same streams; they differ in the last bit of log / sin / cos, so
+    individual histories decorrelate, but the profile must pass the same gate and the two
+    profiles must agree within their Monte Carlo noise."""
+    _, mesh, e_libm, *_ = _run("stepdiff", STEPDIFF, orc.MATH_LIBM)
+    Op, _, e_port, *_ = _run("stepdiff", STEPDIFF, orc.MATH_PORTABLE)
+    assert e_port["mean_frac_error_weighted"] <= 0.05
+    assert abs(e_port["mean_frac_error_weighted"] - e_libm["mean_frac_error_weighted"]) < 0.02
+
+
+def test_small_runs_match_committed_golden_outputs():
+    import os
+    from golden.make_golden import SMALL_RUNS  # noqa: F401  (same list the fixture was made from)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "small_runs.npz"))
+    for mode in (orc.MATH_LIBM, orc.MATH_PORTABLE):
+        for deck, ov, cyc in SMALL_RUNS:
+            pin = load_deck(deck, ov)
+            O, mesh, _ = make_oracle(pin, mode, threads=4)
+            run_oracle_cycles(O, pin, cyc)
+            key = f"{deck}_m{mode}"
+            assert np.array_equal(O.sw["rng"][:O.n], g[key + "_rng"]), key
+            assert np.array_equal(O.sw["x"][:O.n], g[key + "_x"]), key
+            assert np.array_equal(O.fields["tally"][mesh.interior()], g[key + "_tally"]), key
+            assert O.events == int(g[key + "_events"][0])
+
+
+def test_absorption_and_feedback_conserve_energy():
+    ov = {"parthenon/mesh/nx1": 16, "parthenon/meshblock/nx1": 8, "jaybenne/num_particles": 20000,
+          "jaybenne/do_emission": "true", "jaybenne/do_feedback": "true",
+          "mcblock/opacity_model": "constant", "mcblock/opacity_constant_value": 40.0,
+          "mcblock/scattering_constant_value": 20.0, "mcblock/initial_temperature": 1.0e6}
+    pin = load_deck("stepdiff", ov)
+    O, mesh, _ = make_oracle(pin, orc.MATH_LIBM, threads=4, capacity_factor=6.0)
+    sl = mesh.interior()
+    dv = mesh.cell_volume(0)
+    e_rad0 = O.sw["w"][:O.n].sum()
+    e_mat0 = O.fields["u"][sl].sum() * dv
+    run_oracle_cycles(O, pin, 4)
+    e_rad = O.sw["w"][:O.n].sum()
+    e_mat = O.fields["u"][sl].sum() * dv
+    assert e_rad + e_mat == pytest.approx(e_rad0 + e_mat0, rel=1e-12)
+    assert e_mat != e_mat0
