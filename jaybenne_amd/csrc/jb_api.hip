@@ -414,6 +414,7 @@ static void launch_transport(jb_context *ctx, const DevMesh &M, const DevSwarm &
                              double dt, long long first, long long last, bool tally) {
   const int g = grid_for(ctx, last - first, 8);
   const bool gray = M.lam_abs != nullptr;
+  (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, sizeof(unsigned long long), ctx->stream);
 #define JB_LAUNCH(T, G)                                                                            \
   hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G>), dim3(g), dim3(kBlock), 0, ctx->stream, M,    \
                      ctx->dp, S, t_start, dt, first, last, ctx->counters_d)

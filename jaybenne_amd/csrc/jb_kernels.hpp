@@ -26,6 +26,7 @@ constexpr int kBlock = 256;  // 4 waves per workgroup
 
 // counters[]: 0 census, 1 absorbed, 2 escaped, 3 outgoing, 4 events, 5 unfinished
 enum { CNT_CENSUS = 0, CNT_ABSORBED, CNT_ESCAPED, CNT_OUTGOING, CNT_EVENTS, CNT_UNFINISHED, CNT_N };
+constexpr int CNT_QUEUE = 8;  // head of the particle queue of the running transport launch
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
@@ -262,35 +263,114 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 
 // -------------------------------------------------------------------------------------------
 // The history loop.  One lane follows one particle from its state at t_start to census /
-// absorption / escape / departure to another rank; a wave owns 64 consecutive particles and
-// loops until all of them are done, then takes the next batch (grid stride).
+// absorption / escape / departure to another rank.  Particles are dealt from one device-wide
+// queue: whenever fewer than kRefillThreshold of a wave's 64 lanes still hold an unfinished
+// history, its idle lanes take the next particles (ballot + popcount prefix over the idle mask,
+// one returning atomic per wave), so lanes do not wait for the longest history of a fixed group
+// of 64 and the particles in flight across the chip form one contiguous window of the
+// (cell-ordered) swarm -- which keeps the cell data they gather L2-resident.
 #ifndef JB_TRANSPORT_WAVES_PER_SIMD
 #define JB_TRANSPORT_WAVES_PER_SIMD 1
 #endif
+#ifndef JB_REFILL_THRESHOLD
+#define JB_REFILL_THRESHOLD 64
+#endif
+constexpr int kRefillThreshold = JB_REFILL_THRESHOLD;
+
 template <int NDIM, bool DDMC, bool TALLY, bool GRAY>
 __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
     k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
                 long long last, unsigned long long *counters) {
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  constexpr bool kFastGray = GRAY && !DDMC;
   const double vv = P.c;
-  unsigned long long c_census = 0, c_abs = 0, c_esc = 0, c_out = 0, c_ev = 0;
+  const double t_end = t_start + dt;  // the reference re-evaluates t_start + dt: same double
+  const int lane = threadIdx.x & 63;
+  unsigned long long *queue = counters + CNT_QUEUE;  // zeroed by the host before the launch
+  bool more = true;                                  // wave-uniform: the queue is not drained
 
-  for (long long n = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; n < last;
-       n += (long long)gridDim.x * blockDim.x) {
-    if (S.status[n] != ST_ACTIVE) continue;
-    XorShiftRng rng(S.rng[n]);
-    int b = S.blk[n];
-    Blk B;
-    load_block(M, b, B);
-    double t = S.t[n];
-    double x = S.x[n], y = S.y[n], z = S.z[n];
-    double vx = S.vx[n], vy = S.vy[n], vz = S.vz[n];
-    const double ee = S.e[n];
-    int ip, jp, kp;
-    int status = ST_ACTIVE;
-    xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:96
+  unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0, c_ev = 0;
 
-    while (t < t_start + dt) {
+  // lane state
+  bool active = false;
+  long long n = 0;
+  XorShiftRng rng(0);
+  int b = 0, ip = 0, jp = 0, kp = 0, status = ST_ACTIVE;
+  double t = 0, x = 0, y = 0, z = 0, vx = 0, vy = 0, vz = 0, ee = 0;
+  Blk B;
+  const double *f0 = nullptr, *f1 = nullptr, *f2 = nullptr;  // this block's cell arrays
+
+  auto bind_block = [&](int blk) {
+    load_block(M, blk, B);
+    if constexpr (kFastGray) {
+      f0 = M.lam_abs[blk];
+      f1 = M.lam_sc[blk];
+    } else {
+      f0 = M.rho[blk];
+      f1 = M.sie[blk];
+      f2 = M.fleck[blk];
+    }
+  };
+
+  auto finish = [&]() {
+    S.blk[n] = b;
+    S.t[n] = t;
+    S.x[n] = x; S.y[n] = y; S.z[n] = z;
+    S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+    S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
+    S.status[n] = status;
+    S.rng[n] = rng.s;
+    if (status == ST_ACTIVE) {
+      ++c_census;
+      if constexpr (TALLY) {  // jaybenne.cpp:547-561
+        const double dv = B.dx[0] * B.dx[1] * B.dx[2];
+        atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
+      }
+    } else if (status == ST_ABSORBED) {
+      ++c_abs;
+    } else if (status == ST_ESCAPED) {
+      ++c_esc;
+    } else {
+      ++c_out;
+    }
+    active = false;
+  };
+
+  for (;;) {
+    // ---- hand new particles to idle lanes ----
+    const unsigned long long idle = __ballot(!active);
+    if (idle != 0ull && more) {
+      const int leader = __ffsll((long long)idle) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(queue, (unsigned long long)__popcll(idle));
+      base = __shfl(base, leader, 64);
+      const long long cand = first + (long long)base + __popcll(idle & ((1ull << lane) - 1ull));
+      more = first + (long long)base + __popcll(idle) < last;
+      if (!active && cand < last && S.status[cand] == ST_ACTIVE) {
+        n = cand;
+        rng.s = S.rng[n];
+        b = S.blk[n];
+        bind_block(b);
+        t = S.t[n];
+        x = S.x[n]; y = S.y[n]; z = S.z[n];
+        vx = S.vx[n]; vy = S.vy[n]; vz = S.vz[n];
+        ee = S.e[n];
+        status = ST_ACTIVE;
+        xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:96
+        active = true;
+        if (!(t < t_end)) finish();  // already at census: nothing to track
+      }
+    }
+    if (__ballot(active) == 0ull) {
+      if (more) continue;
+      break;
+    }
+    const int thresh = more ? kRefillThreshold : 1;
+
+    // ---- events ----
+    // (no `continue` / `break` below: every lane must reach the ballot of the loop condition)
+    while (__popcll(__ballot(active)) >= thresh) {
+      if (active) {
       ++c_ev;
       Step s;
       s.t_start = t_start; s.dt = dt; s.vv = vv; s.dx_push = B.dx_push;
@@ -303,16 +383,16 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
       s.zu = xc(B, 2, kp) + 0.5 * B.dx[2];
       const long long q = cidx(M, kp, jp, ip);
       double lam_abs, lam_sc;
-      if constexpr (GRAY && !DDMC) {
+      if constexpr (kFastGray) {
         // per-cell mean free paths precomputed by k_fleck: two gathers instead of three, and no
         // division (same values: same operations on the same operands)
-        lam_abs = M.lam_abs[b][q];
-        lam_sc = M.lam_sc[b][q];
+        lam_abs = f0[q];
+        lam_sc = f1[q];
         s.ff = 0.0; s.ss = 0.0; s.aa = 0.0;
       } else {
-        const double rho = M.rho[b][q];
-        const double temp = eos_temperature(P, rho, M.sie[b][q]);
-        s.ff = M.fleck[b][q];
+        const double rho = f0[q];
+        const double temp = eos_temperature(P, rho, f1[q]);
+        s.ff = f2[q];
         s.ss = opac_scattering(P, rho, temp, ee);
         s.aa = opac_absorption(P, rho, temp, ee);
         imc_cell_mfp(s.ff, s.aa, s.ss, lam_abs, lam_sc);
@@ -348,63 +428,38 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
         // ---- comm phase, in flight ----
         if (!apply_swarm_bcs<NDIM>(M, x, y, z, vx, vy, vz)) {
           status = ST_ESCAPED;
-          break;
+        } else {
+          const int g = find_block<NDIM>(M, x, y, z);
+          if (M.owner[g] != M.rank) {
+            status = ST_OUTGOING;
+            b = g;  // global id travels in blk
+          } else {
+            b = M.local_index[g];
+            bind_block(b);
+            if constexpr (DDMC && multi_d)
+              sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
+            xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // next launch's transport.cpp:96
+          }
         }
-        const int g = find_block<NDIM>(M, x, y, z);
-        if (M.owner[g] != M.rank) {
-          status = ST_OUTGOING;
-          b = g;  // global id travels in blk
-          break;
-        }
-        b = M.local_index[g];
-        load_block(M, b, B);
-        if constexpr (DDMC && multi_d)
-          sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
-        xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // next launch's transport.cpp:96
-        continue;
-      }
-      if (s.is_absorbed) {  // transport.cpp:157-163
+      } else if (s.is_absorbed) {  // transport.cpp:157-163
         atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
         status = ST_ABSORBED;
-        break;
+      } else if (s.is_scattered) {
+        scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
       }
-      if (s.is_scattered) scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
-    }
-
-    S.blk[n] = b;
-    S.t[n] = t;
-    S.x[n] = x; S.y[n] = y; S.z[n] = z;
-    S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
-    S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
-    S.status[n] = status;
-    S.rng[n] = rng.s;
-
-    if (status == ST_ACTIVE) {
-      ++c_census;
-      if constexpr (TALLY) {  // jaybenne.cpp:547-561
-        const double dv = B.dx[0] * B.dx[1] * B.dx[2];
-        atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
-      }
-    } else if (status == ST_ABSORBED) {
-      ++c_abs;
-    } else if (status == ST_ESCAPED) {
-      ++c_esc;
-    } else {
-      ++c_out;
+      if (status != ST_ACTIVE || !(t < t_end)) finish();  // left, absorbed, or census
+      }  // if (active)
     }
   }
 
-  c_census = wave_sum(c_census);
-  c_abs = wave_sum(c_abs);
-  c_esc = wave_sum(c_esc);
-  c_out = wave_sum(c_out);
-  c_ev = wave_sum(c_ev);
-  if ((threadIdx.x & 63) == 0) {
-    if (c_census) atomicAdd(&counters[CNT_CENSUS], c_census);
-    if (c_abs) atomicAdd(&counters[CNT_ABSORBED], c_abs);
-    if (c_esc) atomicAdd(&counters[CNT_ESCAPED], c_esc);
-    if (c_out) atomicAdd(&counters[CNT_OUTGOING], c_out);
-    if (c_ev) atomicAdd(&counters[CNT_EVENTS], c_ev);
+  unsigned long long r_census = wave_sum(c_census), r_abs = wave_sum(c_abs), r_esc = wave_sum(c_esc),
+                     r_out = wave_sum(c_out), r_ev = wave_sum(c_ev);
+  if (lane == 0) {
+    if (r_census) atomicAdd(&counters[CNT_CENSUS], r_census);
+    if (r_abs) atomicAdd(&counters[CNT_ABSORBED], r_abs);
+    if (r_esc) atomicAdd(&counters[CNT_ESCAPED], r_esc);
+    if (r_out) atomicAdd(&counters[CNT_OUTGOING], r_out);
+    if (r_ev) atomicAdd(&counters[CNT_EVENTS], r_ev);
   }
 }
 
