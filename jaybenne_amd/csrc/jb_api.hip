@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -412,9 +413,11 @@ extern "C" jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh,
 template <int NDIM, bool DDMC>
 static void launch_transport(jb_context *ctx, const DevMesh &M, const DevSwarm &S, double t_start,
                              double dt, long long first, long long last, bool tally) {
-  const int g = grid_for(ctx, last - first, 8);
+  int per_cu = 8;
+  if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 8;  // tuning aid
+  const int g = grid_for(ctx, last - first, per_cu);
   const bool gray = M.lam_abs != nullptr;
-  (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, sizeof(unsigned long long), ctx->stream);
+  (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream);
 #define JB_LAUNCH(T, G)                                                                            \
   hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G>), dim3(g), dim3(kBlock), 0, ctx->stream, M,    \
                      ctx->dp, S, t_start, dt, first, last, ctx->counters_d)

@@ -26,7 +26,8 @@ constexpr int kBlock = 256;  // 4 waves per workgroup
 
 // counters[]: 0 census, 1 absorbed, 2 escaped, 3 outgoing, 4 events, 5 unfinished
 enum { CNT_CENSUS = 0, CNT_ABSORBED, CNT_ESCAPED, CNT_OUTGOING, CNT_EVENTS, CNT_UNFINISHED, CNT_N };
-constexpr int CNT_QUEUE = 8;  // head of the particle queue of the running transport launch
+constexpr int CNT_QUEUE = 8;  // heads of the 8 particle queues of the running transport launch
+constexpr int kQueues = 8;    // one per XCD (workgroups b and b + 8 share an XCD and its L2)
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
@@ -263,12 +264,15 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 
 // -------------------------------------------------------------------------------------------
 // The history loop.  One lane follows one particle from its state at t_start to census /
-// absorption / escape / departure to another rank.  Particles are dealt from one device-wide
-// queue: whenever fewer than kRefillThreshold of a wave's 64 lanes still hold an unfinished
-// history, its idle lanes take the next particles (ballot + popcount prefix over the idle mask,
-// one returning atomic per wave), so lanes do not wait for the longest history of a fixed group
-// of 64 and the particles in flight across the chip form one contiguous window of the
-// (cell-ordered) swarm -- which keeps the cell data they gather L2-resident.
+// absorption / escape / departure to another rank.  Particles are dealt from queues: whenever
+// fewer than kRefillThreshold of a wave's 64 lanes still hold an unfinished history, its idle
+// lanes take the next particles (ballot + popcount prefix over the idle mask, one returning
+// atomic per wave), so lanes do not wait for the longest history of a fixed group of 64.
+// There are 8 queues, each over one contiguous eighth of the (cell-ordered) swarm; a workgroup
+// starts on queue blockIdx % 8 -- the workgroups that share an XCD, hence an L2 -- and moves on to
+// the next queue when its own is drained.  The particles in flight on one XCD therefore form one
+// short contiguous window of the swarm and the cell data they gather stays resident in that
+// XCD's 4 MiB L2.  Placement only affects speed, never results.
 #ifndef JB_TRANSPORT_WAVES_PER_SIMD
 #define JB_TRANSPORT_WAVES_PER_SIMD 1
 #endif
@@ -287,7 +291,10 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
   const double t_end = t_start + dt;  // the reference re-evaluates t_start + dt: same double
   const int lane = threadIdx.x & 63;
   unsigned long long *queue = counters + CNT_QUEUE;  // zeroed by the host before the launch
-  bool more = true;                                  // wave-uniform: the queue is not drained
+  const long long per_q = (last - first + kQueues - 1) / kQueues;
+  int cur = blockIdx.x % kQueues;  // wave-uniform: queue this wave draws from
+  int tried = 0;                   // queues found drained so far
+  bool more = true;                // wave-uniform: some queue may still hold particles
 
   unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0, c_ev = 0;
 
@@ -341,12 +348,19 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
     const unsigned long long idle = __ballot(!active);
     if (idle != 0ull && more) {
       const int leader = __ffsll((long long)idle) - 1;
+      const int want = __popcll(idle);
       unsigned long long base = 0;
-      if (lane == leader) base = atomicAdd(queue, (unsigned long long)__popcll(idle));
+      if (lane == leader) base = atomicAdd(&queue[cur], (unsigned long long)want);
       base = __shfl(base, leader, 64);
-      const long long cand = first + (long long)base + __popcll(idle & ((1ull << lane) - 1ull));
-      more = first + (long long)base + __popcll(idle) < last;
-      if (!active && cand < last && S.status[cand] == ST_ACTIVE) {
+      const long long q_first = first + (long long)cur * per_q;
+      long long q_last = q_first + per_q;
+      if (q_last > last) q_last = last;
+      const long long cand = q_first + (long long)base + __popcll(idle & ((1ull << lane) - 1ull));
+      if (q_first + (long long)base + want >= q_last) {  // this queue is drained: move on
+        cur = (cur + 1) % kQueues;
+        if (++tried == kQueues) more = false;
+      }
+      if (!active && cand < q_last && S.status[cand] == ST_ACTIVE) {
         n = cand;
         rng.s = S.rng[n];
         b = S.blk[n];
