@@ -37,8 +37,20 @@ def block_grid(ngpus: int):
     return {1: (4, 4, 4), 2: (8, 4, 4), 4: (8, 8, 4), 8: (8, 8, 8)}.get(ngpus) or (4 * ngpus, 4, 4)
 
 
-def make_deck(ngpus: int, particles_per_gpu: int, block_nx: int = 64):
+def make_deck(ngpus: int, particles_per_gpu: int, block_nx: int = 64, workload: str = "c2"):
+    """c2: stepdiff.in pure IMC, 64 x 64^3 blocks per GPU (the headline workload).
+    c3: stepdiff_ddmc.in, 3-D 128^3 cells in 8 x 64^3 blocks (sigma dx = 7.8: every step DDMC).
+    c3-1d: stepdiff_ddmc.in as shipped but 128 cells in one block (tally-contention stress)."""
     from helpers import load_deck
+    if workload == "c3-1d":
+        return load_deck("stepdiff_ddmc", {"jaybenne/num_particles": particles_per_gpu * ngpus,
+                                           "parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128})
+    if workload == "c3":
+        ov = {"jaybenne/num_particles": particles_per_gpu * ngpus}
+        for d in range(3):
+            ov[f"parthenon/mesh/nx{d + 1}"] = 128
+            ov[f"parthenon/meshblock/nx{d + 1}"] = 64
+        return load_deck("stepdiff_ddmc", ov)
     nb = block_grid(ngpus)
     ov = {"jaybenne/num_particles": particles_per_gpu * ngpus}
     for d in range(3):
@@ -78,6 +90,8 @@ def main() -> None:
     ap.add_argument("--block-nx", type=int, default=64)
     ap.add_argument("--cpu-sample", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3-1d"],
+                    help="c2 = headline (BASELINE configs[1]); c3* = DDMC side measurements")
     args = ap.parse_args()
 
     import torch
@@ -99,7 +113,7 @@ def main() -> None:
         from jaybenne_amd.comm import Comm
         comm = Comm(device=device)
 
-    pin = make_deck(args.gpus, args.particles_per_gpu, args.block_nx)
+    pin = make_deck(args.gpus, args.particles_per_gpu, args.block_nx, args.workload)
     drv = mcblock.McblockDriver(pin, rank=rank, nranks=world, comm=comm, device=device,
                                 capacity_factor=1.5)
     md = drv.md
@@ -133,7 +147,8 @@ def main() -> None:
         k_time = sum(t for t, _ in kt)
         k_hist = sum(n for _, n in kt)
         ev_per_hist = events / max(histories, 1)
-        k_bytes = k_hist * (BYTES_PER_HISTORY + BYTES_PER_EVENT_IMC * ev_per_hist)
+        per_event = BYTES_PER_EVENT_IMC if args.workload == "c2" else 72.0
+        k_bytes = k_hist * (BYTES_PER_HISTORY + per_event * ev_per_hist)
         achieved = k_bytes / k_time / 1e9 if k_time > 0 else 0.0
         fp64 = k_hist * ev_per_hist * FLOPS_PER_EVENT / k_time / 1e12 if k_time > 0 else 0.0
         out = {
@@ -144,7 +159,8 @@ def main() -> None:
             "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "stepdiff pure-IMC, uniform 3-D mesh, "
+            "config": {"workload": ("" if args.workload == "c2" else f"[{args.workload}] ") +
+                                   "stepdiff pure-IMC, uniform 3-D mesh, "
                                    f"{md.mesh.nblocks} meshblocks of {args.block_nx}^3 cells, "
                                    f"{args.particles_per_gpu * args.gpus:.3g} particles, 1 cycle per step "
                                    "(BASELINE.json configs[1] per GPU)",
@@ -157,7 +173,7 @@ def main() -> None:
                          "kernel": "k_transport<3,false,true>",
                          "kernel_ms_avg": 1e3 * k_time / max(len(kt), 1),
                          "launches": len(kt),
-                         "algorithmic_bytes_per_history": BYTES_PER_HISTORY + BYTES_PER_EVENT_IMC * ev_per_hist,
+                         "algorithmic_bytes_per_history": BYTES_PER_HISTORY + per_event * ev_per_hist,
                          "fp64_valu": {"achieved_tflops": fp64, "peak_tflops": FP64_VALU_PEAK_TF,
                                        "frac": fp64 / FP64_VALU_PEAK_TF,
                                        "note": "IMC regime is FP64-VALU bound, not HBM bound (SURVEY 8d)"}},

@@ -275,6 +275,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   // gray (frequency-independent) opacities: library-owned per-cell mean-free-path arrays
   D.lam_abs = nullptr;
   D.lam_sc = nullptr;
+  D.ddmc_cell = nullptr;
   if (ctx->opac.model == JB_OPAC_GRAY && ctx->scat.model == JB_SCAT_GRAY) {
     const size_t per = (size_t)D.ntot;
     double *base = nullptr;
@@ -291,6 +292,17 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
     D.lam_abs = (double *const *)tmp;
     if ((st = upload(m, (const double *const *)ps.data(), (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
     D.lam_sc = (double *const *)tmp;
+    D.ddmc_cell = nullptr;
+    if (ctx->params.use_ddmc) {
+      double *pack = nullptr;
+      e = hipMalloc(&pack, sizeof(double) * per * 8 * (size_t)v->nblocks);
+      if (e != hipSuccess) { jb_mesh_destroy(m); return fail(JB_ERR_HIP, "hipMalloc of the DDMC cell records failed: %s", hipGetErrorString(e)); }
+      m->owned.push_back(pack);
+      std::vector<const double *> pp(v->nblocks);
+      for (int b = 0; b < v->nblocks; ++b) pp[b] = pack + (size_t)b * per * 8;
+      if ((st = upload(m, (const double *const *)pp.data(), (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
+      D.ddmc_cell = (double *const *)tmp;
+    }
   }
   *out = m;
   return JB_COMPLETE;
@@ -333,6 +345,12 @@ extern "C" jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh
     hipLaunchKernelGGL(k_face_prob<0>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
     if (M.ndim > 1) hipLaunchKernelGGL(k_face_prob<1>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
     if (M.ndim > 2) hipLaunchKernelGGL(k_face_prob<2>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
+    if (M.ddmc_cell) {
+      const int gp = grid_for(ctx, cells);
+      if (M.ndim == 1) hipLaunchKernelGGL(k_ddmc_pack<1>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
+      else if (M.ndim == 2) hipLaunchKernelGGL(k_ddmc_pack<2>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
+      else hipLaunchKernelGGL(k_ddmc_pack<3>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
+    }
   }
   JB_HIP(hipGetLastError());
   return JB_COMPLETE;
@@ -761,6 +779,8 @@ __global__ void k_dbg_step(int which, jb_debug_step *d, const double *tape, int 
   Step s;
   s.t_start = d->t_start; s.dt = d->dt; s.ff = d->ff; s.aa = d->aa; s.ss = d->ss; s.vv = d->vv;
   s.dx_push = d->dx_push;
+  s.ffaa = s.ff * s.aa;
+  s.sig = s.aa + s.ss;
   s.xl = d->xl; s.yl = d->yl; s.zl = d->zl; s.xu = d->xu; s.yu = d->yu; s.zu = d->zu;
   s.Px_l = d->Px_l; s.Py_l = d->Py_l; s.Pz_l = d->Pz_l; s.Px_u = d->Px_u; s.Py_u = d->Py_u; s.Pz_u = d->Pz_u;
   s.t = d->t; s.x = d->x; s.y = d->y; s.z = d->z; s.vx = d->vx; s.vy = d->vy; s.vz = d->vz;

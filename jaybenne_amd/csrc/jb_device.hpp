@@ -28,6 +28,9 @@ struct DevMesh {
   // library-owned per-cell mean free paths 1/(f sigma_a), 1/(sigma_s + (1-f) sigma_a), filled by
   // UpdateDerivedTransportFields for frequency-independent (gray) opacities
   double *const *lam_abs, *const *lam_sc;
+  // library-owned, gray opacities with DDMC: 8 doubles per cell {f sigma_a, sigma_a + sigma_s,
+  // Px_l, Px_u, Py_l, Py_u, Pz_l, Pz_u} -- everything a DDMC step gathers, in one 64-byte record
+  double *const *ddmc_cell;
 };
 
 struct DevParams {

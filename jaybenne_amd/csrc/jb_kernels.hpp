@@ -114,6 +114,35 @@ __global__ void __launch_bounds__(kBlock) k_face_prob(DevMesh M, DevParams P) {
   }
 }
 
+// Gray opacities + DDMC: gather what a DDMC step reads for one cell into one 64-byte record
+// (instead of nine gathers from seven arrays per step).  Same values: the products / sums are
+// the ones the step functions form (f * sigma_a, sigma_a + sigma_s).
+template <int NDIM>
+__global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P) {
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  const long long total = (long long)M.nblocks * M.ncell;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+       c += (long long)gridDim.x * blockDim.x) {
+    int b, k, j, i, cell;
+    decode_cell(M, c, b, k, j, i, cell);
+    const long long q = cidx(M, k, j, i);
+    const double rho = M.rho[b][q];
+    const double temp = eos_temperature(P, rho, M.sie[b][q]);
+    const double ff = M.fleck[b][q];
+    const double ss = opac_scattering(P, rho, temp, 1.0);
+    const double aa = opac_absorption(P, rho, temp, 1.0);
+    double *o = M.ddmc_cell[b] + 8 * q;
+    o[0] = ff * aa;
+    o[1] = aa + ss;
+    o[2] = M.P1[b][q];
+    o[3] = M.P1[b][cidx(M, k, j, i + 1)];
+    o[4] = multi_d ? M.P2[b][q] : 0.0;
+    o[5] = multi_d ? M.P2[b][cidx(M, k, j + 1, i)] : 0.0;
+    o[6] = three_d ? M.P3[b][q] : 0.0;
+    o[7] = three_d ? M.P3[b][cidx(M, k + 1, j, i)] : 0.0;
+  }
+}
+
 // -------------------------------------------------------------------------------------------
 // SourcePhotons phase 1: one workgroup per block.  Per cell: energy to source, stochastically
 // rounded particle count (1 draw from the cell's own stream), energy weight; then an exclusive
@@ -264,22 +293,33 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 
 // -------------------------------------------------------------------------------------------
 // The history loop.  One lane follows one particle from its state at t_start to census /
-// absorption / escape / departure to another rank.  Particles are dealt from queues: whenever
-// fewer than kRefillThreshold of a wave's 64 lanes still hold an unfinished history, its idle
-// lanes take the next particles (ballot + popcount prefix over the idle mask, one returning
-// atomic per wave), so lanes do not wait for the longest history of a fixed group of 64.
-// There are 8 queues, each over one contiguous eighth of the (cell-ordered) swarm; a workgroup
-// starts on queue blockIdx % 8 -- the workgroups that share an XCD, hence an L2 -- and moves on to
-// the next queue when its own is drained.  The particles in flight on one XCD therefore form one
-// short contiguous window of the swarm and the cell data they gather stays resident in that
-// XCD's 4 MiB L2.  Placement only affects speed, never results.
+// absorption / escape / departure to another rank.
+//
+// Structure.  A wave alternates between an EVENT loop -- every running lane takes one tracking
+// step per pass; nothing else is in it -- and a SERVICE phase that does everything that happens
+// once per history or once per block crossing: relocation of particles that left their block
+// (swarm boundary conditions, destination-block lookup, DDMC block-face resampling), DDMC census
+// resampling, write-back, tallies, and handing the next particles to idle lanes.  The event loop
+// runs until kServiceAfter lanes have left it; keeping the rare, long code paths out of it keeps
+// its 64 lanes on one instruction stream.
+//
+// Particles are dealt from 8 queues, each over one contiguous eighth of the (cell-ordered) swarm
+// (ballot + popcount prefix over the idle mask, one returning atomic per wave).  A workgroup
+// starts on queue blockIdx % 8 -- the workgroups that share an XCD, hence an L2 -- and moves on
+// when its queue is drained, so the particles in flight on one XCD form one short contiguous
+// window of the swarm and the cell data they gather stays in that XCD's 4 MiB L2.  Placement only
+// affects speed, never results.
 #ifndef JB_TRANSPORT_WAVES_PER_SIMD
 #define JB_TRANSPORT_WAVES_PER_SIMD 1
 #endif
-#ifndef JB_REFILL_THRESHOLD
-#define JB_REFILL_THRESHOLD 64
+#ifndef JB_SERVICE_AFTER
+#define JB_SERVICE_AFTER 4
 #endif
-constexpr int kRefillThreshold = JB_REFILL_THRESHOLD;
+#ifndef JB_SERVICE_AFTER_DDMC
+#define JB_SERVICE_AFTER_DDMC 24
+#endif
+
+enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
 
 template <int NDIM, bool DDMC, bool TALLY, bool GRAY>
 __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
@@ -287,6 +327,8 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
                 long long last, unsigned long long *counters) {
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   constexpr bool kFastGray = GRAY && !DDMC;
+  constexpr bool kPackedDdmc = GRAY && DDMC;
+  constexpr int kServiceAfter = DDMC ? JB_SERVICE_AFTER_DDMC : JB_SERVICE_AFTER;
   const double vv = P.c;
   const double t_end = t_start + dt;  // the reference re-evaluates t_start + dt: same double
   const int lane = threadIdx.x & 63;
@@ -299,7 +341,8 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
   unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0, c_ev = 0;
 
   // lane state
-  bool active = false;
+  int ls = LS_IDLE;
+  bool resample = false;  // DDMC particle reached census: position / direction to be resampled
   long long n = 0;
   XorShiftRng rng(0);
   int b = 0, ip = 0, jp = 0, kp = 0, status = ST_ACTIVE;
@@ -312,40 +355,84 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
     if constexpr (kFastGray) {
       f0 = M.lam_abs[blk];
       f1 = M.lam_sc[blk];
+    } else if constexpr (kPackedDdmc) {
+      f0 = M.ddmc_cell[blk];
+      f1 = M.lam_abs[blk];
+      f2 = M.lam_sc[blk];
     } else {
       f0 = M.rho[blk];
       f1 = M.sie[blk];
       f2 = M.fleck[blk];
     }
   };
-
-  auto finish = [&]() {
-    S.blk[n] = b;
-    S.t[n] = t;
-    S.x[n] = x; S.y[n] = y; S.z[n] = z;
-    S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
-    S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
-    S.status[n] = status;
-    S.rng[n] = rng.s;
-    if (status == ST_ACTIVE) {
-      ++c_census;
-      if constexpr (TALLY) {  // jaybenne.cpp:547-561
-        const double dv = B.dx[0] * B.dx[1] * B.dx[2];
-        atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
-      }
-    } else if (status == ST_ABSORBED) {
-      ++c_abs;
-    } else if (status == ST_ESCAPED) {
-      ++c_esc;
-    } else {
-      ++c_out;
-    }
-    active = false;
+  auto cell_faces = [&](Step &s) {  // transport.cpp:114-119
+    s.xl = xc(B, 0, ip) - 0.5 * B.dx[0];
+    s.xu = xc(B, 0, ip) + 0.5 * B.dx[0];
+    s.yl = xc(B, 1, jp) - 0.5 * B.dx[1];
+    s.yu = xc(B, 1, jp) + 0.5 * B.dx[1];
+    s.zl = xc(B, 2, kp) - 0.5 * B.dx[2];
+    s.zu = xc(B, 2, kp) + 0.5 * B.dx[2];
   };
 
   for (;;) {
-    // ---- hand new particles to idle lanes ----
-    const unsigned long long idle = __ballot(!active);
+    // ================================ SERVICE ================================
+    if (ls == LS_RELOC) {
+      // the comm phase of the reference, for one particle in flight: boundary conditions
+      // (boundaries.hpp:46-82, periodic, outflow), destination block, SampleDDMCBlockFace
+      if (!apply_swarm_bcs<NDIM>(M, x, y, z, vx, vy, vz)) {
+        status = ST_ESCAPED;
+        ls = LS_DONE;
+      } else {
+        const int g = find_block<NDIM>(M, x, y, z);
+        if (M.owner[g] != M.rank) {
+          status = ST_OUTGOING;
+          b = g;  // global id travels in blk
+          ls = LS_DONE;
+        } else {
+          b = M.local_index[g];
+          bind_block(b);
+          if constexpr (DDMC && multi_d)
+            sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
+          xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // next launch's transport.cpp:96
+          ls = (t < t_end) ? LS_RUN : LS_DONE;
+        }
+      }
+    }
+    if (ls == LS_DONE) {
+      if constexpr (DDMC) {
+        if (resample) {  // transport_utils.hpp:265-276, once per history
+          Step s;
+          s.vv = vv;
+          cell_faces(s);
+          ddmc_census_resample(s, rng);
+          x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
+          resample = false;
+        }
+      }
+      S.blk[n] = b;
+      S.t[n] = t;
+      S.x[n] = x; S.y[n] = y; S.z[n] = z;
+      S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+      S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
+      S.status[n] = status;
+      S.rng[n] = rng.s;
+      if (status == ST_ACTIVE) {
+        ++c_census;
+        if constexpr (TALLY) {  // jaybenne.cpp:547-561
+          const double dv = B.dx[0] * B.dx[1] * B.dx[2];
+          atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
+        }
+      } else if (status == ST_ABSORBED) {
+        ++c_abs;
+      } else if (status == ST_ESCAPED) {
+        ++c_esc;
+      } else {
+        ++c_out;
+      }
+      ls = LS_IDLE;
+    }
+    // hand new particles to idle lanes
+    const unsigned long long idle = __ballot(ls == LS_IDLE);
     if (idle != 0ull && more) {
       const int leader = __ffsll((long long)idle) - 1;
       const int want = __popcll(idle);
@@ -360,7 +447,7 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
         cur = (cur + 1) % kQueues;
         if (++tried == kQueues) more = false;
       }
-      if (!active && cand < q_last && S.status[cand] == ST_ACTIVE) {
+      if (ls == LS_IDLE && cand < q_last && S.status[cand] == ST_ACTIVE) {
         n = cand;
         rng.s = S.rng[n];
         b = S.blk[n];
@@ -370,99 +457,95 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
         vx = S.vx[n]; vy = S.vy[n]; vz = S.vz[n];
         ee = S.e[n];
         status = ST_ACTIVE;
+        resample = false;
         xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:96
-        active = true;
-        if (!(t < t_end)) finish();  // already at census: nothing to track
+        ls = (t < t_end) ? LS_RUN : LS_DONE;      // already at census: nothing to track
       }
     }
-    if (__ballot(active) == 0ull) {
-      if (more) continue;
+    const int running = __popcll(__ballot(ls == LS_RUN));
+    if (running == 0) {
+      if (__ballot(ls != LS_IDLE) != 0ull || more) continue;  // pending service / more to load
       break;
     }
-    const int thresh = more ? kRefillThreshold : 1;
+    // leave the event loop once kServiceAfter lanes have left it (while the queues still hold
+    // particles every lane is running here, so this is 64 - kServiceAfter + 1)
+    int thresh = running - kServiceAfter + 1;
+    if (thresh < 1) thresh = 1;
 
-    // ---- events ----
+    // ================================ EVENTS =================================
     // (no `continue` / `break` below: every lane must reach the ballot of the loop condition)
-    while (__popcll(__ballot(active)) >= thresh) {
-      if (active) {
-      ++c_ev;
-      Step s;
-      s.t_start = t_start; s.dt = dt; s.vv = vv; s.dx_push = B.dx_push;
-      // cell faces from cell centres (transport.cpp:114-119)
-      s.xl = xc(B, 0, ip) - 0.5 * B.dx[0];
-      s.xu = xc(B, 0, ip) + 0.5 * B.dx[0];
-      s.yl = xc(B, 1, jp) - 0.5 * B.dx[1];
-      s.yu = xc(B, 1, jp) + 0.5 * B.dx[1];
-      s.zl = xc(B, 2, kp) - 0.5 * B.dx[2];
-      s.zu = xc(B, 2, kp) + 0.5 * B.dx[2];
-      const long long q = cidx(M, kp, jp, ip);
-      double lam_abs, lam_sc;
-      if constexpr (kFastGray) {
-        // per-cell mean free paths precomputed by k_fleck: two gathers instead of three, and no
-        // division (same values: same operations on the same operands)
-        lam_abs = f0[q];
-        lam_sc = f1[q];
-        s.ff = 0.0; s.ss = 0.0; s.aa = 0.0;
-      } else {
-        const double rho = f0[q];
-        const double temp = eos_temperature(P, rho, f1[q]);
-        s.ff = f2[q];
-        s.ss = opac_scattering(P, rho, temp, ee);
-        s.aa = opac_absorption(P, rho, temp, ee);
-        imc_cell_mfp(s.ff, s.aa, s.ss, lam_abs, lam_sc);
-      }
-      s.t = t; s.x = x; s.y = y; s.z = z; s.vx = vx; s.vy = vy; s.vz = vz;
-      s.ip = ip; s.jp = jp; s.kp = kp;
-      s.is_absorbed = false; s.is_scattered = false; s.is_rejected = false;
-
-      bool is_ddmc_step = false;
-      if constexpr (DDMC) is_ddmc_step = B.dx_push * (s.ss + s.aa) > P.tau_ddmc;
-      if (DDMC && is_ddmc_step) {
-        // transport_ddmc.cpp:137-179
-        s.Px_l = M.P1[b][q];
-        s.Px_u = M.P1[b][cidx(M, kp, jp, ip + 1)];
-        s.Py_l = multi_d ? M.P2[b][q] : 0.0;
-        s.Py_u = multi_d ? M.P2[b][cidx(M, kp, jp + 1, ip)] : 0.0;
-        s.Pz_l = three_d ? M.P3[b][q] : 0.0;
-        s.Pz_u = three_d ? M.P3[b][cidx(M, kp + 1, jp, ip)] : 0.0;
-        ptcl_ddmc_albedo<NDIM>(s, rng);
-        if (!s.is_rejected) ptcl_ddmc_step<NDIM>(s, rng);
-      } else {
-        imc_step_core<NDIM>(s, lam_abs, lam_sc, rng);
-      }
-      t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
-
-      xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:146
-
-      if (!on_block(M, ip, jp, kp)) {
-        if constexpr (DDMC) {  // transport_ddmc.cpp:203-211: zero velocity flags a DDMC leak
-          const double vmask = (is_ddmc_step && multi_d && !s.is_rejected) ? 0.0 : 1.0;
-          vx *= vmask; vy *= vmask; vz *= vmask;
-        }
-        // ---- comm phase, in flight ----
-        if (!apply_swarm_bcs<NDIM>(M, x, y, z, vx, vy, vz)) {
-          status = ST_ESCAPED;
-        } else {
-          const int g = find_block<NDIM>(M, x, y, z);
-          if (M.owner[g] != M.rank) {
-            status = ST_OUTGOING;
-            b = g;  // global id travels in blk
+    while (__popcll(__ballot(ls == LS_RUN)) >= thresh) {
+      if (ls == LS_RUN) {
+        ++c_ev;
+        Step s;
+        s.t_start = t_start; s.dt = dt; s.vv = vv; s.dx_push = B.dx_push;
+        cell_faces(s);
+        const long long q = cidx(M, kp, jp, ip);
+        s.t = t; s.x = x; s.y = y; s.z = z; s.vx = vx; s.vy = vy; s.vz = vz;
+        s.ip = ip; s.jp = jp; s.kp = kp;
+        s.is_absorbed = false; s.is_scattered = false; s.is_rejected = false;
+        bool is_ddmc_step = false;
+        if constexpr (kFastGray) {
+          // per-cell mean free paths precomputed by k_fleck: two gathers instead of three, and
+          // no division (same values: same operations on the same operands)
+          imc_step_core<NDIM>(s, f0[q], f1[q], rng);
+        } else if constexpr (kPackedDdmc) {
+          const double4 *rec = reinterpret_cast<const double4 *>(f0 + 8 * q);
+          const double4 r0 = rec[0];
+          s.ffaa = r0.x; s.sig = r0.y;
+          is_ddmc_step = B.dx_push * s.sig > P.tau_ddmc;  // transport_ddmc.cpp:135
+          if (is_ddmc_step) {
+            const double4 r1 = rec[1];
+            s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
+            ptcl_ddmc_albedo<NDIM>(s, rng);
+            if (!s.is_rejected) resample = ddmc_step_event<NDIM>(s, rng);
           } else {
-            b = M.local_index[g];
-            bind_block(b);
-            if constexpr (DDMC && multi_d)
-              sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
-            xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // next launch's transport.cpp:96
+            imc_step_core<NDIM>(s, f1[q], f2[q], rng);
+          }
+        } else {
+          const double rho = f0[q];
+          const double temp = eos_temperature(P, rho, f1[q]);
+          s.ff = f2[q];
+          s.ss = opac_scattering(P, rho, temp, ee);
+          s.aa = opac_absorption(P, rho, temp, ee);
+          s.ffaa = s.ff * s.aa;
+          s.sig = s.aa + s.ss;
+          if constexpr (DDMC) is_ddmc_step = B.dx_push * s.sig > P.tau_ddmc;
+          if (DDMC && is_ddmc_step) {
+            // transport_ddmc.cpp:137-179
+            s.Px_l = M.P1[b][q];
+            s.Px_u = M.P1[b][cidx(M, kp, jp, ip + 1)];
+            s.Py_l = multi_d ? M.P2[b][q] : 0.0;
+            s.Py_u = multi_d ? M.P2[b][cidx(M, kp, jp + 1, ip)] : 0.0;
+            s.Pz_l = three_d ? M.P3[b][q] : 0.0;
+            s.Pz_u = three_d ? M.P3[b][cidx(M, kp + 1, jp, ip)] : 0.0;
+            ptcl_ddmc_albedo<NDIM>(s, rng);
+            if (!s.is_rejected) resample = ddmc_step_event<NDIM>(s, rng);
+          } else {
+            double lam_abs, lam_sc;
+            imc_cell_mfp(s.ff, s.aa, s.ss, lam_abs, lam_sc);
+            imc_step_core<NDIM>(s, lam_abs, lam_sc, rng);
           }
         }
-      } else if (s.is_absorbed) {  // transport.cpp:157-163
-        atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
-        status = ST_ABSORBED;
-      } else if (s.is_scattered) {
-        scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
+        t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
+
+        xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:146
+
+        if (!on_block(M, ip, jp, kp)) {
+          if constexpr (DDMC) {  // transport_ddmc.cpp:203-211: zero velocity flags a DDMC leak
+            const double vmask = (is_ddmc_step && multi_d && !s.is_rejected) ? 0.0 : 1.0;
+            vx *= vmask; vy *= vmask; vz *= vmask;
+          }
+          ls = LS_RELOC;  // comm phase: in the service phase
+        } else if (s.is_absorbed) {  // transport.cpp:157-163
+          atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
+          status = ST_ABSORBED;
+          ls = LS_DONE;
+        } else {
+          if (s.is_scattered) scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
+          if (!(t < t_end)) ls = LS_DONE;                    // census
+        }
       }
-      if (status != ST_ACTIVE || !(t < t_end)) finish();  // left, absorbed, or census
-      }  // if (active)
     }
   }
 

@@ -87,6 +87,7 @@ __device__ __forceinline__ double sample_planck_energy(Rng &rng, double sb, doub
 struct Step {
   double t_start, dt;
   double ff, aa, ss, vv, dx_push;
+  double ffaa, sig;  // ff * aa and aa + ss (DDMC functions read these; set by the caller)
   double xl, yl, zl, xu, yu, zu;
   double Px_l, Py_l, Pz_l, Px_u, Py_u, Pz_u;
   double t, x, y, z, vx, vy, vz;
@@ -156,10 +157,24 @@ __device__ __forceinline__ void ptcl_transport_step(Step &s, Rng &rng) {
   imc_step_core<NDIM>(s, lam_abs, lam_sc, rng);
 }
 
+// Cyclic assignment (axis, axis+1, axis+2) <- (v1, v2, v3): the component order the reference
+// passes to sample_face_iso_dir for an x-, y- or z-face (transport_utils.hpp:217,235,253).
+__device__ __forceinline__ void assign_cyclic(int axis, double v1, double v2, double v3, double &vx,
+                                              double &vy, double &vz) {
+  vx = (axis == 0) ? v1 : (axis == 1 ? v3 : v2);
+  vy = (axis == 0) ? v2 : (axis == 1 ? v1 : v3);
+  vz = (axis == 0) ? v3 : (axis == 1 ? v2 : v1);
+}
+
 // reference transport_utils.hpp:163-277 -- one DDMC step
 // draws: 1 (time); event: +1 (channel), leak: +2 (direction); census: +5
+// The reference's six leak branches differ only in which face / axis they act on; here the
+// channel is selected as data and the shared arithmetic (one half-isotropic direction sample)
+// is executed once, so a wave whose lanes leak through different faces does not serialise six
+// copies of it.  Operations and operands per lane are unchanged.
+// Returns true when the particle reached census without an event (the caller then resamples it).
 template <int NDIM, class Rng>
-__device__ __forceinline__ void ptcl_ddmc_step(Step &s, Rng &rng) {
+__device__ __forceinline__ bool ddmc_step_event(Step &s, Rng &rng) {
   constexpr int multi_d = NDIM >= 2 ? 1 : 0, three_d = NDIM == 3 ? 1 : 0;
   const double rmin = DBL_MIN;
   const double eps = kEpsDdmc;
@@ -175,7 +190,7 @@ __device__ __forceinline__ void ptcl_ddmc_step(Step &s, Rng &rng) {
   const double leakz_u = s.Pz_u / dz;
   const double leak_tot = leakx_l + leakx_u + leaky_l + leaky_u + leakz_l + leakz_u;
 
-  const double cdf_ddmc = s.ff * s.aa + leak_tot + rmin;
+  const double cdf_ddmc = s.ffaa + leak_tot + rmin;
   const double dt_ddmc = -m_log(rng.drand()) / (s.vv * cdf_ddmc);
   const double dt_end = (s.t_start + s.dt) - s.t;
   const bool is_ddmc_event = dt_ddmc < dt_end;
@@ -184,81 +199,69 @@ __device__ __forceinline__ void ptcl_ddmc_step(Step &s, Rng &rng) {
 
   if (is_ddmc_event) {
     const double xi = cdf_ddmc * rng.drand();
-    if (xi < s.ff * s.aa) {
+    if (xi < s.ffaa) {
       s.is_absorbed = true;
-    } else if (xi < s.ff * s.aa + leak_tot) {
-      const double xim = xi - s.ff * s.aa;
-      if (xim < leakx_l) {  // -x
-        s.ip -= 1;
-        s.x = s.xl - eps * dx;
-        s.y = s.yl + 0.5 * dy;
-        s.z = s.zl + 0.5 * dz;
-        sample_face_iso_dir(-s.vv, rng, s.vx, s.vy, s.vz);
-      } else if (xim < leakx_l + leakx_u) {  // +x
-        s.ip += 1;
-        s.x = s.xu + eps * dx;
-        s.y = s.yl + 0.5 * dy;
-        s.z = s.zl + 0.5 * dz;
-        sample_face_iso_dir(s.vv, rng, s.vx, s.vy, s.vz);
-      } else if (xim < leakx_l + leakx_u + leaky_l) {  // -y
-        s.jp -= multi_d;
-        s.y = s.yl - eps * dy;
-        s.z = s.zl + 0.5 * dz;
-        s.x = s.xl + 0.5 * dx;
-        sample_face_iso_dir(-s.vv, rng, s.vy, s.vz, s.vx);
-      } else if (xim < leakx_l + leakx_u + leaky_l + leaky_u) {  // +y
-        s.jp += multi_d;
-        s.y = s.yu + eps * dy;
-        s.z = s.zl + 0.5 * dz;
-        s.x = s.xl + 0.5 * dx;
-        sample_face_iso_dir(s.vv, rng, s.vy, s.vz, s.vx);
-      } else if (xim < leakx_l + leakx_u + leaky_l + leaky_u + leakz_l) {  // -z
-        s.kp -= three_d;
-        s.z = s.zl - eps * dz;
-        s.x = s.xl + 0.5 * dx;
-        s.y = s.yl + 0.5 * dy;
-        sample_face_iso_dir(-s.vv, rng, s.vz, s.vx, s.vy);
-      } else if (xim <= leak_tot) {  // +z
-        s.kp += three_d;
-        s.z = s.zu + eps * dz;
-        s.x = s.xl + 0.5 * dx;
-        s.y = s.yl + 0.5 * dy;
-        sample_face_iso_dir(s.vv, rng, s.vz, s.vx, s.vy);
+    } else if (xi < s.ffaa + leak_tot) {
+      const double xim = xi - s.ffaa;
+      // cumulative thresholds, summed left to right exactly as written at lines 218-254
+      const double c1 = leakx_l;
+      const double c2 = leakx_l + leakx_u;
+      const double c3 = c2 + leaky_l;
+      const double c4 = c3 + leaky_u;
+      const double c5 = c4 + leakz_l;
+      const int ch = (xim < c1) ? 0 : (xim < c2) ? 1 : (xim < c3) ? 2 : (xim < c4) ? 3
+                   : (xim < c5) ? 4 : (xim <= leak_tot) ? 5 : -1;
+      if (ch >= 0) {
+        const int axis = ch >> 1;
+        const bool up = (ch & 1) != 0;
+        const int step = up ? 1 : -1;
+        s.ip += (axis == 0) ? step : 0;
+        s.jp += (axis == 1) ? step * multi_d : 0;
+        s.kp += (axis == 2) ? step * three_d : 0;
+        // eps beyond the leak face along the leak axis, cell centre across it
+        s.x = (axis == 0) ? (up ? s.xu + eps * dx : s.xl - eps * dx) : s.xl + 0.5 * dx;
+        s.y = (axis == 1) ? (up ? s.yu + eps * dy : s.yl - eps * dy) : s.yl + 0.5 * dy;
+        s.z = (axis == 2) ? (up ? s.zu + eps * dz : s.zl - eps * dz) : s.zl + 0.5 * dz;
+        double v1, v2, v3;
+        sample_face_iso_dir(up ? s.vv : -s.vv, rng, v1, v2, v3);
+        assign_cyclic(axis, v1, v2, v3, s.vx, s.vy, s.vz);
       }
     }
-  } else {
-    // census: uniform position in the cell (draw order z, x, y), isotropic direction with the
-    // polar axis along z (lines 267-275)
-    s.z = s.zl + rng.drand() * dz;
-    s.x = s.xl + rng.drand() * dx;
-    s.y = s.yl + rng.drand() * dy;
-    const double mu = 1.0 - 2.0 * rng.drand();
-    const double nu = sqrt(1.0 - mu * mu);
-    const double phi = kTwoPi * rng.drand();
-    double sn, cs;
-    m_sincos(phi, sn, cs);
-    s.vz = s.vv * mu;
-    s.vx = s.vv * nu * cs;
-    s.vy = s.vv * nu * sn;
   }
+  return !is_ddmc_event;
 }
 
-// One face of the IMC -> DDMC albedo test (the six branches of transport_utils.hpp:288-389);
-// sgn = +1 lower face, -1 upper face.
+// reference transport_utils.hpp:265-276: a DDMC particle that reaches census gets a uniform
+// position in its cell (draw order z, x, y) and an isotropic direction with the polar axis along
+// z.  5 draws.  Kept apart from the event part so that the tracking kernel can run it once per
+// history, outside its event loop.
 template <class Rng>
-__device__ __forceinline__ void albedo_face(Step &s, Rng &rng, double dcell, double sgn,
-                                            double &vn, double &va, double &vb, double &xn,
-                                            double face) {
-  const double Pf = (2.0 / 3.0) / ((s.aa + s.ss) * dcell + 2.0 * kLamExt);
-  const double P = 2.0 * Pf * (1.0 + sgn * 1.5 * vn / s.vv);
-  if (rng.drand() > P) {
-    sample_face_iso_dir(-sgn * s.vv, rng, vn, va, vb);
-    xn = face - sgn * kEpsImc * dcell;
-    s.is_rejected = true;
-  }
+__device__ __forceinline__ void ddmc_census_resample(Step &s, Rng &rng) {
+  const double dx = s.xu - s.xl;
+  const double dy = s.yu - s.yl;
+  const double dz = s.zu - s.zl;
+  s.z = s.zl + rng.drand() * dz;
+  s.x = s.xl + rng.drand() * dx;
+  s.y = s.yl + rng.drand() * dy;
+  const double mu = 1.0 - 2.0 * rng.drand();
+  const double nu = sqrt(1.0 - mu * mu);
+  const double phi = kTwoPi * rng.drand();
+  double sn, cs;
+  m_sincos(phi, sn, cs);
+  s.vz = s.vv * mu;
+  s.vx = s.vv * nu * cs;
+  s.vy = s.vv * nu * sn;
 }
 
-// reference transport_utils.hpp:279-397 -- 0..3 draws
+// reference transport_utils.hpp:163-277 -- one DDMC step (event part + census resampling)
+template <int NDIM, class Rng>
+__device__ __forceinline__ void ptcl_ddmc_step(Step &s, Rng &rng) {
+  if (ddmc_step_event<NDIM>(s, rng)) ddmc_census_resample(s, rng);
+}
+
+// reference transport_utils.hpp:279-397 -- 0..3 draws.  The six face branches of the reference
+// (x-, x+, y-, y+, z-, z+, in that order, y / z gated by dimensionality) are folded into "which
+// face, if any" followed by one copy of the albedo arithmetic.
 template <int NDIM, class Rng>
 __device__ __forceinline__ void ptcl_ddmc_albedo(Step &s, Rng &rng) {
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
@@ -267,18 +270,33 @@ __device__ __forceinline__ void ptcl_ddmc_albedo(Step &s, Rng &rng) {
   const double dz = s.zu - s.zl;
   const double tol = 2.5 * kEpsImc;
 
-  if (fuzzy_equal(s.x, s.xl, dx, tol)) {
-    albedo_face(s, rng, dx, 1.0, s.vx, s.vy, s.vz, s.x, s.xl);
-  } else if (fuzzy_equal(s.x, s.xu, dx, tol)) {
-    albedo_face(s, rng, dx, -1.0, s.vx, s.vy, s.vz, s.x, s.xu);
-  } else if (multi_d && fuzzy_equal(s.y, s.yl, dy, tol)) {
-    albedo_face(s, rng, dy, 1.0, s.vy, s.vz, s.vx, s.y, s.yl);
-  } else if (multi_d && fuzzy_equal(s.y, s.yu, dy, tol)) {
-    albedo_face(s, rng, dy, -1.0, s.vy, s.vz, s.vx, s.y, s.yu);
-  } else if (three_d && fuzzy_equal(s.z, s.zl, dz, tol)) {
-    albedo_face(s, rng, dz, 1.0, s.vz, s.vx, s.vy, s.z, s.zl);
-  } else if (three_d && fuzzy_equal(s.z, s.zu, dz, tol)) {
-    albedo_face(s, rng, dz, -1.0, s.vz, s.vx, s.vy, s.z, s.zu);
+  int face = -1;  // 0 x-, 1 x+, 2 y-, 3 y+, 4 z-, 5 z+
+  if (fuzzy_equal(s.x, s.xl, dx, tol)) face = 0;
+  else if (fuzzy_equal(s.x, s.xu, dx, tol)) face = 1;
+  else if (multi_d && fuzzy_equal(s.y, s.yl, dy, tol)) face = 2;
+  else if (multi_d && fuzzy_equal(s.y, s.yu, dy, tol)) face = 3;
+  else if (three_d && fuzzy_equal(s.z, s.zl, dz, tol)) face = 4;
+  else if (three_d && fuzzy_equal(s.z, s.zu, dz, tol)) face = 5;
+
+  if (face >= 0) {
+    const int axis = face >> 1;
+    const double sgn = (face & 1) ? -1.0 : 1.0;  // +1 lower face, -1 upper face
+    const double dcell = (axis == 0) ? dx : (axis == 1 ? dy : dz);
+    const double vn = (axis == 0) ? s.vx : (axis == 1 ? s.vy : s.vz);
+    const double fpos = (axis == 0) ? ((face & 1) ? s.xu : s.xl)
+                      : (axis == 1) ? ((face & 1) ? s.yu : s.yl) : ((face & 1) ? s.zu : s.zl);
+    const double Pf = (2.0 / 3.0) / (s.sig * dcell + 2.0 * kLamExt);
+    const double P = 2.0 * Pf * (1.0 + sgn * 1.5 * vn / s.vv);
+    if (rng.drand() > P) {
+      double v1, v2, v3;
+      sample_face_iso_dir(-sgn * s.vv, rng, v1, v2, v3);
+      assign_cyclic(axis, v1, v2, v3, s.vx, s.vy, s.vz);
+      const double xn = fpos - sgn * kEpsImc * dcell;
+      if (axis == 0) s.x = xn;
+      else if (axis == 1) s.y = xn;
+      else s.z = xn;
+      s.is_rejected = true;
+    }
   }
 
   if (!s.is_rejected) {
