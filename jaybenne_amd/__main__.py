@@ -1,0 +1,81 @@
+"""Run an input deck the way the reference's regression harness drives `mcblock`:
+
+    python -m jaybenne_amd -i tests/golden/decks/stepdiff.in parthenon/mesh/nx1=128 \\
+           parthenon/meshblock/nx1=128 [--tolerance 0.05] [--comparison weighted_mean]
+
+Trailing ``block/key=value`` arguments override deck values (Parthenon's command-line syntax,
+which tst/regression_test.py:85-145 emulates by rewriting the deck).  After the last cycle the
+energy tally is compared with the analytic solution of tst/stepdiff.py and the same five numbers
+as tst/regression_test.py:408-412 are printed; the exit code is 0 iff the chosen criterion is
+within the tolerance.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="python -m jaybenne_amd", description=__doc__,
+                                 formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("-i", "--input", required=True, help="Parthenon-style input deck")
+    ap.add_argument("--tolerance", type=float, default=None,
+                    help="pass/fail bound on the chosen error (0.05 stepdiff, 0.3 SMR decks in the reference)")
+    ap.add_argument("--comparison", default="weighted_mean", choices=["mean", "pointwise", "weighted_mean"])
+    ap.add_argument("--output", default=None, help="write tally / coordinates to this .npz")
+    ap.add_argument("overrides", nargs="*", help="block/key=value")
+    args = ap.parse_args(argv)
+
+    import torch
+    from . import analysis, mcblock
+    from .deck import ParameterInput
+
+    pin = ParameterInput.from_file(args.input)
+    ov = {}
+    for item in args.overrides:
+        if "=" not in item:
+            ap.error(f"override '{item}' is not of the form block/key=value")
+        k, v = item.split("=", 1)
+        ov[k] = v
+    pin.modify(ov)
+    if not torch.cuda.is_available():
+        print("jaybenne_amd needs a GPU (the history loop runs only as HIP kernels)", file=sys.stderr)
+        return 2
+    drv = mcblock.McblockDriver(pin, device=torch.device("cuda", 0))
+    print(f"problem {drv.mcb.problem_id}: {drv.mesh.ndim}-D, {drv.mesh.nblocks} meshblocks, "
+          f"levels {sorted(set(drv.mesh.blk_level.tolist()))}, {drv.md.n} photons")
+    t0 = time.perf_counter()
+    while drv.time < drv.tlim:
+        n0, e0 = drv.md.n, drv.md.events
+        c0 = time.perf_counter()
+        drv.Step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - c0
+        print(f"cycle={drv.ncycle} time={drv.time:.6e} dt={drv.dt:.6e} photons={drv.md.n} "
+              f"histories/s={n0 / dt:.3e} events/s={(drv.md.events - e0) / dt:.3e}")
+    print(f"walltime used = {time.perf_counter() - t0:.2f} s")
+    tally = drv.md.get_field("tally")
+    err = analysis.analytic_errors(drv.mesh, tally, drv.time)
+    print(f"Mean error:                     {err['mean_error']:.2e}")
+    print(f"Mean fractional error:          {err['mean_frac_error']:.2e}")
+    print(f"Mean weighted fractional error: {err['mean_frac_error_weighted']:.2e}")
+    print(f"Max error:                      {err['max_error']:.2e}")
+    print(f"Max fractional error:           {err['max_frac_error']:.2e}")
+    if args.output:
+        np.savez(args.output, tally=tally, time=drv.time, blk_xmin=drv.mesh.blk_xmin,
+                 blk_dx=drv.mesh.blk_dx, blk_level=drv.mesh.blk_level)
+    if args.tolerance is None:
+        return 0
+    crit = {"mean": err["mean_frac_error"], "pointwise": err["max_frac_error"],
+            "weighted_mean": err["mean_frac_error_weighted"]}[args.comparison]
+    ok = crit <= args.tolerance
+    print("TEST PASSED" if ok else "TEST FAILED")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -225,6 +225,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   D.ie = D.is + v->nx[0] - 1; D.je = D.js + v->nx[1] - 1; D.ke = D.ks + v->nx[2] - 1;
   D.ncell = v->nx[0] * v->nx[1] * v->nx[2];
   D.ntot = (long long)D.ni * D.nj * D.nk;
+  if (D.ntot * 8 >= (1ll << 31)) { delete m; return fail(JB_ERR_INVALID, "block too large: cell indices are 32-bit"); }
   int maxrank = 0;
   for (int g = 0; g < v->nblocks_total; ++g) maxrank = v->owner[g] > maxrank ? v->owner[g] : maxrank;
   m->nranks_seen = maxrank + 1;

@@ -115,8 +115,10 @@ __device__ __forceinline__ bool on_block(const DevMesh &M, int i, int j, int k) 
   return i >= M.is && i <= M.ie && j >= M.js && j <= M.je && k >= M.ks && k <= M.ke;
 }
 
-__device__ __forceinline__ long long cidx(const DevMesh &M, int k, int j, int i) {
-  return ((long long)k * M.nj + j) * M.ni + i;
+// cell index inside one block's [nk][nj][ni] array (a block has < 2^31 cells: checked at
+// jb_mesh_create)
+__device__ __forceinline__ int cidx(const DevMesh &M, int k, int j, int i) {
+  return (k * M.nj + j) * M.ni + i;
 }
 
 // ---- comm phase applied to one particle in flight ----------------------------------------------

@@ -55,8 +55,12 @@ __device__ __forceinline__ uint64_t rng_seed_state(uint32_t seed, uint32_t domai
   return s;
 }
 
+// (k52 + 0.5) * 2^-52, formed without an integer -> double conversion: 1.k52 (exponent bits of
+// 1.0 over the 52-bit mantissa k52) minus 1 is k52 * 2^-52 exactly, and adding 2^-53 is exact in
+// 53 bits.  Same value as ((double)k52 + 0.5) * 2^-52.
 __device__ __forceinline__ double u52_to_double(uint64_t k52) {
-  return ((double)k52 + 0.5) * 2.220446049250313080847263336181640625e-16;  // 2^-52
+  const double one_to_two = __longlong_as_double((long long)(0x3ff0000000000000ull | k52));
+  return (one_to_two - 1.0) + 1.1102230246251565404236316680908203125e-16;  // 2^-53
 }
 
 struct XorShiftRng {

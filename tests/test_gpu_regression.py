@@ -1,0 +1,47 @@
+"""The reference's regression suite (tst/stepdiff.py, tst/stepdiff_smr.py and the deck list of
+.github/workflows/ci.yml:122-140) on the GPU, through the same command-line surface."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DECKS = os.path.join(os.path.dirname(__file__), "golden", "decks")
+STEPDIFF = ["parthenon/mesh/nx1=128", "parthenon/meshblock/nx1=128"]
+SMR = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "parthenon/meshblock/nx1=16",
+       "parthenon/meshblock/nx2=16"]
+
+
+@pytest.mark.parametrize("deck,overrides,tol", [
+    ("stepdiff", STEPDIFF, 0.05), ("stepdiff_ddmc", STEPDIFF, 0.05),
+    ("stepdiff_smr", SMR, 0.3), ("stepdiff_smr_ddmc", SMR, 0.3), ("stepdiff_smr_hybrid", SMR, 0.3)])
+def test_reference_regression_suite(gpu_device, deck, overrides, tol, capsys):
+    from jaybenne_amd.__main__ import main
+    rc = main(["-i", os.path.join(DECKS, deck + ".in"), "--tolerance", str(tol)] + overrides)
+    out = capsys.readouterr().out
+    assert rc == 0 and "TEST PASSED" in out, out
+
+
+def test_smr_noise_floor_with_more_particles(gpu_device, capsys):
+    """The 0.3 gate of the SMR decks is Monte Carlo noise (20 particles per cell); with 20x the
+    particles the same problem must come down by ~sqrt(20): a systematic error would not."""
+    from jaybenne_amd.__main__ import main
+    rc = main(["-i", os.path.join(DECKS, "stepdiff_smr_hybrid.in"), "--tolerance", "0.08",
+               "jaybenne/num_particles=2000000"] + SMR)
+    assert rc == 0, capsys.readouterr().out
+
+
+def test_three_level_hybrid_extension(gpu_device, tmp_path, capsys):
+    """BASELINE config C5: the shipped hybrid deck (coarse DDMC / fine IMC) with a nested level-2
+    region added (sigma dx = 1.95, IMC) -- a synthetic extension pinned by the erf solution."""
+    from jaybenne_amd.__main__ import main
+    text = open(os.path.join(DECKS, "stepdiff_smr_hybrid.in")).read()
+    text += ("<parthenon/static_refinement2>\nlevel = 2\nx1min = -0.125\nx1max = 0.125\n"
+             "x2min = -0.125\nx2max = 0.125\nx3min = -0.25\nx3max = 0.25\n")
+    deck = tmp_path / "hybrid3.in"
+    deck.write_text(text)
+    # 32 blocks x 1024 cells: 2e7 particles = 610 per cell, Monte Carlo noise ~ 5 %
+    rc = main(["-i", str(deck), "--tolerance", "0.08", "jaybenne/num_particles=20000000"])
+    out = capsys.readouterr().out
+    assert "levels [0, 1, 2]" in out and rc == 0, out
