@@ -104,18 +104,25 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # JB_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    # (ranks then share devices and records travel through host memory); production is RCCL.
+    backend = os.environ.get("JB_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         from jaybenne_amd.comm import Comm
         comm = Comm(device=device)
 
     pin = make_deck(args.gpus, args.particles_per_gpu, args.block_nx, args.workload)
     drv = mcblock.McblockDriver(pin, rank=rank, nranks=world, comm=comm, device=device,
-                                capacity_factor=1.5)
+                                capacity_factor=1.5 if world == 1 else 3.0)
     md = drv.md
 
     def sync_all():
@@ -167,6 +174,7 @@ def main() -> None:
                        "blocks_per_gpu": md.nblocks, "particles_per_gpu": args.particles_per_gpu,
                        "parallelism": f"meshblocks over {args.gpus} rank(s), RCCL particle hand-off"},
             "events_per_s": events / wall,
+            "transport_iterations_per_step": getattr(md, "transport_iterations", 1),
             "events_per_history": ev_per_hist,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

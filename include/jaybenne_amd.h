@@ -48,7 +48,9 @@ enum {
   JB_ST_ACTIVE = 0,   /* resident on this device (in flight before, at census after transport) */
   JB_ST_ABSORBED = 1, /* MarkParticleForRemoval after an absorption (transport.cpp:157-163) */
   JB_ST_ESCAPED = 2,  /* left through an outflow swarm boundary */
-  JB_ST_OUTGOING = 3  /* destination block lives on another rank; blk holds its GLOBAL id */
+  JB_ST_OUTGOING = 3, /* to be handed to the rank that owns block `blk` (a GLOBAL id): the
+                         particle left the resident blocks, or reached census in a halo copy */
+  JB_ST_OUTGOING_ABSORBED = 4 /* absorbed inside a halo copy: the owner deposits its weight */
 };
 
 /* <jaybenne> input block, keys and defaults of reference jaybenne.cpp:163-223 */
@@ -88,7 +90,7 @@ typedef struct jb_scattering {
  * struct are HOST pointers; rho..P3 are host arrays of per-block DEVICE pointers. */
 typedef struct jb_mesh_view {
   int32_t ndim, ng;
-  int32_t nblocks;        /* local blocks */
+  int32_t nblocks;        /* blocks resident on this rank: the ones it owns + halo copies */
   int32_t nblocks_total;  /* Mesh::nbtotal */
   int32_t nx[3];          /* interior cells per block */
   int32_t nleaf[3];       /* extent of leaf_map (blocks of the finest level) */
@@ -97,8 +99,12 @@ typedef struct jb_mesh_view {
   double gmin[3], gmax[3];
   const int32_t *leaf_map;     /* [nleaf2][nleaf1][nleaf0] -> global block id */
   const int32_t *owner;        /* [nblocks_total] rank that owns each global block */
-  const int32_t *local_index;  /* [nblocks_total] index in this rank's block list, or -1 */
-  const int32_t *gid;          /* [nblocks] global id of each local block */
+  const int32_t *local_index;  /* [nblocks_total] index in this rank's resident list, or -1 */
+  const int32_t *gid;          /* [nblocks] global id of each resident block */
+  const int32_t *owned;        /* [nblocks] 1 = owned by this rank, 0 = halo copy: a read-only
+                                  mirror of a neighbour rank's block (fields filled by the host)
+                                  that lets particles be tracked across the rank boundary; may be
+                                  NULL = every resident block is owned */
   const double *blk_xmin;      /* [nblocks][3] */
   const double *blk_xmax;      /* [nblocks][3] */
   const double *blk_dx;        /* [nblocks][3] (inactive dimensions: full extent) */
@@ -175,12 +181,15 @@ jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh, const jb_swarm_
 
 /* TransportPhotons / TransportPhotons_DDMC(md, t_start, dt) -- jaybenne.hpp:59-60,
  * transport.cpp:28-181, transport_ddmc.cpp:28-237.  Particles [first,last) with status ACTIVE
- * are followed until census, absorption, escape, or until they enter a block owned by another
- * rank (status OUTGOING).  Crossing into a block of THIS rank does not end the launch: the swarm
+ * are followed until census, absorption, escape, or until they enter a block that is not
+ * resident on this rank (status OUTGOING).  Crossing into a resident block -- owned or a halo
+ * copy -- does not end the launch: the swarm
  * boundary conditions (boundaries.hpp:46-82, periodic, outflow), the destination-block lookup
  * and SampleDDMCBlockFace are applied to the particle in flight.  With fuse_census_tally != 0
- * a particle reaching census adds weight / cell volume to energy_tally (EvaluateRadiationEnergy
- * fused; the caller zeroes the tally first with jb_zero_energy_tally). */
+ * a particle reaching census in an OWNED block adds weight / cell volume to energy_tally
+ * (EvaluateRadiationEnergy fused; the caller zeroes the tally first with jb_zero_energy_tally).
+ * A particle that reaches census or is absorbed in a HALO copy is marked OUTGOING /
+ * OUTGOING_ABSORBED: its owner tallies it after the hand-off. */
 jb_status jb_transport_photons(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
                                double t_start, double dt, int64_t first, int64_t last,
                                int fuse_census_tally);
@@ -215,12 +224,15 @@ jb_status jb_photon_reflect_bc(jb_context *ctx, jb_mesh *mesh, const jb_swarm_vi
 jb_status jb_remove_marked_particles(jb_context *ctx, jb_swarm_view *swarm);
 
 /* MeshSend / MeshReceive (jaybenne.cpp:36-61) for the inter-rank part: OUTGOING particles are
- * copied into fixed-size records (JB_RECORD_WORDS x 8 bytes), ordered by destination rank;
- * counts_host[r] = records for rank r.  Unpack appends records to the swarm as ACTIVE particles
- * of this rank's blocks. */
+ * among [first,last) are copied into fixed-size records (JB_RECORD_WORDS x 8 bytes), ordered by
+ * destination rank, and their slots are re-marked JB_ST_ABSORBED-like holes (status
+ * JB_ST_ESCAPED is kept for escapes; packed particles become JB_ST_ABSORBED so that a later
+ * pack does not send them twice).  counts_host[r] = records for rank r.  Unpack appends records
+ * to the swarm as ACTIVE particles of this rank's blocks. */
 #define JB_RECORD_WORDS 13
-jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm, int nranks,
-                           int64_t *records_dev, int64_t record_capacity, int64_t *counts_host);
+jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                           int64_t first, int64_t last, int nranks, int64_t *records_dev,
+                           int64_t record_capacity, int64_t *counts_host);
 jb_status jb_unpack_incoming(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm,
                              const int64_t *records_dev, int64_t nrecords);
 

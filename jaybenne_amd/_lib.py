@@ -17,7 +17,7 @@ JB_COMPLETE, JB_ITERATE, JB_INCOMPLETE = 0, 1, 2
 JB_ERR_INVALID, JB_ERR_HIP, JB_ERR_CAPACITY, JB_ERR_UNSUPPORTED = -1, -2, -3, -4
 JB_SOURCE_THERMAL, JB_SOURCE_EMISSION = 0, 1
 JB_STRATEGY_UNIFORM, JB_STRATEGY_ENERGY = 0, 1
-JB_ST_ACTIVE, JB_ST_ABSORBED, JB_ST_ESCAPED, JB_ST_OUTGOING = 0, 1, 2, 3
+JB_ST_ACTIVE, JB_ST_ABSORBED, JB_ST_ESCAPED, JB_ST_OUTGOING, JB_ST_OUTGOING_ABSORBED = 0, 1, 2, 3, 4
 JB_RECORD_WORDS = 13
 
 _dpp = C.POINTER(C.c_void_p)
@@ -55,7 +55,7 @@ class MeshView(C.Structure):
                  ("bc", C.c_int32 * 6), ("rank", C.c_int32), ("pad", C.c_int32),
                  ("gmin", C.c_double * 3), ("gmax", C.c_double * 3),
                  ("leaf_map", C.c_void_p), ("owner", C.c_void_p), ("local_index", C.c_void_p),
-                 ("gid", C.c_void_p), ("blk_xmin", C.c_void_p), ("blk_xmax", C.c_void_p),
+                 ("gid", C.c_void_p), ("owned", C.c_void_p), ("blk_xmin", C.c_void_p), ("blk_xmax", C.c_void_p),
                  ("blk_dx", C.c_void_p), ("blk_level", C.c_void_p), ("blk_nbr_lev", C.c_void_p)] +
                 [(n, C.c_void_p) for n in FIELD_NAMES])
 
@@ -113,7 +113,7 @@ PROTOTYPES = {
     "jb_update_fluid": (_int, [_vp, _vp]),
     "jb_photon_reflect_bc": (_int, [_vp, _vp, C.POINTER(SwarmView), _int]),
     "jb_remove_marked_particles": (_int, [_vp, C.POINTER(SwarmView)]),
-    "jb_pack_outgoing": (_int, [_vp, _vp, C.POINTER(SwarmView), _int, _vp, _i64, _vp]),
+    "jb_pack_outgoing": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, _i64, _int, _vp, _i64, _vp]),
     "jb_unpack_incoming": (_int, [_vp, _vp, C.POINTER(SwarmView), _vp, _i64]),
     "jb_estimate_timestep": (_f64, [_vp]),
     "jb_radiation_step": (_int, [_vp, _vp, C.POINTER(SwarmView), _f64, _f64,

@@ -61,14 +61,26 @@ class Comm:
         dist.all_to_all_single(r, s, group=self.group)
         return r.cpu().numpy()
 
+    def gather_count_matrix(self, send_counts: np.ndarray) -> np.ndarray:
+        """counts[s, r] = records rank s sends to rank r, known to every rank after ONE
+        all-gather: it carries both each rank's receive sizes and the global total that decides
+        termination (the reference's separate completion all-reduce, jaybenne.cpp:130-131)."""
+        s = torch.from_numpy(np.ascontiguousarray(send_counts, dtype=np.int64)).to(self.device)
+        out = torch.empty(self.nranks * self.nranks, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(out, s, group=self.group)
+        return out.cpu().numpy().reshape(self.nranks, self.nranks)
+
     def exchange_records(self, send: Optional[torch.Tensor], send_counts: np.ndarray,
-                         out_device: torch.device) -> Optional[torch.Tensor]:
+                         out_device: torch.device, recv_counts: Optional[np.ndarray] = None
+                         ) -> Optional[torch.Tensor]:
         """send: [sum(send_counts), 13] int64 ordered by destination rank (or None).  Returns the
-        records addressed to this rank, [nrecv, 13] int64 on ``out_device`` (or None)."""
+        records addressed to this rank, [nrecv, 13] int64 on ``out_device`` (or None).
+        recv_counts: column of the count matrix if the caller already gathered it."""
         send_counts = np.asarray(send_counts, dtype=np.int64)
         if send_counts[self.rank] != 0:
             raise ValueError("a rank does not hand particles to itself")
-        recv_counts = self.exchange_counts(send_counts)
+        if recv_counts is None:
+            recv_counts = self.exchange_counts(send_counts)
         nrecv = int(recv_counts.sum())
         if send is None:
             send = torch.empty((0, RECORD_WORDS), dtype=torch.int64, device=self.device)

@@ -200,11 +200,13 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
       return fail(JB_ERR_INVALID, "leaf_map entry out of range");
   for (int g = 0; g < v->nblocks_total; ++g) {
     const int li = v->local_index[g];
+    if (li >= v->nblocks || li < -1 || (li >= 0 && v->gid[li] != g))
+      return fail(JB_ERR_INVALID, "local_index / gid inconsistent for block %d", g);
     if (v->owner[g] == v->rank) {
-      if (li < 0 || li >= v->nblocks || v->gid[li] != g)
-        return fail(JB_ERR_INVALID, "local_index / gid inconsistent for block %d", g);
-    } else if (li != -1) {
-      return fail(JB_ERR_INVALID, "local_index must be -1 for blocks of other ranks");
+      if (li < 0) return fail(JB_ERR_INVALID, "owned block %d is not resident", g);
+      if (v->owned && !v->owned[li]) return fail(JB_ERR_INVALID, "block %d owned but flagged as halo", g);
+    } else if (li >= 0 && (!v->owned || v->owned[li])) {
+      return fail(JB_ERR_INVALID, "resident block %d of another rank must be flagged as a halo copy", g);
     }
     if (v->owner[g] < 0) return fail(JB_ERR_INVALID, "negative owner rank");
   }
@@ -241,6 +243,14 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   UP(owner, v->nblocks_total);
   UP(local_index, v->nblocks_total);
   UP(gid, v->nblocks);
+  {
+    std::vector<int32_t> ow(v->nblocks, 1);
+    if (v->owned) ow.assign(v->owned, v->owned + v->nblocks);
+    if ((st = upload(m, ow.data(), ow.size(), &D.owned)) != JB_COMPLETE) {
+      jb_mesh_destroy(m);
+      return st;
+    }
+  }
   UP(blk_xmin, 3 * v->nblocks);
   UP(blk_xmax, 3 * v->nblocks);
   UP(blk_dx, 3 * v->nblocks);
@@ -623,19 +633,20 @@ extern "C" jb_status jb_remove_marked_particles(jb_context *ctx, jb_swarm_view *
 }
 
 extern "C" jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
-                                      int nranks, int64_t *records_dev, int64_t record_capacity,
-                                      int64_t *counts_host) {
+                                      int64_t first, int64_t last, int nranks, int64_t *records_dev,
+                                      int64_t record_capacity, int64_t *counts_host) {
   if (!ctx || !mesh || !counts_host) return fail(JB_ERR_INVALID, "null argument");
   jb_status st = check_swarm(swarm, "jb_pack_outgoing");
   if (st != JB_COMPLETE) return st;
+  if (first < 0 || last > swarm->n || first > last) return fail(JB_ERR_INVALID, "bad particle range");
   if (nranks < mesh->nranks_seen || nranks > kCounterWords - kRankBase)
     return fail(JB_ERR_INVALID, "nranks = %d does not cover the owners in the mesh view", nranks);
   unsigned long long *per_rank = ctx->counters_d + kRankBase;
   JB_HIP(hipMemsetAsync(per_rank, 0, sizeof(unsigned long long) * nranks, ctx->stream));
   const DevSwarm S = dev_swarm(swarm);
-  if (swarm->n > 0)
-    hipLaunchKernelGGL(k_count_outgoing, dim3(grid_for(ctx, swarm->n)), dim3(kBlock), 0, ctx->stream,
-                       mesh->dm, S, (long long)swarm->n, per_rank);
+  if (last > first)
+    hipLaunchKernelGGL(k_count_outgoing, dim3(grid_for(ctx, last - first)), dim3(kBlock), 0, ctx->stream,
+                       mesh->dm, S, (long long)first, (long long)last, per_rank);
   JB_HIP(hipGetLastError());
   JB_HIP(hipMemcpyAsync(ctx->counters_h + kRankBase, per_rank, sizeof(unsigned long long) * nranks,
                         hipMemcpyDeviceToHost, ctx->stream));
@@ -656,9 +667,9 @@ extern "C" jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_s
   JB_HIP(hipMemcpyAsync(ctx->scratch_d, firsts.data(), sizeof(long long) * nranks, hipMemcpyHostToDevice,
                         ctx->stream));
   JB_HIP(hipMemsetAsync(per_rank, 0, sizeof(unsigned long long) * nranks, ctx->stream));
-  hipLaunchKernelGGL(k_pack_outgoing, dim3(grid_for(ctx, swarm->n)), dim3(kBlock), 0, ctx->stream, mesh->dm,
-                     S, (long long)swarm->n, (const long long *)ctx->scratch_d, per_rank,
-                     (long long *)records_dev);
+  hipLaunchKernelGGL(k_pack_outgoing, dim3(grid_for(ctx, last - first)), dim3(kBlock), 0, ctx->stream,
+                     mesh->dm, S, (long long)first, (long long)last, (const long long *)ctx->scratch_d,
+                     per_rank, (long long *)records_dev);
   JB_HIP(hipGetLastError());
   JB_HIP(hipStreamSynchronize(ctx->stream));  // firsts lives on this stack frame
   return JB_COMPLETE;
@@ -691,7 +702,7 @@ extern "C" jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_
                                        int32_t *prefix_dev) {
   if (!ctx || !mesh || !swarm || !next_id || !epoch) return fail(JB_ERR_INVALID, "null argument");
   const DevMesh &M = mesh->dm;
-  if (M.nblocks != M.nblocks_total)
+  if (M.nblocks != M.nblocks_total || mesh->nranks_seen != 1)
     return fail(JB_ERR_INVALID, "jb_radiation_step needs the whole mesh on one rank");
   jb_status st = jb_update_derived_transport_fields(ctx, mesh, dt);
   if (st != JB_COMPLETE) return st;

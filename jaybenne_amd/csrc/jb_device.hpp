@@ -19,6 +19,7 @@ struct DevMesh {
   long long ntot;     // cells per block incl. ghosts
   double gmin[3], gmax[3];
   const int *leaf_map, *owner, *local_index, *gid;
+  const int *owned;  // [nblocks] 1 = owned by this rank, 0 = halo copy
   const double *blk_xmin, *blk_xmax, *blk_dx;
   const double *blk_inv_dx;  // [nblocks][3]: 1.0 / dx, computed once on the host
   double inv_leaf_len[3];    // 1.0 / ((gmax - gmin) / nleaf)
@@ -50,7 +51,7 @@ struct DevSwarm {
   uint64_t *rng;  // xorshift64* state of the particle's stream
 };
 
-enum { ST_ACTIVE = 0, ST_ABSORBED = 1, ST_ESCAPED = 2, ST_OUTGOING = 3 };
+enum { ST_ACTIVE = 0, ST_ABSORBED = 1, ST_ESCAPED = 2, ST_OUTGOING = 3, ST_OUTGOING_ABSORBED = 4 };
 enum { BC_PERIODIC = 0, BC_REFLECT = 1, BC_OUTFLOW = 2 };
 
 // ---- EOS / opacity evaluated per event, device side (singularity IdealGas / Gray / GrayS;

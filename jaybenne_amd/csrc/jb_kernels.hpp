@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(kBlock)
   for (int base = 0; base < M.ncell; base += kBlock) {
     const int cell = base + threadIdx.x;
     int cnt = 0;
-    if (cell < M.ncell) {
+    if (cell < M.ncell && M.owned[b]) {   // halo copies source nothing: their owner does
       int k = cell / (M.nx[0] * M.nx[1]);
       const int r = cell - k * (M.nx[0] * M.nx[1]);
       int j = r / M.nx[0];
@@ -280,6 +280,7 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
        c += (long long)gridDim.x * blockDim.x) {
     int b, k, j, i, cell;
     decode_cell(M, c, b, k, j, i, cell);
+    if (!M.owned[b]) continue;
     const long long q = cidx(M, k, j, i);
     double dej = 0.0;
     if (source_type == 1) {
@@ -384,12 +385,13 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
         ls = LS_DONE;
       } else {
         const int g = find_block<NDIM>(M, x, y, z);
-        if (M.owner[g] != M.rank) {
+        const int li = M.local_index[g];
+        if (li < 0) {  // not resident here: hand the particle to the block's owner
           status = ST_OUTGOING;
           b = g;  // global id travels in blk
           ls = LS_DONE;
         } else {
-          b = M.local_index[g];
+          b = li;
           bind_block(b);
           if constexpr (DDMC && multi_d)
             sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
@@ -408,6 +410,12 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
           x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
           resample = false;
         }
+      }
+      if ((status == ST_ACTIVE || status == ST_OUTGOING_ABSORBED) && !M.owned[b]) {
+        // finished inside a halo copy: the owner of the block takes it from here (census tally
+        // or absorption deposit)
+        if (status == ST_ACTIVE) status = ST_OUTGOING;
+        b = M.gid[b];
       }
       S.blk[n] = b;
       S.t[n] = t;
@@ -538,8 +546,12 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
           }
           ls = LS_RELOC;  // comm phase: in the service phase
         } else if (s.is_absorbed) {  // transport.cpp:157-163
-          atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
-          status = ST_ABSORBED;
+          if (M.owned[b]) {
+            atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
+            status = ST_ABSORBED;
+          } else {
+            status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
+          }
           ls = LS_DONE;
         } else {
           if (s.is_scattered) scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
@@ -720,18 +732,22 @@ __global__ void __launch_bounds__(kBlock)
 constexpr int kRecWords = 13;
 
 __global__ void __launch_bounds__(kBlock)
-    k_count_outgoing(DevMesh M, DevSwarm S, long long n_total, unsigned long long *per_rank) {
-  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
+    k_count_outgoing(DevMesh M, DevSwarm S, long long n_first, long long n_total,
+                     unsigned long long *per_rank) {
+  for (long long n = n_first + (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
        n += (long long)gridDim.x * blockDim.x)
-    if (S.status[n] == ST_OUTGOING) atomicAdd(&per_rank[M.owner[S.blk[n]]], 1ull);
+    if (S.status[n] == ST_OUTGOING || S.status[n] == ST_OUTGOING_ABSORBED)
+      atomicAdd(&per_rank[M.owner[S.blk[n]]], 1ull);
 }
 
 __global__ void __launch_bounds__(kBlock)
-    k_pack_outgoing(DevMesh M, DevSwarm S, long long n_total, const long long *rank_first,
-                    unsigned long long *rank_cursor, long long *rec) {
-  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
+    k_pack_outgoing(DevMesh M, DevSwarm S, long long n_first, long long n_total,
+                    const long long *rank_first, unsigned long long *rank_cursor, long long *rec) {
+  for (long long n = n_first + (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
        n += (long long)gridDim.x * blockDim.x) {
-    if (S.status[n] != ST_OUTGOING) continue;
+    const int st = S.status[n];
+    if (st != ST_OUTGOING && st != ST_OUTGOING_ABSORBED) continue;
+    S.status[n] = ST_ABSORBED;  // the slot is a hole from now on (removed by the next compaction)
     const int g = S.blk[n];
     const int r = M.owner[g];
     const long long slot = rank_first[r] + (long long)atomicAdd(&rank_cursor[r], 1ull);
@@ -741,7 +757,8 @@ __global__ void __launch_bounds__(kBlock)
     o[4] = __double_as_longlong(S.vy[n]); o[5] = __double_as_longlong(S.vz[n]);
     o[6] = __double_as_longlong(S.t[n]); o[7] = __double_as_longlong(S.w[n]);
     o[8] = __double_as_longlong(S.e[n]);
-    o[9] = (long long)S.id[n];
+    // bit 63 of the id word: absorbed in a halo copy, the receiver only deposits the weight
+    o[9] = (long long)(S.id[n] | (st == ST_OUTGOING_ABSORBED ? (1ull << 63) : 0ull));
     o[10] = (long long)(((unsigned long long)(unsigned)S.jp[n] << 32) | (unsigned)S.ip[n]);
     o[11] = (long long)(((unsigned long long)(unsigned)g << 32) | (unsigned)S.kp[n]);
     o[12] = (long long)S.rng[n];
@@ -760,14 +777,21 @@ __global__ void __launch_bounds__(kBlock)
     S.vy[n] = __longlong_as_double(o[4]); S.vz[n] = __longlong_as_double(o[5]);
     S.t[n] = __longlong_as_double(o[6]); S.w[n] = __longlong_as_double(o[7]);
     S.e[n] = __longlong_as_double(o[8]);
-    S.id[n] = (uint64_t)o[9];
+    const bool absorbed = ((unsigned long long)o[9] >> 63) != 0ull;
+    S.id[n] = (uint64_t)o[9] & ~(1ull << 63);
     S.ip[n] = (int)(unsigned)(o[10] & 0xffffffffll);
     S.jp[n] = (int)(unsigned)((unsigned long long)o[10] >> 32);
     S.kp[n] = (int)(unsigned)(o[11] & 0xffffffffll);
     const int g = (int)(unsigned)((unsigned long long)o[11] >> 32);
-    S.blk[n] = M.local_index[g];
-    S.status[n] = ST_ACTIVE;
+    const int li = M.local_index[g];
+    S.blk[n] = li;
     S.rng[n] = (uint64_t)o[12];
+    if (absorbed) {  // transport.cpp:159-161 on behalf of the rank that tracked the particle
+      atomicAdd(&M.edelta[li][cidx(M, S.kp[n], S.jp[n], S.ip[n])], S.w[n]);
+      S.status[n] = ST_ABSORBED;
+    } else {
+      S.status[n] = ST_ACTIVE;
+    }
   }
 }
 

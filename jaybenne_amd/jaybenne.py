@@ -134,7 +134,7 @@ class MeshData:
     """
 
     def __init__(self, pkg: StateDescriptor, mesh: Mesh, capacity: int, rank: int = 0,
-                 nranks: int = 1, comm=None):
+                 nranks: int = 1, comm=None, halo_rings: int = 1):
         self.pkg = pkg
         self.mesh = mesh
         self.rank, self.nranks = rank, nranks
@@ -145,12 +145,25 @@ class MeshData:
         owner = np.ascontiguousarray(mesh.owner, dtype=np.int32)
         if owner.max() >= nranks:
             raise ValueError("mesh.owner names a rank >= nranks")
-        self.gids = np.nonzero(owner == rank)[0].astype(np.int32)
+        self.gids = np.nonzero(owner == rank)[0].astype(np.int32)       # the blocks this rank owns
         if len(self.gids) == 0:
             raise ValueError(f"rank {rank} owns no blocks")
-        self.nblocks = len(self.gids)
+        self.nowned = len(self.gids)
+        # Halo copies: read-only mirrors of the neighbouring ranks' blocks that touch ours.  A
+        # particle that wanders across the rank boundary keeps being tracked here and is handed
+        # to its owner once, when its history ends, instead of at every crossing (in the
+        # reference every crossing costs a transport iteration with a global sync,
+        # jaybenne.cpp:113-131).  HBM is plentiful: one ring costs a few GB at most.
+        halo = (mesh.neighbours(self.gids, halo_rings) if (nranks > 1 and halo_rings > 0)
+                else np.zeros(0, dtype=np.int32))
+        if pkg.Param("do_feedback") and len(halo):
+            halo = np.zeros(0, dtype=np.int32)   # halo fields would need a per-cycle refresh
+        self.resident_gids = np.concatenate([self.gids, halo]).astype(np.int32)
+        self.owned_flags = np.concatenate([np.ones(self.nowned, dtype=np.int32),
+                                           np.zeros(len(halo), dtype=np.int32)])
+        self.nblocks = len(self.resident_gids)
         local_index = np.full(mesh.nblocks, -1, dtype=np.int32)
-        local_index[self.gids] = np.arange(self.nblocks, dtype=np.int32)
+        local_index[self.resident_gids] = np.arange(self.nblocks, dtype=np.int32)
         self.local_index = local_index
         shape = (self.nblocks,) + tuple(mesh.field_shape[1:])
         names = list(_lib.FIELD_NAMES)
@@ -183,8 +196,8 @@ class MeshData:
     # ---- C views
     def _make_mesh_handle(self, owner: np.ndarray) -> None:
         m = self.mesh
-        g = self.gids
-        keep = dict(
+        g = self.resident_gids
+        keep = dict(owned=self.owned_flags,
             leaf_map=np.ascontiguousarray(m.leaf_map, dtype=np.int32), owner=owner,
             local_index=self.local_index, gid=np.ascontiguousarray(g, dtype=np.int32),
             blk_xmin=np.ascontiguousarray(m.blk_xmin[g]), blk_xmax=np.ascontiguousarray(m.blk_xmax[g]),
@@ -232,13 +245,14 @@ class MeshData:
 
     # ---- host <-> device helpers for the harness
     def set_field(self, name: str, host: np.ndarray, local: bool = False) -> None:
-        """host: [nblocks_total, nk, nj, ni] (whole mesh; this rank's blocks are picked out) or,
-        with ``local=True``, [nblocks_local, nk, nj, ni]."""
-        src = host if local else host[self.gids]
+        """host: [nblocks_total, nk, nj, ni] (whole mesh; the resident blocks are picked out) or,
+        with ``local=True``, [len(resident_gids), nk, nj, ni]."""
+        src = host if local else host[self.resident_gids]
         self.fields[name].copy_(torch.from_numpy(np.ascontiguousarray(src)))
 
     def get_field(self, name: str) -> np.ndarray:
-        return self.fields[name].cpu().numpy()
+        """The owned blocks' part of a field, in the order of ``gids``."""
+        return self.fields[name][:self.nowned].cpu().numpy()
 
     def get_swarm(self) -> Dict[str, np.ndarray]:
         n = self.n
@@ -263,7 +277,7 @@ def UpdateDerivedTransportFields(md: MeshData, dt: float) -> TaskStatus:
 
 def _global_block_counts(md: MeshData, nper_local: np.ndarray) -> np.ndarray:
     counts = np.zeros(md.mesh.nblocks, dtype=np.int64)
-    counts[md.gids] = nper_local
+    counts[md.resident_gids] = nper_local        # halo copies source nothing (zeros)
     if md.comm is not None and md.nranks > 1:
         counts = md.comm.allreduce_sum_int64(counts)
     return counts
@@ -288,7 +302,7 @@ def SourcePhotons(md: MeshData, source_type: SourceType, t_start: float, dt: flo
     md.epoch += 1
     counts = _global_block_counts(md, nper)
     excl = np.concatenate(([0], np.cumsum(counts)[:-1]))
-    id_base = np.ascontiguousarray(md.next_id + excl[md.gids], dtype=np.uint64)
+    id_base = np.ascontiguousarray(md.next_id + excl[md.resident_gids], dtype=np.uint64)
     local_excl = np.concatenate(([0], np.cumsum(nper.astype(np.int64))[:-1]))
     slot_base = np.ascontiguousarray(md.n + local_excl, dtype=np.int64)
     tot = int(nper.sum())
@@ -395,31 +409,45 @@ def InitializeRadiation(md: MeshData, is_thermal: bool) -> None:
 
 
 # ------------------------------------------------------------------------------------------------
-def _exchange(md: MeshData) -> int:
+def _exchange(md: MeshData, first: int, last: int):
     """MeshResetCommunication -> MeshSend -> MeshReceive (reference jaybenne.cpp:26-61) for the
-    particles whose destination block lives on another rank.  Returns the number received."""
+    particles among [first, last) whose destination block lives on another rank.  Returns
+    (number received, number handed over anywhere on the node).
+
+    Per call: one count kernel + read-back, one all-gather of the rank x rank count matrix (which
+    also answers the completion question), and -- only if anything moved -- one pack kernel, one
+    all-to-all-v of 104-byte records and one unpack kernel.  Departed particles stay behind as
+    holes until the swarm is compacted."""
     lib, ctx = md.lib, md.pkg.ctx
-    n_out = md.stats()["n_outgoing"] - md._outgoing_seen
-    md._outgoing_seen += n_out
+    md._sync_stream()
     counts = np.zeros(md.nranks, dtype=np.int64)
-    send = None
-    if n_out > 0:
-        if md.records is None or md.records.shape[0] < n_out:
-            md.records = torch.empty((int(n_out * 1.5) + 1024, _lib.JB_RECORD_WORDS),
-                                     dtype=torch.int64, device=md.device)
-        _lib.check(lib.jb_pack_outgoing(ctx, md.handle, C.byref(md.sv), md.nranks,
-                                        md.records.data_ptr(), md.records.shape[0],
-                                        counts.ctypes.data))
-        send = md.records[:int(counts.sum())]
-        RemoveMarkedParticles(md)     # drops the OUTGOING (and absorbed / escaped) slots
-    recv = md.comm.exchange_records(send, counts, md.device)
+    if md.records is None:
+        md.records = torch.empty((max(4096, (last - first) // 16), _lib.JB_RECORD_WORDS),
+                                 dtype=torch.int64, device=md.device)
+    st = lib.jb_pack_outgoing(ctx, md.handle, C.byref(md.sv), first, last, md.nranks,
+                              md.records.data_ptr(), md.records.shape[0], counts.ctypes.data)
+    if st == _lib.JB_ERR_CAPACITY:      # counts are filled in before the capacity check: grow once
+        md.records = torch.empty((int(counts.sum() * 1.5) + 4096, _lib.JB_RECORD_WORDS),
+                                 dtype=torch.int64, device=md.device)
+        st = lib.jb_pack_outgoing(ctx, md.handle, C.byref(md.sv), first, last, md.nranks,
+                                  md.records.data_ptr(), md.records.shape[0], counts.ctypes.data)
+    _lib.check(st)
+    matrix = md.comm.gather_count_matrix(counts)
+    total = int(matrix.sum())
+    if total == 0:
+        return 0, 0
+    nsend = int(counts.sum())
+    recv = md.comm.exchange_records(md.records[:nsend] if nsend else None, counts, md.device,
+                                    recv_counts=matrix[:, md.rank].copy())
     nrecv = 0 if recv is None else int(recv.shape[0])
     if nrecv:
         if md.n + nrecv > md.capacity:
-            raise MemoryError(f"swarm capacity {md.capacity} too small for {nrecv} arrivals")
+            RemoveMarkedParticles(md)          # close the holes left by earlier departures
+        if md.n + nrecv > md.capacity:
+            raise MemoryError(f"swarm capacity {md.capacity} too small for {md.n} + {nrecv} particles")
         md._sync_stream()
         _lib.check(lib.jb_unpack_incoming(ctx, md.handle, C.byref(md.sv), recv.data_ptr(), nrecv))
-    return nrecv
+    return nrecv, total
 
 
 def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
@@ -441,27 +469,27 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
     md._sync_stream()
     _lib.check(md.lib.jb_zero_energy_tally(pkg.ctx, md.handle))
     before = md.stats()
-    md._outgoing_seen = before["n_outgoing"]
     first = 0
+    md.transport_iterations = 0
     for it in range(int(pkg.Param("max_transport_iterations"))):
-        transport(md, t_start, dt, first, md.n, fuse_census_tally=True)
+        last = md.n
+        transport(md, t_start, dt, first, last, fuse_census_tally=True)
+        md.transport_iterations += 1
         if md.nranks == 1:
             break
-        n_before = md.n
-        nrecv = _exchange(md)
-        first = md.n - nrecv
+        nrecv, moved = _exchange(md, first, last)
+        if moved == 0:
+            break
+        first = md.n - nrecv        # the arrivals, appended at the end of the swarm
         if use_ddmc and nrecv:
             SampleDDMCBlockFace(md, first, md.n)
-        if md.comm.allreduce_sum_int64(np.array([nrecv], dtype=np.int64))[0] == 0:
-            break
     else:
         return TaskStatus.iterate
     after = md.stats()
-    if md.nranks == 1:
-        if after["n_outgoing"] != before["n_outgoing"]:
-            raise RuntimeError("particles left for another rank in a single-rank step")
-        if (after["n_absorbed"] != before["n_absorbed"] or after["n_escaped"] != before["n_escaped"]):
-            RemoveMarkedParticles(md)
+    if md.nranks == 1 and after["n_outgoing"] != before["n_outgoing"]:
+        raise RuntimeError("particles left for another rank in a single-rank step")
+    if any(after[k] != before[k] for k in ("n_absorbed", "n_escaped", "n_outgoing")):
+        RemoveMarkedParticles(md)
     md.events += after["n_events"] - before["n_events"]
     UpdateFluid(md)
     return TaskStatus.complete

@@ -160,7 +160,8 @@ class McblockDriver:
     reference src/mcblock/mcblock_driver.cpp:38-74."""
 
     def __init__(self, pin: ParameterInput, rank: int = 0, nranks: int = 1, comm=None,
-                 device=None, capacity_factor: float = 1.3, mesh: Mesh = None):
+                 device=None, capacity_factor: float = 1.3, mesh: Mesh = None,
+                 halo_rings: int = 1):
         from . import jaybenne as jb
         self.jb = jb
         self.pin = pin
@@ -173,14 +174,14 @@ class McblockDriver:
         n_local_blocks = int((self.mesh.owner == rank).sum())
         share = self.pkg.Param("num_particles") * n_local_blocks / self.mesh.nblocks
         capacity = int(share * capacity_factor) + 4096
-        self.md = jb.MeshData(self.pkg, self.mesh, capacity, rank, nranks, comm)
+        self.md = jb.MeshData(self.pkg, self.mesh, capacity, rank, nranks, comm, halo_rings)
         self.tlim = pin.GetReal("parthenon/time", "tlim")
         self.nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1)
         self.time = 0.0
         self.ncycle = 0
         self.dt = jb.EstimateTimestepMesh(self.md)
         # ProblemGenerator + PostInitialization + initial ghost fill / FillDerived
-        ic = ProblemGenerator(self.mesh, self.mcb, gids=self.md.gids)
+        ic = ProblemGenerator(self.mesh, self.mcb, gids=self.md.resident_gids)
         for name in ("rho", "sie", "u"):
             self.md.set_field(name, ic[name], local=True)
         jb.InitializeRadiation(self.md, self.mcb.initial_radiation == "thermal")

@@ -318,6 +318,38 @@ class Mesh:
                 samples = [samples[q] + samples[q + 1] for q in range(0, len(samples), 2)]
             f[b][ghost] = samples[0] / len(offs)
 
+    # ------------------------------------------------------------------ halo
+    def neighbours(self, gids: Sequence[int], rings: int = 1) -> np.ndarray:
+        """Leaf blocks that touch (face, edge or corner; through periodic boundaries too) any of
+        the blocks `gids`, excluding those blocks; `rings` repeats the growth."""
+        have = set(int(g) for g in gids)
+        frontier = list(have)
+        fine = (self.gmax - self.gmin) / np.asarray(self.nleaf, dtype=np.float64)
+        for _ in range(rings):
+            new = set()
+            for b in frontier:
+                axes = []
+                for d in range(3):
+                    if d >= self.ndim:
+                        axes.append(np.array([0.5 * (self.gmin[d] + self.gmax[d])]))
+                        continue
+                    lo = self.blk_xmin[b, d] - 0.5 * fine[d]
+                    n = int(round((self.blk_xmax[b, d] - self.blk_xmin[b, d]) / fine[d])) + 2
+                    c = lo + fine[d] * np.arange(n)
+                    ext = self.gmax[d] - self.gmin[d]
+                    if self.mesh_bc[2 * d] == BC_PERIODIC:
+                        c = np.where(c < self.gmin[d], c + ext, c)
+                    if self.mesh_bc[2 * d + 1] == BC_PERIODIC:
+                        c = np.where(c > self.gmax[d], c - ext, c)
+                    axes.append(c[(c > self.gmin[d]) & (c < self.gmax[d])])
+                X, Y, Z = np.meshgrid(*axes, indexing="ij")
+                pts = np.column_stack([X.ravel(), Y.ravel(), Z.ravel()])
+                new.update(int(g) for g in np.unique(self.find_block(pts)))
+            new -= have
+            have |= new
+            frontier = list(new)
+        return np.array(sorted(have - set(int(g) for g in gids)), dtype=np.int32)
+
     # ------------------------------------------------------------------ partition
     def partition(self, nranks: int) -> np.ndarray:
         """Contiguous runs of the Z-ordered block list per rank (Parthenon's default load

@@ -45,6 +45,15 @@ def _worker(rank, world, port, out):
         r2 = comm.exchange_records(s2, counts, torch.device("cpu"))
         assert (r2 is None) if rank == 0 else (r2.shape[0] == 2)
         assert comm.exchange_records(None, np.zeros(world, dtype=np.int64), torch.device("cpu")) is None
+        # 2b. the count matrix (one all-gather answers "how much do I receive" and "did anything
+        # move anywhere")
+        mine = np.zeros(world, dtype=np.int64)
+        mine[1 - rank] = 5 + rank
+        mat = comm.gather_count_matrix(mine)
+        assert mat.tolist() == [[0, 5], [6, 0]]
+        s3 = torch.zeros((5 + rank, RECORD_WORDS), dtype=torch.int64)
+        r3 = comm.exchange_records(s3, mine, torch.device("cpu"), recv_counts=mat[:, rank].copy())
+        assert r3.shape[0] == (6 if rank == 0 else 5)
         # 3. completion test: sum of arrivals
         tot = comm.allreduce_sum_int64(np.array([0 if rank == 0 else 2], dtype=np.int64))
         assert tot[0] == 2

@@ -325,3 +325,113 @@ def test_separate_tasks_match_fused_step(gpu_device):
     ga, gb = a.md.get_swarm(), b.md.get_swarm()
     for k in ga:
         assert np.array_equal(ga[k], gb[k]), k
+
+
+# ------------------------------------------------------------------------------------------------
+def test_ddmc_face_probabilities_match_oracle(gpu_device):
+    """UpdateDerivedTransportFields, DDMC part (jaybenne.cpp:319-489) on a 2-level mesh: interior
+    faces, block faces against coarser / finer / periodic neighbours, physical boundary."""
+    from jaybenne_amd import jaybenne as jb
+    from oracle import orc
+    for deck, ov in (("stepdiff_smr_hybrid", {"jaybenne/num_particles": 1000}),
+                     ("stepdiff_ddmc", {"parthenon/mesh/nx2": 8, "parthenon/mesh/nx3": 8,
+                                        "parthenon/mesh/nx1": 32, "parthenon/meshblock/nx1": 16,
+                                        "parthenon/meshblock/nx2": 4, "parthenon/meshblock/nx3": 4,
+                                        "jaybenne/num_particles": 1000})):
+        drv = _gpu_problem(load_deck(deck, ov), gpu_device)
+        O, mesh, _ = make_oracle(load_deck(deck, ov), orc.MATH_PORTABLE)
+        jb.UpdateDerivedTransportFields(drv.md, drv.dt)
+        O.UpdateDerivedTransportFields(drv.dt)
+        m = mesh
+        for d, name in enumerate(("P1", "P2", "P3")[:m.ndim]):
+            sl = [slice(None)] + [slice(m.is_[dd], m.is_[dd] + m.nx[dd] + (1 if dd == d else 0))
+                                  for dd in (2, 1, 0)]
+            a = drv.md.get_field(name)[tuple(sl)]
+            b = O.fields[name][tuple(sl)]
+            assert np.array_equal(a, b), (deck, name)
+            assert a.min() > 0
+        assert np.array_equal(drv.md.get_field("fleck")[m.interior()], O.fields["fleck"][m.interior()])
+
+
+def test_photon_reflect_bc_task(gpu_device):
+    """PhotonReflectBC<BFACE> as a stand-alone task (boundaries.hpp:24-84) for all six faces."""
+    import torch
+    from jaybenne_amd import jaybenne as jb
+    from oracle import orc
+    ov = {"parthenon/mesh/nx2": 8, "parthenon/mesh/nx3": 8, "parthenon/mesh/nx1": 16,
+          "parthenon/meshblock/nx1": 8, "parthenon/meshblock/nx2": 4, "parthenon/meshblock/nx3": 4,
+          "jaybenne/num_particles": 3000}
+    drv = _gpu_problem(load_deck("stepdiff", ov), gpu_device)
+    O, mesh, _ = make_oracle(load_deck("stepdiff", ov), orc.MATH_PORTABLE)
+    n = drv.md.n
+    rng = np.random.default_rng(3)
+    shift = rng.uniform(-0.7, 0.7, size=(3, n))       # push a good fraction beyond every face
+    for q, k in enumerate(("x", "y", "z")):
+        new = O.sw[k][:n] + shift[q]
+        O.sw[k][:n] = new
+        drv.md.swarm[k][:n] = torch.from_numpy(new).to(gpu_device)
+    for face in range(6):
+        jb.PhotonReflectBC(drv.md, face)
+        O.PhotonReflectBC(face)
+    g = drv.md.get_swarm()
+    for k in ("x", "y", "z", "vx", "vy", "vz", "ip", "jp", "kp"):
+        assert np.array_equal(g[k], O.sw[k][:n]), k
+    assert (g["vx"] != O.sw["vx"][:n] * 0 + g["vx"]).sum() == 0
+
+
+def test_c_level_radiation_step(gpu_device):
+    """jb_radiation_step (the whole task list behind one C call) equals the task-by-task mirror."""
+    import ctypes as C
+    from jaybenne_amd import _lib
+    ov = {"jaybenne/num_particles": 6000, "jaybenne/do_emission": "true",
+          "mcblock/opacity_model": "constant", "mcblock/opacity_constant_value": 30.0,
+          "mcblock/initial_temperature": 1.0e6, "parthenon/mesh/nx1": 16, "parthenon/meshblock/nx1": 8}
+    a = _gpu_problem(load_deck("stepdiff", ov), gpu_device)
+    b = _gpu_problem(load_deck("stepdiff", ov), gpu_device)
+    a.Step()
+    md = b.md
+    md._sync_stream()
+    next_id, epoch = C.c_uint64(md.next_id), C.c_uint32(md.epoch)
+    _lib.check(md.lib.jb_radiation_step(md.pkg.ctx, md.handle, C.byref(md.sv), 0.0, b.dt,
+                                        C.byref(next_id), C.byref(epoch), md.prefix.data_ptr()))
+    assert next_id.value == a.md.next_id and epoch.value == a.md.epoch
+    ga, gb = a.md.get_swarm(), md.get_swarm()
+    oa, ob = np.argsort(ga["id"]), np.argsort(gb["id"])
+    assert a.md.n == md.n
+    for k in ga:
+        assert np.array_equal(ga[k][oa], gb[k][ob]), k
+    sl = a.mesh.interior()
+    for k in ("tally", "edelta", "u", "fleck"):
+        np.testing.assert_allclose(a.md.get_field(k)[sl], md.get_field(k)[sl], rtol=1e-12)
+
+
+def test_c_abi_error_paths(gpu_device):
+    import ctypes as C
+    from jaybenne_amd import _lib, jaybenne as jb
+    drv = _gpu_problem(load_deck("stepdiff", {"jaybenne/num_particles": 1000}), gpu_device)
+    md, lib = drv.md, drv.md.lib
+    # particle range outside the swarm
+    st = lib.jb_transport_photons(md.pkg.ctx, md.handle, C.byref(md.sv), 0.0, 1e-11, 0, md.n + 5, 0)
+    assert st == _lib.JB_ERR_INVALID and b"outside the swarm" in lib.jb_last_error()
+    # DDMC task without face-probability arrays
+    st = lib.jb_transport_photons_ddmc(md.pkg.ctx, md.handle, C.byref(md.sv), 0.0, 1e-11, 0, md.n, 0)
+    assert st == _lib.JB_ERR_INVALID
+    # capacity: arrivals that do not fit
+    rec = np.zeros((md.capacity, _lib.JB_RECORD_WORDS), dtype=np.int64)
+    import torch
+    t = torch.from_numpy(rec).to(gpu_device)
+    st = lib.jb_unpack_incoming(md.pkg.ctx, md.handle, C.byref(md.sv), t.data_ptr(), md.capacity)
+    assert st == _lib.JB_ERR_CAPACITY
+    with pytest.raises(_lib.JaybenneError):
+        _lib.check(st)
+    # bad face
+    assert lib.jb_photon_reflect_bc(md.pkg.ctx, md.handle, C.byref(md.sv), 7) == _lib.JB_ERR_INVALID
+    # unsupported opacity model is rejected at Initialize
+    p, e = _lib.Params(num_particles=10, dt=1.0), _lib.Eos(model=0, gm1=0.6, cv=1.5)
+    o, s = _lib.Opacity(model=1, kappa=0.0, c=3e10, sb=5.67e-5), _lib.Scattering(model=0, kappa_s=1.0, apm=1.0)
+    ctx = C.c_void_p()
+    assert lib.jb_initialize(C.byref(p), C.byref(e), C.byref(o), C.byref(s), 0, C.byref(ctx)) == _lib.JB_ERR_UNSUPPORTED
+    # the energy source strategy is accepted by Initialize and rejected by SourcePhotons (sourcing.cpp:38)
+    pin = load_deck("stepdiff", {"jaybenne/source_strategy": "energy", "jaybenne/num_particles": 100})
+    with pytest.raises(NotImplementedError, match="Energy source strategy"):
+        _gpu_problem(pin, gpu_device)

@@ -192,3 +192,30 @@ def test_package_initialize_parameter_checks_need_no_gpu():
         pin = load_deck("stepdiff")
         del pin.blocks["jaybenne"]["num_particles"]
         jb.Initialize(pin, mcb.opacity, mcb.scattering, mcb.eos)
+
+
+def test_halo_ring_of_a_partition():
+    m = Mesh.from_deck(load_deck("stepdiff_smr"))
+    owner = m.partition(2)
+    mine = np.nonzero(owner == 0)[0]
+    ring = m.neighbours(mine)
+    assert len(ring) and not set(ring) & set(mine)
+    # every ring block touches an owned block (bounding boxes overlap after periodic wrap in y)
+    ext = m.gmax - m.gmin
+    for g in ring:
+        touches = False
+        for b in mine:
+            ok = True
+            for d in range(m.ndim):
+                shifts = (0.0,) if m.mesh_bc[2 * d] != BC_PERIODIC else (-ext[d], 0.0, ext[d])
+                ok &= any(m.blk_xmin[g, d] + s <= m.blk_xmax[b, d] + 1e-12 and
+                          m.blk_xmax[g, d] + s >= m.blk_xmin[b, d] - 1e-12 for s in shifts)
+            touches |= ok
+        assert touches, g
+    # 1-D, two blocks, reflecting ends: each block's ring is the other block
+    m1 = Mesh.from_deck(load_deck("stepdiff"))
+    assert m1.neighbours([0]).tolist() == [1] and m1.neighbours([1]).tolist() == [0]
+    # two rings reach further than one
+    m3 = Mesh(3, [64, 64, 64], [8, 8, 8], [-0.5] * 3, [0.5] * 3)
+    own = np.nonzero(m3.partition(8) == 0)[0]
+    assert len(m3.neighbours(own, 2)) > len(m3.neighbours(own, 1)) > 0
