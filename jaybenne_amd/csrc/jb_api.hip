@@ -774,6 +774,7 @@ __global__ void k_dbg_seed(uint32_t seed, uint32_t domain, unsigned long long id
   *out = rng_seed_state(seed, domain, id);
 }
 __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
+  load_math_tables();
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     double s, c;
     switch (which) {
@@ -787,6 +788,7 @@ __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
   }
 }
 __global__ void k_dbg_step(int which, jb_debug_step *d, const double *tape, int ntape, int *ndraws) {
+  load_math_tables();
   TapeRng rng(tape, ntape);
   Step s;
   s.t_start = d->t_start; s.dt = d->dt; s.ff = d->ff; s.aa = d->aa; s.ss = d->ss; s.vv = d->vv;
@@ -815,6 +817,7 @@ __global__ void k_dbg_step(int which, jb_debug_step *d, const double *tape, int 
 }
 __global__ void k_dbg_sample(int which, const double *a, const int *iv, const double *tape, int ntape,
                              double *out, int *iout, int *ndraws) {
+  load_math_tables();
   TapeRng rng(tape, ntape);
   if (which == 0) {
     scatter(rng, a[0], out[0], out[1], out[2]);

@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(kBlock)
     k_source_fill(DevMesh M, DevParams P, DevSwarm S, int source_type, double t_start, double dt,
                   const int *prefix, const long long *blk_first, const long long *slot_base,
                   const unsigned long long *id_base, long long total) {
+  load_math_tables();
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
        g += (long long)gridDim.x * blockDim.x) {
     int lo = 0, hi = M.nblocks - 1;  // last b with blk_first[b] <= g
@@ -326,6 +327,7 @@ template <int NDIM, bool DDMC, bool TALLY, bool GRAY>
 __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
     k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
                 long long last, unsigned long long *counters) {
+  load_math_tables();
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   constexpr bool kFastGray = GRAY && !DDMC;
   constexpr bool kPackedDdmc = GRAY && DDMC;
@@ -576,6 +578,7 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
 template <int NDIM>
 __global__ void __launch_bounds__(kBlock)
     k_block_face(DevMesh M, DevParams P, DevSwarm S, long long first, long long last) {
+  load_math_tables();
   for (long long n = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; n < last;
        n += (long long)gridDim.x * blockDim.x) {
     if (S.status[n] != ST_ACTIVE) continue;

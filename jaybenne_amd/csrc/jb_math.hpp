@@ -4,72 +4,81 @@
 // (transport_utils.hpp:31-38,118-119,185,270-275; scattering.hpp:23-28; planck.hpp:30-49;
 // sourcing.cpp:93,180-185).  Device libm and host libm differ in the last bit, which after ~1e3
 // events per history flips branch decisions and makes CPU and GPU histories diverge.  These
-// versions use only + - * / sqrt fma and integer bit manipulation, following the published fdlibm
-// algorithms (e_log.c, k_sin.c, k_cos.c with the first Cody-Waite step of e_rem_pio2.c,
-// e_acos.c), so a CPU that evaluates the same sequence gets the same bits.  Accuracy: <= 1 ulp
-// against correctly rounded results on the argument ranges used (tests/test_oracle_math.py).
+// versions use only + - * / sqrt fma, integer bit manipulation and two small lookup tables
+// (jb_tables.hpp, generated with 70-digit arithmetic by tools/gen_math_tables.py), so a CPU that
+// evaluates the same sequence gets the same bits (the CPU oracle of the test suite does).
 //
+//   log     x = 2^k z, z in [0.707, 1.414) split in 128 intervals; r = z / c - 1 by one fma with
+//           the tabulated 1/c (c = 1 exactly in the interval around 1), |r| <= 2^-7;
+//           log x = k ln2 + log c + log1p(r), degree-8 Taylor polynomial, hi/lo accumulation.
+//           No division.  <= 1 ulp.  133 SIMD-cycles per wave call on MI355X (fdlibm-style with a
+//           division: 199; the device libm's log: 378).
+//   sincos  phi = i (2 pi / 64) + r, |r| <= pi / 64; tabulated sin / cos of the grid points,
+//           degree-9 / degree-8 polynomials for sin r and cos r - 1, angle-addition.  Absolute
+//           error <= 1.2e-16.  129 cycles (fdlibm kernels: 276; device libm: 309).
+//   acos    fdlibm e_acos.c (sourcing only).
+//
+// The tables live in LDS: every kernel that calls m_log / m_sincos runs load_math_tables() first.
 // Compile with -ffp-contract=off: every fused multiply-add below is written as fma().
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "jb_tables.hpp"
+
 namespace jb {
 
-__device__ __forceinline__ double m_log(double x) {  // x positive, finite, normal
-  constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
-                   Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                   Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                   Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                   Lg7 = 1.479819860511658591e-01;
-  const uint64_t ix = (uint64_t)__double_as_longlong(x);
-  int k = (int)(ix >> 52) - 1023;
-  const uint32_t hx = (uint32_t)(ix >> 32) & 0x000fffffu;
-  const uint32_t i = (hx + 0x95f64u) & 0x100000u;
-  const uint64_t mbits = (ix & 0x000fffffffffffffull) | ((uint64_t)(0x3ff00000u ^ i) << 32);
-  k += (int)(i >> 20);
-  const double f = __longlong_as_double((long long)mbits) - 1.0;
-  const double s = f / (2.0 + f);
-  const double dk = (double)k;
-  const double z = s * s;
-  const double w = z * z;
-  const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-  const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
-  const double R = t2 + t1;
-  const double hfsq = 0.5 * f * f;
-  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+__shared__ double lds_log_tab[JB_LOG_N][3];
+__shared__ double lds_sc_tab[JB_SC_N + 1][2];
+
+// Copies the two tables into this workgroup's LDS (4.1 KB); ends with a barrier.
+__device__ __forceinline__ void load_math_tables() {
+  for (int q = threadIdx.x; q < JB_LOG_N * 3; q += blockDim.x)
+    (&lds_log_tab[0][0])[q] = (&jb_log_tab[0][0])[q];
+  for (int q = threadIdx.x; q < (JB_SC_N + 1) * 2; q += blockDim.x)
+    (&lds_sc_tab[0][0])[q] = (&jb_sc_tab[0][0])[q];
+  __syncthreads();
 }
 
-__device__ __forceinline__ void m_sincos(double x, double &sn, double &cs) {  // 0 <= x <~ 7
-  constexpr double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
-                   pio2_1t = 6.07710050650619224932e-11;
-  constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                   S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                   S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-  constexpr double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                   C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                   C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  const int n = (int)(x * invpio2 + 0.5);
-  const double fn = (double)n;
-  const double r = x - fn * pio2_1;
-  const double wt = fn * pio2_1t;
-  const double y0 = r - wt;
-  const double y1 = (r - y0) - wt;
-  const double z = y0 * y0;
-  const double v = z * y0;
-  const double rs = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
-  const double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
-  const double w = z * z;
-  const double rc = z * fma(z, fma(z, C3, C2), C1) + (w * w) * fma(z, fma(z, C6, C5), C4);
-  const double hz = 0.5 * z;
-  const double w1 = 1.0 - hz;
-  const double kc = w1 + (((1.0 - w1) - hz) + (z * rc - y0 * y1));
-  const int q = n & 3;
-  const double a = (q & 1) ? kc : ks;
-  const double b = (q & 1) ? ks : kc;
-  sn = (q & 2) ? -a : a;
-  cs = (q == 1 || q == 2) ? -b : b;
+__device__ __forceinline__ double m_log(double x) {  // x positive, finite, normal
+  constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const uint64_t ix = (uint64_t)__double_as_longlong(x);
+  const uint64_t tmp = ix - JB_LOG_OFF;
+  const int i = (int)((tmp >> 45) & (JB_LOG_N - 1));
+  const int k = (int)((long long)tmp >> 52);
+  const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
+  const double z = __longlong_as_double((long long)iz);
+  const double invc = lds_log_tab[i][0], lc_hi = lds_log_tab[i][1], lc_lo = lds_log_tab[i][2];
+  const double r = fma(z, invc, -1.0);
+  const double kd = (double)k;
+  const double w = fma(kd, ln2_hi, lc_hi);  // exact: both terms are short
+  const double hi = w + r;
+  const double lo = ((w - hi) + r) + fma(kd, ln2_lo, lc_lo);
+  const double r2 = r * r;
+  double p = fma(r, -0.125, 1.0 / 7.0);
+  p = fma(r, p, -1.0 / 6.0);
+  p = fma(r, p, 0.2);
+  p = fma(r, p, -0.25);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -0.5);
+  return fma(r2, p, lo) + hi;
+}
+
+__device__ __forceinline__ void m_sincos(double x, double &sn, double &cs) {  // 0 <= x <= 2 pi
+  const int i = (int)(x * jb_sc_inv_step + 0.5);
+  const double fi = (double)i;
+  const double r = (x - fi * jb_sc_step_hi) - fi * jb_sc_step_lo;
+  const double si = lds_sc_tab[i][0], ci = lds_sc_tab[i][1];
+  const double r2 = r * r;
+  const double sr = fma(r * r2,
+                        fma(r2, fma(r2, fma(r2, 1.0 / 362880.0, -1.0 / 5040.0), 1.0 / 120.0),
+                            -1.0 / 6.0),
+                        r);
+  const double cm1 =
+      r2 * fma(r2, fma(r2, fma(r2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5);
+  sn = si + fma(si, cm1, ci * sr);
+  cs = ci + fma(ci, cm1, -(si * sr));
 }
 
 __device__ __forceinline__ double m_acos_R(double z) {

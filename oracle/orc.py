@@ -64,7 +64,7 @@ class Step(C.Structure):
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("orc.c", "orc.h", "orc_steps.h", "orc_math.h",
-                                             "orc_rng.h", "Makefile")]
+                                             "orc_rng.h", "orc_tables.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH) or
              any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs))
     if force or stale:

@@ -6,13 +6,13 @@
  *                      std::acos / std::pow from the host libm (what the reference CPU build
  *                      calls at transport_utils.hpp:31-38,118-119,185,270-275,
  *                      scattering.hpp:23-28, planck.hpp:30-49, sourcing.cpp:93,180-185).
- *   ORC_MATH_PORTABLE  a fully specified IEEE-754 sequence (only +,-,*,/,sqrt,fma and integer
- *                      bit manipulation) following the published fdlibm algorithms
- *                      (e_log.c, k_sin.c, k_cos.c, e_rem_pio2.c first reduction step,
- *                      e_acos.c; Sun Microsystems 1993).  The HIP device code implements the
- *                      same specification, which makes CPU-oracle and GPU results
- *                      BIT-IDENTICAL event for event.  tests/test_oracle_math.py bounds the
- *                      difference between the two flavours at <= 2 ulp per call.
+ *   ORC_MATH_PORTABLE  a fully specified IEEE-754 sequence (only +,-,*,/,sqrt,fma, integer bit
+ *                      manipulation and two generated lookup tables, orc_tables.h): table-driven
+ *                      log and sincos, fdlibm's e_acos.c (Sun Microsystems 1993).  The HIP
+ *                      device code implements the same specification, which makes CPU-oracle
+ *                      and GPU results BIT-IDENTICAL event for event.  tests/test_oracle_math.py
+ *                      bounds the difference between the two flavours (log, acos <= 1 ulp;
+ *                      sin, cos <= 2.5e-16 absolute).
  *
  * All other arithmetic (+,-,*,/,sqrt) is IEEE correctly rounded on both sides; the oracle is
  * compiled with -ffp-contract=off so no multiply-add is fused unless written as fma().
@@ -24,6 +24,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "orc_tables.h"
+
 #define ORC_MATH_LIBM 0
 #define ORC_MATH_PORTABLE 1
 
@@ -32,65 +34,45 @@ extern int orc_math_mode; /* defined in orc.c */
 static inline uint64_t orc_d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 static inline double orc_u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
 
-/* ---- portable log: x positive, finite, normal ------------------------------------------ */
+/* ---- portable log: x positive, finite, normal (table-driven, no division; see the description
+ * in jaybenne_amd/csrc/jb_math.hpp -- this is the same sequence, written independently) ------- */
 static inline double orc_pm_log(double x) {
-  static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
-                      Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                      Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                      Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                      Lg7 = 1.479819860511658591e-01;
+  static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const uint64_t ix = orc_d2u(x);
-  int k = (int)(ix >> 52) - 1023;
-  const uint32_t hx = (uint32_t)(ix >> 32) & 0x000fffffu;
-  const uint32_t i = (hx + 0x95f64u) & 0x100000u;
-  /* mantissa scaled into [sqrt(2)/2, sqrt(2)) */
-  const uint64_t mbits = (ix & 0x000fffffffffffffull) | ((uint64_t)(0x3ff00000u ^ i) << 32);
-  k += (int)(i >> 20);
-  const double f = orc_u2d(mbits) - 1.0;
-  const double s = f / (2.0 + f);
-  const double dk = (double)k;
-  const double z = s * s;
-  const double w = z * z;
-  const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-  const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
-  const double R = t2 + t1;
-  const double hfsq = 0.5 * f * f;
-  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  const uint64_t tmp = ix - JB_LOG_OFF;
+  const int i = (int)((tmp >> 45) & (JB_LOG_N - 1));
+  const int k = (int)((int64_t)tmp >> 52);
+  const double z = orc_u2d(ix - (tmp & 0xfff0000000000000ull));
+  const double r = fma(z, jb_log_tab[i][0], -1.0);
+  const double kd = (double)k;
+  const double w = fma(kd, ln2_hi, jb_log_tab[i][1]);
+  const double hi = w + r;
+  const double lo = ((w - hi) + r) + fma(kd, ln2_lo, jb_log_tab[i][2]);
+  const double r2 = r * r;
+  double p = fma(r, -0.125, 1.0 / 7.0);
+  p = fma(r, p, -1.0 / 6.0);
+  p = fma(r, p, 0.2);
+  p = fma(r, p, -0.25);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -0.5);
+  return fma(r2, p, lo) + hi;
 }
 
-/* ---- portable sincos: 0 <= x <= ~7 (first Cody-Waite step only) ------------------------ */
+/* ---- portable sincos: 0 <= x <= 2 pi (64-point table + short polynomials) ----------------- */
 static inline void orc_pm_sincos(double x, double *sn, double *cs) {
-  static const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
-                      pio2_1t = 6.07710050650619224932e-11;
-  static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                      S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                      S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-  static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                      C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                      C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  const int n = (int)(x * invpio2 + 0.5);
-  const double fn = (double)n;
-  const double r = x - fn * pio2_1;
-  const double wt = fn * pio2_1t;
-  const double y0 = r - wt;
-  const double y1 = (r - y0) - wt;
-  const double z = y0 * y0;
-  /* sin kernel */
-  const double v = z * y0;
-  const double rs = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
-  const double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
-  /* cos kernel */
-  const double w = z * z;
-  const double rc = z * fma(z, fma(z, C3, C2), C1) + (w * w) * fma(z, fma(z, C6, C5), C4);
-  const double hz = 0.5 * z;
-  const double w1 = 1.0 - hz;
-  const double kc = w1 + (((1.0 - w1) - hz) + (z * rc - y0 * y1));
-  switch (n & 3) {
-  case 0: *sn = ks; *cs = kc; break;
-  case 1: *sn = kc; *cs = -ks; break;
-  case 2: *sn = -ks; *cs = -kc; break;
-  default: *sn = -kc; *cs = ks; break;
-  }
+  const int i = (int)(x * jb_sc_inv_step + 0.5);
+  const double fi = (double)i;
+  const double r = (x - fi * jb_sc_step_hi) - fi * jb_sc_step_lo;
+  const double si = jb_sc_tab[i][0], ci = jb_sc_tab[i][1];
+  const double r2 = r * r;
+  const double sr = fma(r * r2,
+                        fma(r2, fma(r2, fma(r2, 1.0 / 362880.0, -1.0 / 5040.0), 1.0 / 120.0),
+                            -1.0 / 6.0),
+                        r);
+  const double cm1 =
+      r2 * fma(r2, fma(r2, fma(r2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5);
+  *sn = si + fma(si, cm1, ci * sr);
+  *cs = ci + fma(ci, cm1, -(si * sr));
 }
 
 /* ---- portable acos: |x| <= 1 ------------------------------------------------------------ */

@@ -80,6 +80,7 @@ __global__ void k_xorwow(double *out) {  // rocRAND default generator's recurren
   out[blockIdx.x * blockDim.x + threadIdx.x] = a;
 }
 __global__ void k_log(double *out) {
+  load_math_tables();
   double a = seed_val(1);
   for (int i = 0; i < ITER; ++i) a = 0.5 + 0.4 * (m_log(a) * -0.3);  // stays in (0,1)
   out[blockIdx.x * blockDim.x + threadIdx.x] = a;
@@ -105,6 +106,7 @@ __global__ void k_sqrt(double *out) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = a;
 }
 __global__ void k_sincos(double *out) {
+  load_math_tables();
   double a = seed_val(5);
   for (int i = 0; i < ITER; ++i) {
     double s, c;
@@ -165,7 +167,7 @@ int run(const char *name, K kernel, double *out, double calls_per_iter, double b
 
 int main() {
   double *out;
-  CHECK(hipMalloc(&out, sizeof(double) * 256 * 8 * 256));
+  CHECK(hipMalloc(&out, sizeof(double) * 2 * 256 * 8 * 256));
   run("loop+fma", k_empty, out, 1);
   run("fma x16", k_fma, out, 16);
   run("philox block", k_philox, out, 1);
