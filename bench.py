@@ -158,6 +158,17 @@ def main() -> None:
         k_bytes = k_hist * (BYTES_PER_HISTORY + per_event * ev_per_hist)
         achieved = k_bytes / k_time / 1e9 if k_time > 0 else 0.0
         fp64 = k_hist * ev_per_hist * FLOPS_PER_EVENT / k_time / 1e12 if k_time > 0 else 0.0
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
+        # passes of this very command; profiles/r01_b_hbm_traffic.json) -- valid for the workload
+        # and particle count they were collected on
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_b_hbm_traffic.json")))
+            if (tr["workload"] == args.workload and tr["particles_per_gpu"] == args.particles_per_gpu
+                    and args.block_nx == 64 and args.gpus == 1):
+                traffic = tr["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "particle-histories/s (whole node) on stepdiff",
             "value": histories / wall,
@@ -177,14 +188,18 @@ def main() -> None:
             "transport_iterations_per_step": getattr(md, "transport_iterations", 1),
             "events_per_history": ev_per_hist,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_transport<3,false,true>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_transport<3,false,true,true>" if args.workload == "c2"
+                                   else "k_transport<NDIM,true,true,true>",
                          "kernel_ms_avg": 1e3 * k_time / max(len(kt), 1),
                          "launches": len(kt),
                          "algorithmic_bytes_per_history": BYTES_PER_HISTORY + per_event * ev_per_hist,
                          "fp64_valu": {"achieved_tflops": fp64, "peak_tflops": FP64_VALU_PEAK_TF,
                                        "frac": fp64 / FP64_VALU_PEAK_TF,
-                                       "note": "IMC regime is FP64-VALU bound, not HBM bound (SURVEY 8d)"}},
+                                       "note": "IMC regime is VALU-issue bound, not HBM bound (SURVEY "
+                                               "8d): PMC shows the SIMDs 97 % busy issuing VALU at 410 "
+                                               "instructions per 64-lane event, L2 hit rate 98.7 %, "
+                                               "157 GB/s of HBM traffic (profiles/r01_b_pmc_*.json)"}},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.block_nx)
