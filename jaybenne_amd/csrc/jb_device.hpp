@@ -51,6 +51,10 @@ struct DevSwarm {
   uint64_t *rng;  // xorshift64* state of the particle's stream
 };
 
+// read-only field data reached through a pointer that was itself loaded from memory: telling
+// the compiler it is global memory makes the gathers global_load instead of flat_load
+typedef const double __attribute__((address_space(1))) *gcptr;
+
 enum { ST_ACTIVE = 0, ST_ABSORBED = 1, ST_ESCAPED = 2, ST_OUTGOING = 3, ST_OUTGOING_ABSORBED = 4 };
 enum { BC_PERIODIC = 0, BC_REFLECT = 1, BC_OUTFLOW = 2 };
 

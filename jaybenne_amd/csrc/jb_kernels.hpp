@@ -351,21 +351,21 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
   int b = 0, ip = 0, jp = 0, kp = 0, status = ST_ACTIVE;
   double t = 0, x = 0, y = 0, z = 0, vx = 0, vy = 0, vz = 0, ee = 0;
   Blk B;
-  const double *f0 = nullptr, *f1 = nullptr, *f2 = nullptr;  // this block's cell arrays
+  gcptr f0 = nullptr, f1 = nullptr, f2 = nullptr;  // this block's cell arrays
 
   auto bind_block = [&](int blk) {
     load_block(M, blk, B);
     if constexpr (kFastGray) {
-      f0 = M.lam_abs[blk];
-      f1 = M.lam_sc[blk];
+      f0 = (gcptr)M.lam_abs[blk];
+      f1 = (gcptr)M.lam_sc[blk];
     } else if constexpr (kPackedDdmc) {
-      f0 = M.ddmc_cell[blk];
-      f1 = M.lam_abs[blk];
-      f2 = M.lam_sc[blk];
+      f0 = (gcptr)M.ddmc_cell[blk];
+      f1 = (gcptr)M.lam_abs[blk];
+      f2 = (gcptr)M.lam_sc[blk];
     } else {
-      f0 = M.rho[blk];
-      f1 = M.sie[blk];
-      f2 = M.fleck[blk];
+      f0 = (gcptr)M.rho[blk];
+      f1 = (gcptr)M.sie[blk];
+      f2 = (gcptr)M.fleck[blk];
     }
   };
   auto cell_faces = [&](Step &s) {  // transport.cpp:114-119
@@ -500,12 +500,14 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
           // no division (same values: same operations on the same operands)
           imc_step_core<NDIM>(s, f0[q], f1[q], rng);
         } else if constexpr (kPackedDdmc) {
-          const double4 *rec = reinterpret_cast<const double4 *>(f0 + 8 * q);
-          const double4 r0 = rec[0];
+          typedef double v4d __attribute__((ext_vector_type(4)));
+          typedef const v4d __attribute__((address_space(1))) *grec;
+          const grec rec = (grec)(f0 + 8 * q);
+          const v4d r0 = rec[0];
           s.ffaa = r0.x; s.sig = r0.y;
           is_ddmc_step = B.dx_push * s.sig > P.tau_ddmc;  // transport_ddmc.cpp:135
           if (is_ddmc_step) {
-            const double4 r1 = rec[1];
+            const v4d r1 = rec[1];
             s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
             ptcl_ddmc_albedo<NDIM>(s, rng);
             if (!s.is_rejected) resample = ddmc_step_event<NDIM>(s, rng);

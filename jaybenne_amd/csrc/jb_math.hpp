@@ -41,12 +41,29 @@ __device__ __forceinline__ void load_math_tables() {
   __syncthreads();
 }
 
+// Correctly rounded sqrt for 2^-700 < x < 2^700 (here: 1 - mu^2 and xi, both in (0, 1]): the
+// refinement the compiler emits for sqrt(double) (v_rsq_f64 seed, Goldschmidt step, two fused
+// residual corrections), without its scaling of tiny / huge inputs and its 0 / inf special cases.
+// Bit-identical to IEEE sqrt on that range (tests/test_gpu_parity.py::test_device_math_bit_exact).
+__device__ __forceinline__ double m_sqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d0 = fma(-g, g, x);
+  g = fma(d0, h, g);
+  const double d1 = fma(-g, g, x);
+  return fma(d1, h, g);
+}
+
 __device__ __forceinline__ double m_log(double x) {  // x positive, finite, normal
   constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const uint64_t ix = (uint64_t)__double_as_longlong(x);
   const uint64_t tmp = ix - JB_LOG_OFF;
   const int i = (int)((tmp >> 45) & (JB_LOG_N - 1));
-  const int k = (int)((long long)tmp >> 52);
+  const int k = (int)(uint32_t)(tmp >> 32) >> 20;  // = (int64)tmp >> 52, from the high word
   const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
   const double z = __longlong_as_double((long long)iz);
   const double invc = lds_log_tab[i][0], lc_hi = lds_log_tab[i][1], lc_lo = lds_log_tab[i][2];

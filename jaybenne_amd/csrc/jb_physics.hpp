@@ -34,8 +34,8 @@ __device__ __forceinline__ bool fuzzy_equal(double a, double b, double c, double
 template <class Rng>
 __device__ __forceinline__ void sample_face_iso_dir(double vv, Rng &rng, double &v1, double &v2,
                                                     double &v3) {
-  const double mu = sqrt(rng.drand());
-  const double nu = sqrt(1.0 - mu * mu);
+  const double mu = m_sqrt(rng.drand());
+  const double nu = sqrt(1.0 - mu * mu);  // may be exactly 0 (mu rounds to 1): general sqrt
   const double phi = kTwoPi * rng.drand();
   double sn, cs;
   m_sincos(phi, sn, cs);
@@ -49,7 +49,7 @@ template <class Rng>
 __device__ __forceinline__ void scatter(Rng &rng, double vv, double &vx, double &vy, double &vz) {
   const double mu = 2.0 * rng.drand() - 1.0;
   const double phi = kTwoPi * rng.drand();
-  const double st = sqrt(1.0 - mu * mu);
+  const double st = m_sqrt(1.0 - mu * mu);  // |mu| <= 1 - 2^-52, so 1 - mu^2 >= 2^-52
   double sn, cs;
   m_sincos(phi, sn, cs);
   vx = vv * st * cs;

@@ -401,8 +401,9 @@ def test_c_level_radiation_step(gpu_device):
     for k in ga:
         assert np.array_equal(ga[k][oa], gb[k][ob]), k
     sl = a.mesh.interior()
-    for k in ("tally", "edelta", "u", "fleck"):
-        np.testing.assert_allclose(a.md.get_field(k)[sl], md.get_field(k)[sl], rtol=1e-12)
+    for k in ("tally", "edelta", "u", "fleck"):   # atomic accumulation order differs run to run
+        fa, fb = a.md.get_field(k)[sl], md.get_field(k)[sl]
+        np.testing.assert_allclose(fa, fb, rtol=1e-12, atol=1e-12 * np.abs(fa).max(), err_msg=k)
 
 
 def test_c_abi_error_paths(gpu_device):
