@@ -182,7 +182,7 @@ def main() -> None:
                                    f"{md.mesh.nblocks} meshblocks of {args.block_nx}^3 cells, "
                                    f"{args.particles_per_gpu * args.gpus:.3g} particles, 1 cycle per step "
                                    "(BASELINE.json configs[1] per GPU)",
-                       "blocks_per_gpu": md.nblocks, "particles_per_gpu": args.particles_per_gpu,
+                       "blocks_per_gpu": md.nowned, "halo_blocks_per_gpu": md.nblocks - md.nowned, "particles_per_gpu": args.particles_per_gpu,
                        "parallelism": f"meshblocks over {args.gpus} rank(s), RCCL particle hand-off"},
             "events_per_s": events / wall,
             "transport_iterations_per_step": getattr(md, "transport_iterations", 1),
