@@ -541,7 +541,18 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
         }
         t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
 
-        xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:146
+        // Xtoijk (transport.cpp:146)
+        if constexpr (kFastGray) {
+          // After an IMC step a particle is either >= eps_imc dx inside its cell or has been put
+          // eps_imc dx beyond the face it reached (transport_utils.hpp:151-159), so
+          // floor((x - xmin) / dx) moves by exactly one in that direction: two compares per axis
+          // instead of subtract / multiply / floor / convert.
+          ip += (int)(x > s.xu) - (int)(x < s.xl);
+          if constexpr (multi_d) jp += (int)(y > s.yu) - (int)(y < s.yl);
+          if constexpr (three_d) kp += (int)(z > s.zu) - (int)(z < s.zl);
+        } else {
+          xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);
+        }
 
         if (!on_block(M, ip, jp, kp)) {
           if constexpr (DDMC) {  // transport_ddmc.cpp:203-211: zero velocity flags a DDMC leak

@@ -69,3 +69,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_plain_c_program_links_and_gets_reference_style_errors(tmp_path):
+    import subprocess
+    exe = tmp_path / "cabi_example"
+    lib_dir = os.path.join(ROOT, "jaybenne_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cabi_example.c"), "-o", str(exe),
+                    "-L", lib_dir, "-ljaybenne_amd", f"-Wl,-rpath,{lib_dir}"], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "jaybenne_amd" in res.stdout and "swarm occupancy" in res.stdout
