@@ -765,7 +765,7 @@ __global__ void k_dbg_rocrand(unsigned long long seed, unsigned long long subseq
   out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
 }
 __global__ void k_dbg_draw(unsigned long long state, int n, double *out, unsigned long long *fin) {
-  XorShiftRng rng(state);
+  LcgRng rng(state);
   for (int i = 0; i < n; ++i) out[i] = rng.drand();
   *fin = rng.s;
 }

@@ -48,7 +48,7 @@ struct DevSwarm {
   double *x, *y, *z, *vx, *vy, *vz, *t, *w, *e;
   int *ip, *jp, *kp, *blk, *status;
   uint64_t *id;   // creation index (diagnostic key, never read by the tracking kernel)
-  uint64_t *rng;  // xorshift64* state of the particle's stream
+  uint64_t *rng;  // LCG state of the particle's stream
 };
 
 // read-only field data reached through a pointer that was itself loaded from memory: telling

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(kBlock)
       int i = r - j * M.nx[0];
       k += M.ks; j += M.js; i += M.is;
       const long long q = cidx(M, k, j, i);
-      XorShiftRng rng(rng_seed_state(P.key0, kRngDomainCell, cell_stream_id(epoch, M.gid[b], cell)));
+      LcgRng rng(rng_seed_state(P.key0, kRngDomainCell, cell_stream_id(epoch, M.gid[b], cell)));
       const double rho = M.rho[b][q];
       const double temp = eos_temperature(P, rho, M.sie[b][q]);
       double erad;
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(kBlock)
     load_block(M, b, B);
     const long long n = slot_base[b] + np;
     const uint64_t id = id_base[b] + (uint64_t)np;
-    XorShiftRng rng(rng_seed_state(P.key0, kRngDomainParticle, id));
+    LcgRng rng(rng_seed_state(P.key0, kRngDomainParticle, id));
     S.ip[n] = i; S.jp[n] = j; S.kp[n] = k;
     S.blk[n] = b;
     S.status[n] = ST_ACTIVE;
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
   int ls = LS_IDLE;
   bool resample = false;  // DDMC particle reached census: position / direction to be resampled
   long long n = 0;
-  XorShiftRng rng(0);
+  LcgRng rng(0);
   int b = 0, ip = 0, jp = 0, kp = 0, status = ST_ACTIVE;
   double t = 0, x = 0, y = 0, z = 0, vx = 0, vy = 0, vz = 0, ee = 0;
   Blk B;
@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(kBlock)
     const int b = S.blk[n];
     Blk B;
     load_block(M, b, B);
-    XorShiftRng rng(S.rng[n]);
+    LcgRng rng(S.rng[n]);
     double x = S.x[n], y = S.y[n], z = S.z[n];
     double vx = S.vx[n], vy = S.vy[n], vz = S.vz[n];
     int ip = S.ip[n], jp = S.jp[n], kp = S.kp[n];

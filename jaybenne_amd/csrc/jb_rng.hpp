@@ -2,20 +2,21 @@
 //
 // The reference checks a Kokkos::Random_XorShift64 generator out of a pool once per particle per
 // launch (reference src/jaybenne/transport.cpp:73,172; jaybenne.hpp:24-27), so which uniforms a
-// particle sees depends on launch geometry.  Here every particle owns its generator -- the same
-// xorshift64* recurrence the reference's pool runs (shifts 12, 25, 27, multiplier
-// 2685821657736338717) -- and its 64-bit state travels with the particle (8 bytes in the swarm):
+// particle sees depends on launch geometry.  Here every particle owns its generator, whose
+// 64-bit state travels with the particle (8 bytes in the swarm) -- one linear congruential
+// stream per history, as in MCNP and OpenMC:
 //
 //   seeding  state = words (0,1) of Philox4x32-10(counter = {0, 0, id_lo, id_hi},
 //            key = {seed, domain}); Philox laid out like rocRAND's
 //            rocrand_init(seed, subsequence = id, offset = 0).  Done once, when the particle is
 //            sourced.
-//   draw     s ^= s >> 12; s ^= s << 25; s ^= s >> 27; r = s * 2685821657736338717;
-//            xi = ((r >> 12) + 0.5) * 2^-52   in the open interval (0,1)
+//   draw     s = s * 6364136223846793005 + 1442695040888963407 (mod 2^64, Knuth's MMIX LCG);
+//            xi = ((s >> 12) + 0.5) * 2^-52   in the open interval (0,1)
 //
 // Results are therefore independent of wave scheduling, block -> GPU partition and hand-off.
-// Measured on MI355X (tools/microbench.hip): 87 SIMD-cycles per wave-level uniform, against 163
-// for a Philox4x32-10 block per two uniforms; an IMC event draws four.
+// Cost on MI355X (tools/microbench.hip), SIMD-cycles per wave-level uniform: this generator 43,
+// xorshift64* (the recurrence of the reference's pool; built and measured first) 77,
+// Philox4x32-10 per pair of uniforms 163 each.  An IMC event draws four.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -50,9 +51,7 @@ constexpr uint32_t kRngDomainCell = 1u;      // per-cell streams of the source's
 
 __device__ __forceinline__ uint64_t rng_seed_state(uint32_t seed, uint32_t domain, uint64_t id) {
   const PhiloxBlock b = philox4x32_10(0u, 0u, (uint32_t)id, (uint32_t)(id >> 32), seed, domain);
-  uint64_t s = ((uint64_t)b.w1 << 32) | b.w0;
-  if (s == 0) s = (((uint64_t)b.w3 << 32) | b.w2) | 1ull;
-  return s;
+  return ((uint64_t)b.w1 << 32) | b.w0;
 }
 
 // (k52 + 0.5) * 2^-52, formed without an integer -> double conversion: 1.k52 (exponent bits of
@@ -63,14 +62,12 @@ __device__ __forceinline__ double u52_to_double(uint64_t k52) {
   return (one_to_two - 1.0) + 1.1102230246251565404236316680908203125e-16;  // 2^-53
 }
 
-struct XorShiftRng {
+struct LcgRng {
   uint64_t s;
-  __device__ __forceinline__ explicit XorShiftRng(uint64_t state) : s(state) {}
+  __device__ __forceinline__ explicit LcgRng(uint64_t state) : s(state) {}
   __device__ __forceinline__ double drand() {
-    s ^= s >> 12;
-    s ^= s << 25;
-    s ^= s >> 27;
-    return u52_to_double((s * 2685821657736338717ull) >> 12);
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    return u52_to_double(s >> 12);
   }
 };
 

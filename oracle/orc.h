@@ -66,7 +66,7 @@ typedef struct orc_swarm {
   double *x, *y, *z, *vx, *vy, *vz, *t, *w, *e;
   int32_t *ip, *jp, *kp, *blk, *status;
   uint64_t *id;  /* creation index (diagnostic key) */
-  uint64_t *rng; /* xorshift64* state of the particle's stream */
+  uint64_t *rng; /* LCG state of the particle's stream */
 } orc_swarm;
 
 void orc_set_math_mode(int mode); /* 0 = libm (reference arithmetic), 1 = portable spec */

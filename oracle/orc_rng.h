@@ -4,23 +4,22 @@
  *
  * The reference draws every uniform through Kokkos::Random_XorShift64_Pool
  * (reference src/jaybenne/jaybenne.hpp:24-27; checkout/return at transport.cpp:73,172): a pool of
- * xorshift64* generators shared by whatever threads run, so which uniforms a particle sees depends
- * on the launch.  Kokkos is an un-vendored dependency (absent from /root/reference, pin unknown) and
- * the reference's tests pin nothing about the generator, so parity at the level of individual
- * uniforms is UNPINNED.  This build keeps the reference's generator algorithm (Marsaglia / Vigna
- * xorshift64*, shifts 12, 25, 27, multiplier 2685821657736338717) but gives every particle its own
- * generator, whose 64-bit state travels with the particle:
+ * generators shared by whatever threads run, so which uniforms a particle sees depends on the
+ * launch.  Kokkos is an un-vendored dependency (absent from /root/reference, pin unknown) and the
+ * reference's tests pin nothing about the generator, so parity at the level of individual uniforms
+ * is UNPINNED.  This build gives every particle its own generator, whose 64-bit state travels
+ * with the particle -- the arrangement of the production Monte Carlo transport codes (MCNP,
+ * OpenMC: one linear congruential stream per history):
  *
  *     seeding   state = words (0,1) of Philox4x32-10( counter = {0, 0, id_lo, id_hi},
  *                                                     key = {seed, domain} )
- *               (words (2,3) | 1 if that is zero).  Philox4x32-10 is the published Random123
- *               algorithm (Salmon et al., SC'11), laid out like rocRAND's
- *               rocrand_init(seed, subsequence = id, offset = 0).
- *     draw      s ^= s >> 12;  s ^= s << 25;  s ^= s >> 27;  r = s * 2685821657736338717;
- *               xi = ((r >> 12) + 0.5) * 2^-52      in the OPEN interval (0,1)
+ *               Philox4x32-10 is the published Random123 algorithm (Salmon et al., SC'11), laid
+ *               out like rocRAND's rocrand_init(seed, subsequence = id, offset = 0).
+ *     draw      s = s * 6364136223846793005 + 1442695040888963407  (mod 2^64; Knuth's MMIX LCG)
+ *               xi = ((s >> 12) + 0.5) * 2^-52      in the OPEN interval (0,1)
  *
- * Pinned by the Random123 Philox known-answer vectors and by the xorshift64* reference values in
- * tests/test_oracle_rng.py.
+ * Pinned by the Random123 Philox known-answer vectors and by a big-integer restatement of the
+ * recurrence in tests/test_oracle_rng.py.
  *
  * A "tape" mode replays a caller-supplied list of uniforms, so that every branch of the step
  * functions can be driven deterministically (golden vectors, tests/golden/).
@@ -54,7 +53,7 @@ static inline void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2
 }
 
 typedef struct orc_rng {
-  uint64_t s;          /* xorshift64* state */
+  uint64_t s;          /* LCG state */
   uint32_t ctr;        /* number of uniforms drawn through this handle (diagnostic) */
   const double *tape;  /* if non-NULL: replay tape[pos++ % ntape] instead */
   int ntape;
@@ -68,9 +67,7 @@ static inline uint64_t orc_rng_seed_state(uint32_t seed, uint32_t domain, uint64
   const uint32_t k[2] = {seed, domain};
   uint32_t o[4];
   orc_philox4x32_10(c, k, o);
-  uint64_t s = ((uint64_t)o[1] << 32) | o[0];
-  if (s == 0) s = (((uint64_t)o[3] << 32) | o[2]) | 1ull;
-  return s;
+  return ((uint64_t)o[1] << 32) | o[0];
 }
 
 static inline orc_rng orc_rng_from_state(uint64_t state) {
@@ -88,13 +85,10 @@ static inline double orc_drand(orc_rng *r) {
     r->ctr++;
     return v;
   }
-  uint64_t s = r->s;
-  s ^= s >> 12;
-  s ^= s << 25;
-  s ^= s >> 27;
+  const uint64_t s = r->s * 6364136223846793005ull + 1442695040888963407ull;
   r->s = s;
   r->ctr++;
-  return orc_u52_to_double((s * 2685821657736338717ull) >> 12);
+  return orc_u52_to_double(s >> 12);
 }
 
 #endif /* ORC_RNG_H_ */

@@ -1,5 +1,5 @@
 """Pins the oracle's random-number source: Philox4x32-10 against the Random123 known-answer
-vectors, xorshift64* against an independent big-integer restatement of the published recurrence."""
+vectors, the 64-bit LCG against an independent big-integer restatement of the recurrence."""
 import numpy as np
 
 from oracle import orc
@@ -16,24 +16,17 @@ def test_philox_known_answers():
         assert tuple(orc.philox(ctr, key)) == want
 
 
-def _xorshift64star(s):
-    m = (1 << 64) - 1
-    s ^= s >> 12
-    s = (s ^ (s << 25)) & m
-    s ^= s >> 27
-    return s, (s * 2685821657736338717) & m
-
-
-def test_xorshift64star_stream_matches_published_recurrence():
-    state = 0x9E3779B97F4A7C15
-    got, final = orc.draw_stream(state, 1000)
-    s = state
-    for i in range(1000):
-        s, r = _xorshift64star(s)
-        want = ((r >> 12) + 0.5) * 2.0 ** -52
-        assert got[i] == want
-    assert final == s
-    assert got.min() > 0.0 and got.max() < 1.0
+def test_lcg_stream_matches_recurrence():
+    """s <- s * 6364136223846793005 + 1442695040888963407 mod 2^64 (Knuth, MMIX);
+    xi = ((s >> 12) + 0.5) 2^-52."""
+    for state in (0, 1, 0x9E3779B97F4A7C15, (1 << 64) - 1):
+        got, final = orc.draw_stream(state, 1000)
+        s = state
+        for i in range(1000):
+            s = (s * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+            assert got[i] == ((s >> 12) + 0.5) * 2.0 ** -52
+        assert final == s
+        assert got.min() > 0.0 and got.max() < 1.0
 
 
 def test_stream_seeding_layout():

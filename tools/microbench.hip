@@ -46,7 +46,7 @@ __global__ void k_philox(double *out) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = (double)acc;
 }
 __global__ void k_drand2(double *out) {  // two uniforms from the product generator
-  XorShiftRng rng(rng_seed_state(349857u, 0u, blockIdx.x * 256ull + threadIdx.x));
+  LcgRng rng(rng_seed_state(349857u, 0u, blockIdx.x * 256ull + threadIdx.x));
   double a = 0.0;
   for (int i = 0; i < ITER; ++i) a += rng.drand() * rng.drand();
   out[blockIdx.x * blockDim.x + threadIdx.x] = a;
