@@ -186,6 +186,7 @@ def main() -> None:
                        "parallelism": f"meshblocks over {args.gpus} rank(s), RCCL particle hand-off"},
             "events_per_s": events / wall,
             "transport_iterations_per_step": getattr(md, "transport_iterations", 1),
+            "kernel_diagnostics": md.stats(),
             "events_per_history": ev_per_hist,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -136,6 +136,8 @@ typedef struct jb_swarm_view {
 typedef struct jb_transport_stats {
   int64_t n_census, n_absorbed, n_escaped, n_outgoing;
   int64_t n_events;  /* passes through the while loop of transport.cpp:98-171 */
+  int64_t n_wave_passes;    /* diagnostics: 64-lane passes through the kernel's event loop ... */
+  int64_t n_wave_services;  /* ... and through its service phase, summed over waves */
 } jb_transport_stats;
 
 typedef struct jb_context jb_context;

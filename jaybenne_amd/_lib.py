@@ -72,7 +72,8 @@ class SwarmView(C.Structure):
 
 class TransportStats(C.Structure):
     _fields_ = [("n_census", C.c_int64), ("n_absorbed", C.c_int64), ("n_escaped", C.c_int64),
-                ("n_outgoing", C.c_int64), ("n_events", C.c_int64)]
+                ("n_outgoing", C.c_int64), ("n_events", C.c_int64),
+                ("n_wave_passes", C.c_int64), ("n_wave_services", C.c_int64)]
 
 
 class DebugStep(C.Structure):

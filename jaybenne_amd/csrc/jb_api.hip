@@ -51,7 +51,6 @@ struct jb_context {
   unsigned long long *counters_h = nullptr;   // pinned
   long long *scratch_d = nullptr;             // holes / movers / small tables
   size_t scratch_words = 0;
-  jb_transport_stats stats{};
 };
 constexpr int kCounterWords = 1024;  // CNT_N.. | 16..17 cursors | 32.. per-rank counts (<= 480 ranks)
 constexpr int kCursorBase = 16;
@@ -61,7 +60,6 @@ struct jb_mesh {
   jb_context *ctx = nullptr;
   DevMesh dm{};
   std::vector<void *> owned;  // device allocations
-  std::vector<int32_t> owner_h, gid_h;
   int nranks_seen = 1;
 };
 
@@ -231,8 +229,6 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   int maxrank = 0;
   for (int g = 0; g < v->nblocks_total; ++g) maxrank = v->owner[g] > maxrank ? v->owner[g] : maxrank;
   m->nranks_seen = maxrank + 1;
-  m->owner_h.assign(v->owner, v->owner + v->nblocks_total);
-  m->gid_h.assign(v->gid, v->gid + v->nblocks);
   jb_status st;
 #define UP(field, count)                                                         \
   if ((st = upload(m, v->field, (size_t)(count), &D.field)) != JB_COMPLETE) {     \
@@ -511,6 +507,8 @@ extern "C" jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats 
   stats->n_escaped = (int64_t)ctx->counters_h[CNT_ESCAPED];
   stats->n_outgoing = (int64_t)ctx->counters_h[CNT_OUTGOING];
   stats->n_events = (int64_t)ctx->counters_h[CNT_EVENTS];
+  stats->n_wave_passes = (int64_t)ctx->counters_h[CNT_PASSES];
+  stats->n_wave_services = (int64_t)ctx->counters_h[CNT_SERVICE];
   if (reset) JB_HIP(hipMemsetAsync(ctx->counters_d, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
   return JB_COMPLETE;
 }

@@ -25,7 +25,7 @@ namespace jb {
 constexpr int kBlock = 256;  // 4 waves per workgroup
 
 // counters[]: 0 census, 1 absorbed, 2 escaped, 3 outgoing, 4 events, 5 unfinished
-enum { CNT_CENSUS = 0, CNT_ABSORBED, CNT_ESCAPED, CNT_OUTGOING, CNT_EVENTS, CNT_UNFINISHED, CNT_N };
+enum { CNT_CENSUS = 0, CNT_ABSORBED, CNT_ESCAPED, CNT_OUTGOING, CNT_EVENTS, CNT_UNFINISHED, CNT_PASSES, CNT_SERVICE, CNT_N };
 constexpr int CNT_QUEUE = 8;  // heads of the 8 particle queues of the running transport launch
 constexpr int kQueues = 8;    // one per XCD (workgroups b and b + 8 share an XCD and its L2)
 
@@ -323,8 +323,12 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 
 enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
 
+#ifndef JB_DDMC_WAVES_PER_SIMD
+#define JB_DDMC_WAVES_PER_SIMD 2
+#endif
 template <int NDIM, bool DDMC, bool TALLY, bool GRAY>
-__global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
+__global__ void
+__launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER_SIMD)
     k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
                 long long last, unsigned long long *counters) {
   load_math_tables();
@@ -342,6 +346,7 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
   bool more = true;                // wave-uniform: some queue may still hold particles
 
   unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0, c_ev = 0;
+  unsigned int c_pass = 0, c_service = 0;  // wave-level: event-loop passes, service phases
 
   // lane state
   int ls = LS_IDLE;
@@ -379,6 +384,7 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
 
   for (;;) {
     // ================================ SERVICE ================================
+    ++c_service;
     if (ls == LS_RELOC) {
       // the comm phase of the reference, for one particle in flight: boundary conditions
       // (boundaries.hpp:46-82, periodic, outflow), destination block, SampleDDMCBlockFace
@@ -485,6 +491,7 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
     // ================================ EVENTS =================================
     // (no `continue` / `break` below: every lane must reach the ballot of the loop condition)
     while (__popcll(__ballot(ls == LS_RUN)) >= thresh) {
+      ++c_pass;
       if (ls == LS_RUN) {
         ++c_ev;
         Step s;
@@ -584,6 +591,8 @@ __global__ void __launch_bounds__(kBlock, JB_TRANSPORT_WAVES_PER_SIMD)
     if (r_esc) atomicAdd(&counters[CNT_ESCAPED], r_esc);
     if (r_out) atomicAdd(&counters[CNT_OUTGOING], r_out);
     if (r_ev) atomicAdd(&counters[CNT_EVENTS], r_ev);
+    atomicAdd(&counters[CNT_PASSES], (unsigned long long)c_pass);
+    atomicAdd(&counters[CNT_SERVICE], (unsigned long long)c_service);
   }
 }
 

@@ -11,8 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import enum
 import sys
-from dataclasses import dataclass
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch

@@ -493,3 +493,55 @@ def test_full_size_invariants_c2(gpu_device):
     assert n1 == n0
     for k, ref in keep.items():
         assert bool((b.md.swarm[k][:n0] == ref).all()), k
+
+
+# ------------------------------------------------------------------------------------------------
+def test_empty_and_ragged_inputs(gpu_device):
+    """Empty swarm, zero-length ranges, fewer particles than cells, a rank-local pool that is
+    mostly holes: every task must be a no-op or handle the ragged case, never fault."""
+    import ctypes as C
+    from jaybenne_amd import _lib, jaybenne as jb
+    from oracle import orc
+    # (a) no initial radiation at all: every task on an empty swarm
+    ov = {"mcblock/initial_radiation": "none", "jaybenne/num_particles": 1000}
+    drv = _gpu_problem(load_deck("stepdiff_ddmc", ov), gpu_device)
+    md = drv.md
+    assert md.n == 0
+    drv.Step()
+    assert md.n == 0 and md.stats()["n_events"] == 0
+    assert jb.CheckCompletion(md, 1.0) == jb.TaskStatus.complete and md.num_unfinished == 0
+    jb.EvaluateRadiationEnergy(md)
+    assert float(md.fields["tally"].abs().max()) == 0.0
+    assert jb.RemoveMarkedParticles(md) == 0
+    jb.SampleDDMCBlockFace(md)
+    for face in range(6):
+        jb.PhotonReflectBC(md, face)
+    counts = np.zeros(1, dtype=np.int64)
+    _lib.check(md.lib.jb_pack_outgoing(md.pkg.ctx, md.handle, C.byref(md.sv), 0, 0, 1, None, 0,
+                                       counts.ctypes.data))
+    assert counts[0] == 0
+    # (b) far fewer particles than cells (npc = 0.05): most cells source nothing
+    ov = {"parthenon/mesh/nx2": 16, "parthenon/mesh/nx3": 16, "parthenon/mesh/nx1": 32,
+          "parthenon/meshblock/nx1": 16, "parthenon/meshblock/nx2": 8, "parthenon/meshblock/nx3": 8,
+          "jaybenne/num_particles": 400}
+    drv = _gpu_problem(load_deck("stepdiff", ov), gpu_device)
+    O, _, _ = make_oracle(load_deck("stepdiff", ov), orc.MATH_PORTABLE)
+    assert 0 < drv.md.n == O.n < 8192
+    drv.Step()
+    run_oracle_cycles(O, load_deck("stepdiff", ov), 1)
+    _compare_swarm(drv.md, O)
+    # (c) a pool that is mostly holes compacts to the survivors, whatever their positions
+    import torch
+    n = drv.md.n
+    st = torch.ones(n, dtype=torch.int32, device=gpu_device)
+    keep = torch.arange(3, n, 7, device=gpu_device)
+    st[keep] = 0
+    ids_before = drv.md.swarm["id"][:n][keep].clone()
+    drv.md.swarm["status"][:n] = st
+    assert jb.RemoveMarkedParticles(drv.md) == len(keep)
+    g = drv.md.get_swarm()
+    assert sorted(g["id"].tolist()) == sorted(ids_before.cpu().numpy().view(np.uint64).tolist())
+    assert (g["status"] == 0).all()
+    # all holes
+    drv.md.swarm["status"][:drv.md.n] = 1
+    assert jb.RemoveMarkedParticles(drv.md) == 0
