@@ -88,7 +88,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--particles-per-gpu", type=int, default=10_000_000)
     ap.add_argument("--block-nx", type=int, default=64)
-    ap.add_argument("--cpu-sample", type=int, default=400_000)
+    ap.add_argument("--cpu-sample", type=int, default=2_500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3-1d"],
                     help="c2 = headline (BASELINE configs[1]); c3* = DDMC side measurements")
@@ -159,11 +159,11 @@ def main() -> None:
         achieved = k_bytes / k_time / 1e9 if k_time > 0 else 0.0
         fp64 = k_hist * ev_per_hist * FLOPS_PER_EVENT / k_time / 1e12 if k_time > 0 else 0.0
         # HBM bytes per launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
-        # passes of this very command; profiles/r01_b_hbm_traffic.json) -- valid for the workload
+        # passes of this very command; profiles/r01_c_hbm_traffic.json) -- valid for the workload
         # and particle count they were collected on
         traffic = None
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_b_hbm_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")))
             if (tr["workload"] == args.workload and tr["particles_per_gpu"] == args.particles_per_gpu
                     and args.block_nx == 64 and args.gpus == 1):
                 traffic = tr["hbm_bytes_per_launch"]
@@ -198,9 +198,9 @@ def main() -> None:
                          "fp64_valu": {"achieved_tflops": fp64, "peak_tflops": FP64_VALU_PEAK_TF,
                                        "frac": fp64 / FP64_VALU_PEAK_TF,
                                        "note": "IMC regime is VALU-issue bound, not HBM bound (SURVEY "
-                                               "8d): PMC shows the SIMDs 97 % busy issuing VALU at 410 "
-                                               "instructions per 64-lane event, L2 hit rate 98.7 %, "
-                                               "157 GB/s of HBM traffic (profiles/r01_b_pmc_*.json)"}},
+                                               "8d): PMC shows the SIMDs 98 % busy issuing VALU at 359 "
+                                               "instructions per 64-lane event, L2 hit rate 98.8 %, "
+                                               "162 GB/s of HBM traffic (profiles/r01_c_pmc_*.json)"}},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.block_nx)
