@@ -59,7 +59,15 @@ def main(argv=None) -> int:
               f"histories/s={n0 / dt:.3e} events/s={(drv.md.events - e0) / dt:.3e}")
     print(f"walltime used = {time.perf_counter() - t0:.2f} s")
     tally = drv.md.get_field("tally")
-    err = analysis.analytic_errors(drv.mesh, tally, drv.time)
+    if drv.mcb.problem_id.startswith("inf"):
+        from . import constants
+        solution = analysis.equilibrium_solution(drv.mcb.initial_temperature,
+                                                 constants.STEFAN_BOLTZMANN, constants.SPEED_OF_LIGHT)
+        print(f"domain-mean energy tally / (a T0^4): "
+              f"{float(np.mean(np.asarray(tally)[drv.mesh.interior()])) / float(solution(0.0, 0.0)):.4f}")
+    else:
+        solution = analysis.ur_solution
+    err = analysis.analytic_errors(drv.mesh, tally, drv.time, solution)
     print(f"Mean error:                     {err['mean_error']:.2e}")
     print(f"Mean fractional error:          {err['mean_frac_error']:.2e}")
     print(f"Mean weighted fractional error: {err['mean_frac_error_weighted']:.2e}")

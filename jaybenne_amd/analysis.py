@@ -3,6 +3,11 @@
 ``ur_solution`` is the analytic diffusion profile of reference tst/stepdiff.py:33-46 (and
 tst/stepdiff_smr.py:35-48); ``analytic_errors`` reproduces the loop of
 tst/regression_test.py:361-406 over every interior cell of every block.
+
+``equilibrium_solution`` is the answer of the two infinite-medium decks (inputs/inf.in,
+inputs/inf_stiff.in: uniform emitting / absorbing material held at T0, periodic box): the
+radiation energy density stays at a T0^4.  The reference ships no script for these decks; the
+criterion is the same five numbers against that constant.
 """
 from __future__ import annotations
 
@@ -19,6 +24,11 @@ SHIFT = 0.5
 def ur_solution(t, x, y=0.0, z=0.0):
     s = 2.0 * np.sqrt(t / TAU)
     return UR0 / 2.0 * (erf(((x + SHIFT) + 0.5) / s) - erf(((x + SHIFT) - 0.5) / s))
+
+
+def equilibrium_solution(t0_kelvin: float, sb: float, c: float) -> Callable:
+    ur = 4.0 * sb / c * t0_kelvin ** 4
+    return lambda t, x, y=0.0, z=0.0: np.full_like(np.asarray(x, dtype=np.float64), ur)
 
 
 def analytic_errors(mesh, tally: np.ndarray, t: float,

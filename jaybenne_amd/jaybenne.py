@@ -184,6 +184,7 @@ class MeshData:
         self.sv = _lib.SwarmView(n=0, capacity=self.capacity)
         for n in _F64 + _I32 + ("id", "rng"):
             setattr(self.sv, n, self.swarm[n].data_ptr())
+        self.max_capacity: Optional[int] = None   # set to forbid growth beyond a slot count
         self.prefix = torch.zeros(self.nblocks * mesh.ncell, dtype=torch.int32, device=dev)
         self.records: Optional[torch.Tensor] = None
         self.next_id = 0     # first unused stream id (global, kept in step on every rank)
@@ -191,6 +192,29 @@ class MeshData:
         self.events = 0
         self.kernel_events = None   # set to [] to time every transport launch with HIP events
         self._make_mesh_handle(owner)
+
+    def reserve(self, nslots: int) -> None:
+        """Make room for ``nslots`` particles (the role of Parthenon's pool growth inside
+        ``Swarm::AddEmptyParticles``, reference sourcing.cpp:123-131): the swarm arrays are
+        reallocated at twice the need and the live prefix ``0..n-1`` is carried over."""
+        if nslots <= self.capacity:
+            return
+        if self.max_capacity is not None and nslots > self.max_capacity:
+            raise MemoryError(f"swarm capacity {self.max_capacity} too small for {nslots} particles")
+        new_cap = 2 * int(nslots)
+        if self.max_capacity is not None:
+            new_cap = min(new_cap, int(self.max_capacity))
+        self._sync_stream()
+        n = int(self.sv.n)
+        for name in _F64 + _I32 + ("id", "rng"):
+            old = self.swarm[name]
+            new = torch.zeros(new_cap, dtype=old.dtype, device=old.device)
+            new[:n].copy_(old[:n])
+            self.swarm[name] = new
+            setattr(self.sv, name, new.data_ptr())
+        torch.cuda.synchronize(self.device)
+        self.capacity = new_cap
+        self.sv.capacity = new_cap
 
     # ---- C views
     def _make_mesh_handle(self, owner: np.ndarray) -> None:
@@ -305,8 +329,7 @@ def SourcePhotons(md: MeshData, source_type: SourceType, t_start: float, dt: flo
     local_excl = np.concatenate(([0], np.cumsum(nper.astype(np.int64))[:-1]))
     slot_base = np.ascontiguousarray(md.n + local_excl, dtype=np.int64)
     tot = int(nper.sum())
-    if md.n + tot > md.capacity:
-        raise MemoryError(f"swarm capacity {md.capacity} too small for {md.n} + {tot} particles")
+    md.reserve(md.n + tot)
     _lib.check(md.lib.jb_source_photons_fill(pkg.ctx, md.handle, C.byref(md.sv), int(source_type),
                                              t_start, dt, nper.ctypes.data, md.prefix.data_ptr(),
                                              slot_base.ctypes.data, id_base.ctypes.data))
@@ -442,8 +465,7 @@ def _exchange(md: MeshData, first: int, last: int):
     if nrecv:
         if md.n + nrecv > md.capacity:
             RemoveMarkedParticles(md)          # close the holes left by earlier departures
-        if md.n + nrecv > md.capacity:
-            raise MemoryError(f"swarm capacity {md.capacity} too small for {md.n} + {nrecv} particles")
+        md.reserve(md.n + nrecv)
         md._sync_stream()
         _lib.check(lib.jb_unpack_incoming(ctx, md.handle, C.byref(md.sv), recv.data_ptr(), nrecv))
     return nrecv, total

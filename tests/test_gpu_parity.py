@@ -188,6 +188,23 @@ def _compare_swarm(md, O, exact=True):
             np.testing.assert_allclose(a, b, rtol=1e-9, atol=0, err_msg=k)
 
 
+def _compare_swarm_by_id(md, O, exact=True):
+    """Compaction reorders the survivors: compare as sets keyed by stream id."""
+    from oracle import orc
+    g = md.get_swarm()
+    order_g = np.argsort(g["id"])
+    order_o = np.argsort(O.sw["id"][:O.n])
+    assert md.n == O.n
+    for k in ("id", "rng", "ip", "jp", "kp", "blk"):
+        assert np.array_equal(g[k][order_g], O.sw[k][:O.n][order_o]), k
+    for k in orc.SWARM_F64:
+        a, b = g[k][order_g], O.sw[k][:O.n][order_o]
+        if exact:
+            assert np.array_equal(a, b), k
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-11, atol=0, err_msg=k)
+
+
 def _compare_fields(md, O, names=("tally", "edelta", "fleck", "src_num", "src_ew"), scale=None):
     """1e-12 relative; `scale` (per cell) is the magnitude of the terms summed into a cell when
     the sum itself cancels (energy_delta = absorbed - emitted)."""
@@ -257,19 +274,7 @@ def test_absorption_emission_feedback_bit_exact(gpu_device):
     drv = _gpu_problem(pin, gpu_device)
     O, _, _ = make_oracle(load_deck("stepdiff", ov), orc.MATH_PORTABLE)
     def compare(exact):
-        # compaction reorders the survivors: compare as sets keyed by stream id
-        g = drv.md.get_swarm()
-        order_g = np.argsort(g["id"])
-        order_o = np.argsort(O.sw["id"][:O.n])
-        assert drv.md.n == O.n
-        for k in ("id", "rng", "ip", "blk"):
-            assert np.array_equal(g[k][order_g], O.sw[k][:O.n][order_o]), k
-        for k in orc.SWARM_F64:
-            a, b = g[k][order_g], O.sw[k][:O.n][order_o]
-            if exact:
-                assert np.array_equal(a, b), k
-            else:
-                np.testing.assert_allclose(a, b, rtol=1e-11, atol=0, err_msg=k)
+        _compare_swarm_by_id(drv.md, O, exact)
         sl = drv.mesh.interior()
         emitted = np.where(O.fields["src_num"][sl] > 0,
                            O.fields["src_num"][sl] * O.fields["src_ew"][sl], 0.0)
@@ -289,6 +294,31 @@ def test_absorption_emission_feedback_bit_exact(gpu_device):
         O.RadiationStep(cyc * dt, dt)
         O.fields["sie"][...] = O.fields["u"] / O.fields["rho"]
     compare(exact=False)
+
+
+@pytest.mark.parametrize("deck,cycles", [("inf", 12), ("inf_stiff", 10)])
+def test_infinite_medium_decks_bit_exact(gpu_device, deck, cycles):
+    """The reference's two equilibrium decks (inputs/inf.in: 3-D IMC, sigma_s = 1e5;
+    inputs/inf_stiff.in: 1-D DDMC, sigma_a = 1e3): emission every cycle, absorption, removal.
+    No feedback, so the material state never sees the order of the absorption atomics and the
+    particles stay bit-identical for the whole run."""
+    from oracle import orc
+    pin = load_deck(deck)
+    drv = _gpu_problem(pin, gpu_device)
+    O, _, _ = make_oracle(load_deck(deck), orc.MATH_PORTABLE, capacity_factor=40.0)
+    dt = pin.GetReal("jaybenne", "dt")
+    t = 0.0
+    for cyc in range(cycles):
+        drv.Step()
+        O.RadiationStep(t, dt)
+        t += dt                      # the driver's own accumulation (mcblock_driver.cpp:46-56)
+        if cyc in (0, cycles - 1):
+            _compare_swarm_by_id(drv.md, O, exact=True)
+    sl = drv.mesh.interior()
+    emitted = O.fields["src_num"][sl] * O.fields["src_ew"][sl]
+    _compare_fields(drv.md, O, ("tally", "fleck", "src_num", "src_ew"))
+    _compare_fields(drv.md, O, ("edelta",), scale=emitted)
+    assert drv.md.events == O.events
 
 
 def test_erf_gate_on_gpu(gpu_device):

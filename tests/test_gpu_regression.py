@@ -45,3 +45,28 @@ def test_three_level_hybrid_extension(gpu_device, tmp_path, capsys):
     rc = main(["-i", str(deck), "--tolerance", "0.08", "jaybenne/num_particles=20000000"])
     out = capsys.readouterr().out
     assert "levels [0, 1, 2]" in out and rc == 0, out
+
+
+@pytest.mark.parametrize("deck,tol", [("inf", 0.03), ("inf_stiff", 0.08)])
+def test_infinite_medium_decks(gpu_device, deck, tol):
+    """inputs/inf.in and inputs/inf_stiff.in run as shipped (100 and 10 cycles; the swarm pool grows
+    as emission particles accumulate): the domain-mean radiation energy density stays at a T0^4."""
+    from helpers import load_deck
+    from jaybenne_amd import constants, mcblock
+    drv = mcblock.McblockDriver(load_deck(deck), device=gpu_device)
+    ur = 4.0 * constants.STEFAN_BOLTZMANN / constants.SPEED_OF_LIGHT * drv.mcb.initial_temperature ** 4
+    sl = drv.mesh.interior()
+    cap0, ratio = drv.md.capacity, []
+    while drv.time < drv.tlim:
+        drv.Step()
+        ratio.append(float(drv.md.get_field("tally")[sl].mean()) / ur)
+    assert abs(np.mean(ratio) - 1.0) < tol, ratio
+    if deck == "inf":
+        assert drv.ncycle in (100, 101) and drv.md.capacity > cap0   # the pool had to grow
+
+
+def test_infinite_medium_cli(gpu_device, capsys):
+    from jaybenne_amd.__main__ import main
+    rc = main(["-i", os.path.join(DECKS, "inf.in"), "--tolerance", "0.2", "--comparison", "mean"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "TEST PASSED" in out and "a T0^4" in out, out

@@ -92,3 +92,24 @@ def test_absorption_and_feedback_conserve_energy():
     e_mat = O.fields["u"][sl].sum() * dv
     assert e_rad + e_mat == pytest.approx(e_rad0 + e_mat0, rel=1e-12)
     assert e_mat != e_mat0
+
+
+@pytest.mark.parametrize("deck,cycles,capacity_factor,tol", [("inf", 25, 40.0, 0.03),
+                                                            ("inf_stiff", 10, 12.0, 0.08)])
+def test_infinite_medium_equilibrium(deck, cycles, capacity_factor, tol):
+    """The reference's equilibrium decks (inputs/inf.in: 3-D IMC with sigma_s = 1e5;
+    inputs/inf_stiff.in: 1-D DDMC with sigma_a = 1e3): material held at T0 emits f j dV dt per
+    cycle and absorbs at f sigma_a c, so the radiation energy density must stay at a T0^4.
+    Checked on the domain mean, averaged over the cycles (Monte Carlo noise: ~1 % and ~5 %)."""
+    from jaybenne_amd import constants
+    pin = load_deck(deck)
+    O, mesh, pkg = make_oracle(pin, orc.MATH_LIBM, threads=8, capacity_factor=capacity_factor)
+    ur = 4.0 * constants.STEFAN_BOLTZMANN / constants.SPEED_OF_LIGHT * pkg.initial_temperature ** 4
+    sl = mesh.interior()
+    dt = pin.GetReal("jaybenne", "dt")
+    ratio = []
+    for cyc in range(cycles):
+        O.RadiationStep(cyc * dt, dt)
+        ratio.append(float(O.fields["tally"][sl].mean()) / ur)
+    assert abs(np.mean(ratio) - 1.0) < tol, ratio
+    assert O.n > 0 and np.all(O.sw["t"][:O.n] >= cycles * dt * (1 - 1e-12))
