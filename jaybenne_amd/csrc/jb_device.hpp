@@ -270,11 +270,20 @@ __device__ __forceinline__ void sample_block_face(const DevMesh &M, const DevPar
   if constexpr (NDIM >= 2) {
     const double vv = P.c;
     if (!(vx * vx + vy * vy + vz * vz < kEps * vv * vv)) return;
-    xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);
-    if (bface_axis<NDIM, 0>(M, B, b, M.P1[b], rng, vv, x, y, z, vx, vy, vz, ip, jp, kp)) return;
-    if (bface_axis<NDIM, 1>(M, B, b, M.P2[b], rng, vv, x, y, z, vx, vy, vz, ip, jp, kp)) return;
-    if constexpr (NDIM == 3)
-      bface_axis<NDIM, 2>(M, B, b, M.P3[b], rng, vv, x, y, z, vx, vy, vz, ip, jp, kp);
+    // Work on copies: the compiler merges the per-axis code paths below into stores through a
+    // selected ADDRESS, which would pin the caller's own x, y, z, ip, jp, kp (live across its
+    // whole event loop) in scratch memory instead of registers.
+    double lx = x, ly = y, lz = z, lvx = vx, lvy = vy, lvz = vz;
+    int li, lj, lk;
+    xtoijk<NDIM>(M, B, lx, ly, lz, li, lj, lk);
+    bool done = bface_axis<NDIM, 0>(M, B, b, M.P1[b], rng, vv, lx, ly, lz, lvx, lvy, lvz, li, lj, lk);
+    if (!done)
+      done = bface_axis<NDIM, 1>(M, B, b, M.P2[b], rng, vv, lx, ly, lz, lvx, lvy, lvz, li, lj, lk);
+    if constexpr (NDIM == 3) {
+      if (!done) bface_axis<NDIM, 2>(M, B, b, M.P3[b], rng, vv, lx, ly, lz, lvx, lvy, lvz, li, lj, lk);
+    }
+    x = lx; y = ly; z = lz; vx = lvx; vy = lvy; vz = lvz;
+    ip = li; jp = lj; kp = lk;
   }
 }
 

@@ -382,9 +382,15 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
     s.zu = xc(B, 2, kp) + 0.5 * B.dx[2];
   };
 
+#ifdef JB_TIMING  // scratch diagnostics: CNT_PASSES / CNT_SERVICE carry cycles / 1024 instead
+  unsigned long long cyc_ev = 0, cyc_sv = 0, cyc_mark = __builtin_readcyclecounter();
+#endif
   for (;;) {
     // ================================ SERVICE ================================
     ++c_service;
+#ifdef JB_TIMING
+    { const unsigned long long now = __builtin_readcyclecounter(); cyc_ev += now - cyc_mark; cyc_mark = now; }
+#endif
     if (ls == LS_RELOC) {
       // the comm phase of the reference, for one particle in flight: boundary conditions
       // (boundaries.hpp:46-82, periodic, outflow), destination block, SampleDDMCBlockFace
@@ -490,6 +496,9 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
 
     // ================================ EVENTS =================================
     // (no `continue` / `break` below: every lane must reach the ballot of the loop condition)
+#ifdef JB_TIMING
+    { const unsigned long long now = __builtin_readcyclecounter(); cyc_sv += now - cyc_mark; cyc_mark = now; }
+#endif
     while (__popcll(__ballot(ls == LS_RUN)) >= thresh) {
       ++c_pass;
       if (ls == LS_RUN) {
@@ -591,8 +600,13 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
     if (r_esc) atomicAdd(&counters[CNT_ESCAPED], r_esc);
     if (r_out) atomicAdd(&counters[CNT_OUTGOING], r_out);
     if (r_ev) atomicAdd(&counters[CNT_EVENTS], r_ev);
+#ifdef JB_TIMING
+    atomicAdd(&counters[CNT_PASSES], cyc_ev >> 10);
+    atomicAdd(&counters[CNT_SERVICE], cyc_sv >> 10);
+#else
     atomicAdd(&counters[CNT_PASSES], (unsigned long long)c_pass);
     atomicAdd(&counters[CNT_SERVICE], (unsigned long long)c_service);
+#endif
   }
 }
 

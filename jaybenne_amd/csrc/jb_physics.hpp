@@ -281,10 +281,15 @@ __device__ __forceinline__ void ptcl_ddmc_albedo(Step &s, Rng &rng) {
   if (face >= 0) {
     const int axis = face >> 1;
     const double sgn = (face & 1) ? -1.0 : 1.0;  // +1 lower face, -1 upper face
+    // (copies first: `c ? s.a : s.b` on members is an lvalue conditional, i.e. a select of
+    // ADDRESSES followed by a load, which pins the whole Step record in scratch memory)
+    const double svx = s.vx, svy = s.vy, svz = s.vz;
+    const double sxl = s.xl, sxu = s.xu, syl = s.yl, syu = s.yu, szl = s.zl, szu = s.zu;
+    const bool upper = (face & 1) != 0;
     const double dcell = (axis == 0) ? dx : (axis == 1 ? dy : dz);
-    const double vn = (axis == 0) ? s.vx : (axis == 1 ? s.vy : s.vz);
-    const double fpos = (axis == 0) ? ((face & 1) ? s.xu : s.xl)
-                      : (axis == 1) ? ((face & 1) ? s.yu : s.yl) : ((face & 1) ? s.zu : s.zl);
+    const double vn = (axis == 0) ? svx : (axis == 1 ? svy : svz);
+    const double fx = upper ? sxu : sxl, fy = upper ? syu : syl, fz = upper ? szu : szl;
+    const double fpos = (axis == 0) ? fx : (axis == 1 ? fy : fz);
     const double Pf = (2.0 / 3.0) / (s.sig * dcell + 2.0 * kLamExt);
     const double P = 2.0 * Pf * (1.0 + sgn * 1.5 * vn / s.vv);
     if (rng.drand() > P) {
