@@ -115,8 +115,9 @@ __global__ void __launch_bounds__(kBlock) k_face_prob(DevMesh M, DevParams P) {
 }
 
 // Gray opacities + DDMC: gather what a DDMC step reads for one cell into one 64-byte record
-// (instead of nine gathers from seven arrays per step).  Same values: the products / sums are
-// the ones the step functions form (f * sigma_a, sigma_a + sigma_s).
+// {f sigma_a, sigma_a + sigma_s, leak opacities P_face / dx_d of the six faces} (instead of nine
+// gathers from seven arrays and six divisions per step).  Same values: the products, sums and
+// quotients are the ones the step functions form, from the same operands.
 template <int NDIM>
 __global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P) {
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
@@ -131,15 +132,23 @@ __global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P) {
     const double ff = M.fleck[b][q];
     const double ss = opac_scattering(P, rho, temp, 1.0);
     const double aa = opac_absorption(P, rho, temp, 1.0);
+    // cell widths exactly as the tracking kernel forms them (upper face - lower face, faces from
+    // the cell centre, transport_ddmc.cpp:139-147), so P / dx has the same operands as
+    // transport_utils.hpp:175-181
+    Blk B;
+    load_block(M, b, B);
+    const double dx = (xc(B, 0, i) + 0.5 * B.dx[0]) - (xc(B, 0, i) - 0.5 * B.dx[0]);
+    const double dy = (xc(B, 1, j) + 0.5 * B.dx[1]) - (xc(B, 1, j) - 0.5 * B.dx[1]);
+    const double dz = (xc(B, 2, k) + 0.5 * B.dx[2]) - (xc(B, 2, k) - 0.5 * B.dx[2]);
     double *o = M.ddmc_cell[b] + 8 * q;
     o[0] = ff * aa;
     o[1] = aa + ss;
-    o[2] = M.P1[b][q];
-    o[3] = M.P1[b][cidx(M, k, j, i + 1)];
-    o[4] = multi_d ? M.P2[b][q] : 0.0;
-    o[5] = multi_d ? M.P2[b][cidx(M, k, j + 1, i)] : 0.0;
-    o[6] = three_d ? M.P3[b][q] : 0.0;
-    o[7] = three_d ? M.P3[b][cidx(M, k + 1, j, i)] : 0.0;
+    o[2] = M.P1[b][q] / dx;
+    o[3] = M.P1[b][cidx(M, k, j, i + 1)] / dx;
+    o[4] = multi_d ? M.P2[b][q] / dy : 0.0;
+    o[5] = multi_d ? M.P2[b][cidx(M, k, j + 1, i)] / dy : 0.0;
+    o[6] = three_d ? M.P3[b][q] / dz : 0.0;
+    o[7] = three_d ? M.P3[b][cidx(M, k + 1, j, i)] / dz : 0.0;
   }
 }
 
@@ -526,7 +535,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
             const v4d r1 = rec[1];
             s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
             ptcl_ddmc_albedo<NDIM>(s, rng);
-            if (!s.is_rejected) resample = ddmc_step_event<NDIM>(s, rng);
+            if (!s.is_rejected) resample = ddmc_step_event<NDIM, true>(s, rng);
           } else {
             imc_step_core<NDIM>(s, f1[q], f2[q], rng);
           }
@@ -548,7 +557,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
             s.Pz_l = three_d ? M.P3[b][q] : 0.0;
             s.Pz_u = three_d ? M.P3[b][cidx(M, kp + 1, jp, ip)] : 0.0;
             ptcl_ddmc_albedo<NDIM>(s, rng);
-            if (!s.is_rejected) resample = ddmc_step_event<NDIM>(s, rng);
+            if (!s.is_rejected) resample = ddmc_step_event<NDIM, false>(s, rng);
           } else {
             double lam_abs, lam_sc;
             imc_cell_mfp(s.ff, s.aa, s.ss, lam_abs, lam_sc);

@@ -35,7 +35,8 @@ template <class Rng>
 __device__ __forceinline__ void sample_face_iso_dir(double vv, Rng &rng, double &v1, double &v2,
                                                     double &v3) {
   const double mu = m_sqrt(rng.drand());
-  const double nu = sqrt(1.0 - mu * mu);  // may be exactly 0 (mu rounds to 1): general sqrt
+  const double om = 1.0 - mu * mu;  // exactly 0 when mu rounds to 1, else >= 2^-53
+  const double nu = (om > 0.0) ? m_sqrt(om > 0.0 ? om : 1.0) : 0.0;
   const double phi = kTwoPi * rng.drand();
   double sn, cs;
   m_sincos(phi, sn, cs);
@@ -173,7 +174,9 @@ __device__ __forceinline__ void assign_cyclic(int axis, double v1, double v2, do
 // is executed once, so a wave whose lanes leak through different faces does not serialise six
 // copies of it.  Operations and operands per lane are unchanged.
 // Returns true when the particle reached census without an event (the caller then resamples it).
-template <int NDIM, class Rng>
+// LEAK_READY: s.P*_* already hold the leak opacities P_face / dx_d (lines 175-181), formed per
+// cell by k_ddmc_pack from the same operands, instead of the face probabilities.
+template <int NDIM, bool LEAK_READY = false, class Rng>
 __device__ __forceinline__ bool ddmc_step_event(Step &s, Rng &rng) {
   constexpr int multi_d = NDIM >= 2 ? 1 : 0, three_d = NDIM == 3 ? 1 : 0;
   const double rmin = DBL_MIN;
@@ -182,12 +185,12 @@ __device__ __forceinline__ bool ddmc_step_event(Step &s, Rng &rng) {
   const double dy = s.yu - s.yl;
   const double dz = s.zu - s.zl;
 
-  const double leakx_l = s.Px_l / dx;
-  const double leakx_u = s.Px_u / dx;
-  const double leaky_l = s.Py_l / dy;
-  const double leaky_u = s.Py_u / dy;
-  const double leakz_l = s.Pz_l / dz;
-  const double leakz_u = s.Pz_u / dz;
+  const double leakx_l = LEAK_READY ? s.Px_l : s.Px_l / dx;
+  const double leakx_u = LEAK_READY ? s.Px_u : s.Px_u / dx;
+  const double leaky_l = LEAK_READY ? s.Py_l : s.Py_l / dy;
+  const double leaky_u = LEAK_READY ? s.Py_u : s.Py_u / dy;
+  const double leakz_l = LEAK_READY ? s.Pz_l : s.Pz_l / dz;
+  const double leakz_u = LEAK_READY ? s.Pz_u : s.Pz_u / dz;
   const double leak_tot = leakx_l + leakx_u + leaky_l + leaky_u + leakz_l + leakz_u;
 
   const double cdf_ddmc = s.ffaa + leak_tot + rmin;
@@ -256,7 +259,7 @@ __device__ __forceinline__ void ddmc_census_resample(Step &s, Rng &rng) {
 // reference transport_utils.hpp:163-277 -- one DDMC step (event part + census resampling)
 template <int NDIM, class Rng>
 __device__ __forceinline__ void ptcl_ddmc_step(Step &s, Rng &rng) {
-  if (ddmc_step_event<NDIM>(s, rng)) ddmc_census_resample(s, rng);
+  if (ddmc_step_event<NDIM, false>(s, rng)) ddmc_census_resample(s, rng);
 }
 
 // reference transport_utils.hpp:279-397 -- 0..3 draws.  The six face branches of the reference
