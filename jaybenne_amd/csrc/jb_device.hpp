@@ -30,7 +30,8 @@ struct DevMesh {
   // UpdateDerivedTransportFields for frequency-independent (gray) opacities
   double *const *lam_abs, *const *lam_sc;
   // library-owned, gray opacities with DDMC: 8 doubles per cell {f sigma_a, sigma_a + sigma_s,
-  // Px_l, Px_u, Py_l, Py_u, Pz_l, Pz_u} -- everything a DDMC step gathers, in one 64-byte record
+  // leak opacities P/dx of the faces x-, x+, y-, y+, z-, z+} -- everything a DDMC step gathers,
+  // in one 64-byte record
   double *const *ddmc_cell;
 };
 

@@ -26,6 +26,7 @@ constexpr int kBlock = 256;  // 4 waves per workgroup
 
 // counters[]: 0 census, 1 absorbed, 2 escaped, 3 outgoing, 4 events, 5 unfinished
 enum { CNT_CENSUS = 0, CNT_ABSORBED, CNT_ESCAPED, CNT_OUTGOING, CNT_EVENTS, CNT_UNFINISHED, CNT_PASSES, CNT_SERVICE, CNT_N };
+constexpr int kLdsTally = 1024;  // cells (all resident blocks, ghosts included) tallied in LDS
 constexpr int CNT_QUEUE = 8;  // heads of the 8 particle queues of the running transport launch
 constexpr int kQueues = 8;    // one per XCD (workgroups b and b + 8 share an XCD and its L2)
 
@@ -340,7 +341,16 @@ __global__ void
 __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER_SIMD)
     k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
                 long long last, unsigned long long *counters) {
-  load_math_tables();
+  // Small meshes (the reference's 1-D decks: ~1e2 cells under 1e5..1e8 particles): the census
+  // tally of every workgroup goes to LDS and is flushed once at the end, instead of 1e8 global
+  // atomics contending for a handful of cache lines.
+  __shared__ double lds_tally[TALLY ? kLdsTally : 1];
+  const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
+  if constexpr (TALLY) {
+    if (tally_in_lds)
+      for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) lds_tally[q] = 0.0;
+  }
+  load_math_tables();  // (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   constexpr bool kFastGray = GRAY && !DDMC;
   constexpr bool kPackedDdmc = GRAY && DDMC;
@@ -451,7 +461,8 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         ++c_census;
         if constexpr (TALLY) {  // jaybenne.cpp:547-561
           const double dv = B.dx[0] * B.dx[1] * B.dx[2];
-          atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
+          if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], S.w[n] / dv);
+          else atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
         }
       } else if (status == ST_ABSORBED) {
         ++c_abs;
@@ -601,6 +612,16 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
     }
   }
 
+  if constexpr (TALLY) {
+    if (tally_in_lds) {
+      __syncthreads();  // every wave of the workgroup leaves the loop above exactly once
+      for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) {
+        const double v = lds_tally[q];
+        if (v != 0.0) atomicAdd(&M.tally[q / (int)M.ntot][q % (int)M.ntot], v);
+      }
+    }
+  }
+
   unsigned long long r_census = wave_sum(c_census), r_abs = wave_sum(c_abs), r_esc = wave_sum(c_esc),
                      r_out = wave_sum(c_out), r_ev = wave_sum(c_ev);
   if (lane == 0) {
@@ -663,12 +684,28 @@ __global__ void __launch_bounds__(kBlock) k_zero_tally(DevMesh M) {
 }
 
 __global__ void __launch_bounds__(kBlock) k_tally(DevMesh M, DevSwarm S, long long n_total) {
+  __shared__ double lds_tally[kLdsTally];  // small meshes: see k_transport
+  const int ncells = M.nblocks * (int)M.ntot;
+  const bool in_lds = (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
+  if (in_lds) {
+    for (int q = threadIdx.x; q < ncells; q += blockDim.x) lds_tally[q] = 0.0;
+    __syncthreads();
+  }
   for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
        n += (long long)gridDim.x * blockDim.x) {
     if (S.status[n] != ST_ACTIVE) continue;
     const int b = S.blk[n];
     const double dv = M.blk_dx[3 * b] * M.blk_dx[3 * b + 1] * M.blk_dx[3 * b + 2];
-    atomicAdd(&M.tally[b][cidx(M, S.kp[n], S.jp[n], S.ip[n])], S.w[n] / dv);
+    const int q = cidx(M, S.kp[n], S.jp[n], S.ip[n]);
+    if (in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + q], S.w[n] / dv);
+    else atomicAdd(&M.tally[b][q], S.w[n] / dv);
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (int q = threadIdx.x; q < ncells; q += blockDim.x) {
+      const double v = lds_tally[q];
+      if (v != 0.0) atomicAdd(&M.tally[q / (int)M.ntot][q % (int)M.ntot], v);
+    }
   }
 }
 
