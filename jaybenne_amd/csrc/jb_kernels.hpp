@@ -30,6 +30,12 @@ constexpr int kLdsTally = 1024;  // cells (all resident blocks, ghosts included)
 constexpr int CNT_QUEUE = 8;  // heads of the 8 particle queues of the running transport launch
 constexpr int kQueues = 8;    // one per XCD (workgroups b and b + 8 share an XCD and its L2)
 
+// lane 0's value in every lane, as a wave-uniform (scalar register) quantity
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -363,6 +369,10 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   int cur = blockIdx.x % kQueues;  // wave-uniform: queue this wave draws from
   int tried = 0;                   // queues found drained so far
   bool more = true;                // wave-uniform: some queue may still hold particles
+  // DDMC: slots [chunk_pos, chunk_end) of the swarm are this wave's to deal out (wave-uniform);
+  // short DDMC histories claim 256 at a time (one contended atomic per ~10 service phases)
+  constexpr long long kChunk = 256;
+  long long chunk_pos = 0, chunk_end = 0;
 
   unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0, c_ev = 0;
   unsigned int c_pass = 0, c_service = 0;  // wave-level: event-loop passes, service phases
@@ -473,35 +483,91 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
       }
       ls = LS_IDLE;
     }
-    // hand new particles to idle lanes
-    const unsigned long long idle = __ballot(ls == LS_IDLE);
-    if (idle != 0ull && more) {
-      const int leader = __ffsll((long long)idle) - 1;
-      const int want = __popcll(idle);
-      unsigned long long base = 0;
-      if (lane == leader) base = atomicAdd(&queue[cur], (unsigned long long)want);
-      base = __shfl(base, leader, 64);
-      const long long q_first = first + (long long)cur * per_q;
-      long long q_last = q_first + per_q;
-      if (q_last > last) q_last = last;
-      const long long cand = q_first + (long long)base + __popcll(idle & ((1ull << lane) - 1ull));
-      if (q_first + (long long)base + want >= q_last) {  // this queue is drained: move on
-        cur = (cur + 1) % kQueues;
-        if (++tried == kQueues) more = false;
+    if constexpr (!DDMC) {
+      // hand new particles to idle lanes: one claim of exactly what they need per service phase.
+      // IMC histories are ~1e3 events long: this keeps the particles in flight on an XCD one tight
+      // window of the swarm and the tail of the launch short.
+      const unsigned long long idle = __ballot(ls == LS_IDLE);
+      if (idle != 0ull && more) {
+        const int leader = __ffsll((long long)idle) - 1;
+        const int want = __popcll(idle);
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(&queue[cur], (unsigned long long)want);
+        base = __shfl(base, leader, 64);
+        const long long q_first = first + (long long)cur * per_q;
+        long long q_last = q_first + per_q;
+        if (q_last > last) q_last = last;
+        const long long cand = q_first + (long long)base + __popcll(idle & ((1ull << lane) - 1ull));
+        if (q_first + (long long)base + want >= q_last) {  // this queue is drained: move on
+          cur = (cur + 1) % kQueues;
+          if (++tried == kQueues) more = false;
+        }
+        if (ls == LS_IDLE && cand < q_last && S.status[cand] == ST_ACTIVE) {
+          n = cand;
+          rng.s = S.rng[n];
+          b = S.blk[n];
+          bind_block(b);
+          t = S.t[n];
+          x = S.x[n]; y = S.y[n]; z = S.z[n];
+          vx = S.vx[n]; vy = S.vy[n]; vz = S.vz[n];
+          ee = S.e[n];
+          status = ST_ACTIVE;
+          resample = false;
+          xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:96
+          ls = (t < t_end) ? LS_RUN : LS_DONE;      // already at census: nothing to track
+        }
       }
-      if (ls == LS_IDLE && cand < q_last && S.status[cand] == ST_ACTIVE) {
-        n = cand;
-        rng.s = S.rng[n];
-        b = S.blk[n];
-        bind_block(b);
-        t = S.t[n];
-        x = S.x[n]; y = S.y[n]; z = S.z[n];
-        vx = S.vx[n]; vy = S.vy[n]; vz = S.vz[n];
-        ee = S.e[n];
-        status = ST_ACTIVE;
-        resample = false;
-        xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:96
-        ls = (t < t_end) ? LS_RUN : LS_DONE;      // already at census: nothing to track
+    } else {
+      // hand new particles to idle lanes: the wave claims kChunk consecutive slots of its queue
+      // with one atomic and deals them out over the following service phases (ballot + popcount
+      // prefix over the idle lanes); slots that hold no live particle leave their lane idle for
+      // the next round of the loop
+      unsigned long long idle = __ballot(ls == LS_IDLE);
+      while (idle != 0ull && more) {
+        if (chunk_pos >= chunk_end) {
+          const long long q_first = first + (long long)cur * per_q;
+          long long q_last = q_first + per_q;
+          if (q_last > last) q_last = last;
+          unsigned long long base = 0;
+          if (lane == 0) base = atomicAdd(&queue[cur], (unsigned long long)kChunk);
+          chunk_pos = q_first + (long long)uniform_u64(base);
+          chunk_end = chunk_pos + kChunk < q_last ? chunk_pos + kChunk : q_last;
+          if (chunk_pos >= q_last) {  // this queue is drained: move on
+            chunk_pos = chunk_end = 0;
+            cur = (cur + 1) % kQueues;
+            if (++tried == kQueues) more = false;
+            continue;
+          }
+        }
+        const int want = __popcll(idle);
+        const long long avail = chunk_end - chunk_pos;
+        const int give = (long long)want < avail ? want : (int)avail;
+        const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+        if (ls == LS_IDLE && rank < give) {
+          // every field is requested before the first one is looked at: one memory latency
+          const long long cand = chunk_pos + rank;
+          const int st_in = S.status[cand];
+          const unsigned long long rng_in = S.rng[cand];
+          const int b_in = S.blk[cand];
+          const double t_in = S.t[cand], x_in = S.x[cand], y_in = S.y[cand], z_in = S.z[cand];
+          const double vx_in = S.vx[cand], vy_in = S.vy[cand], vz_in = S.vz[cand], e_in = S.e[cand];
+          if (st_in == ST_ACTIVE) {
+            n = cand;
+            rng.s = rng_in;
+            b = b_in;
+            bind_block(b);
+            t = t_in;
+            x = x_in; y = y_in; z = z_in;
+            vx = vx_in; vy = vy_in; vz = vz_in;
+            ee = e_in;
+            status = ST_ACTIVE;
+            resample = false;
+            xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:96
+            ls = (t < t_end) ? LS_RUN : LS_DONE;      // already at census: nothing to track
+          }
+        }
+        chunk_pos += give;
+        idle = __ballot(ls == LS_IDLE);
       }
     }
     const int running = __popcll(__ballot(ls == LS_RUN));
@@ -540,10 +606,10 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           typedef const v4d __attribute__((address_space(1))) *grec;
           const grec rec = (grec)(f0 + 8 * q);
           const v4d r0 = rec[0];
+          const v4d r1 = rec[1];  // (same cache line; requested before r0 is looked at)
           s.ffaa = r0.x; s.sig = r0.y;
           is_ddmc_step = B.dx_push * s.sig > P.tau_ddmc;  // transport_ddmc.cpp:135
           if (is_ddmc_step) {
-            const v4d r1 = rec[1];
             s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
             ptcl_ddmc_albedo<NDIM>(s, rng);
             if (!s.is_rejected) resample = ddmc_step_event<NDIM, true>(s, rng);
