@@ -92,10 +92,10 @@ __device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
   const int first[3] = {M.is, M.js, M.ks};
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    B.xmin[d] = M.blk_xmin[3 * b + d];
-    B.dx[d] = M.blk_dx[3 * b + d];
+    B.xmin[d] = ((gcptr)M.blk_xmin)[3 * b + d];
+    B.dx[d] = ((gcptr)M.blk_dx)[3 * b + d];
     B.x0[d] = B.xmin[d] - (double)first[d] * B.dx[d];
-    B.inv_dx[d] = M.blk_inv_dx[3 * b + d];
+    B.inv_dx[d] = ((gcptr)M.blk_inv_dx)[3 * b + d];
   }
   B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));
 }

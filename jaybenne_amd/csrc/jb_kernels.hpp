@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
 
 #ifndef JB_DDMC_WAVES_PER_SIMD
-#define JB_DDMC_WAVES_PER_SIMD 2
+#define JB_DDMC_WAVES_PER_SIMD 3
 #endif
 template <int NDIM, bool DDMC, bool TALLY, bool GRAY>
 __global__ void
@@ -360,6 +360,13 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   constexpr bool kFastGray = GRAY && !DDMC;
   constexpr bool kPackedDdmc = GRAY && DDMC;
+  // DDMC kernels re-read the block geometry (10 cached doubles) at the top of every event pass
+  // instead of carrying it in 26 registers per lane across the whole loop: that is what lets
+  // three waves instead of two share a SIMD.
+#ifndef JB_RELOAD_BLOCK
+#define JB_RELOAD_BLOCK DDMC
+#endif
+  constexpr bool kReloadBlock = JB_RELOAD_BLOCK;
   constexpr int kServiceAfter = DDMC ? JB_SERVICE_AFTER_DDMC : JB_SERVICE_AFTER;
   const double vv = P.c;
   const double t_end = t_start + dt;  // the reference re-evaluates t_start + dt: same double
@@ -402,13 +409,13 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
       f2 = (gcptr)M.fleck[blk];
     }
   };
-  auto cell_faces = [&](Step &s) {  // transport.cpp:114-119
-    s.xl = xc(B, 0, ip) - 0.5 * B.dx[0];
-    s.xu = xc(B, 0, ip) + 0.5 * B.dx[0];
-    s.yl = xc(B, 1, jp) - 0.5 * B.dx[1];
-    s.yu = xc(B, 1, jp) + 0.5 * B.dx[1];
-    s.zl = xc(B, 2, kp) - 0.5 * B.dx[2];
-    s.zu = xc(B, 2, kp) + 0.5 * B.dx[2];
+  auto cell_faces = [&](Step &s, const Blk &Bq) {  // transport.cpp:114-119
+    s.xl = xc(Bq, 0, ip) - 0.5 * Bq.dx[0];
+    s.xu = xc(Bq, 0, ip) + 0.5 * Bq.dx[0];
+    s.yl = xc(Bq, 1, jp) - 0.5 * Bq.dx[1];
+    s.yu = xc(Bq, 1, jp) + 0.5 * Bq.dx[1];
+    s.zl = xc(Bq, 2, kp) - 0.5 * Bq.dx[2];
+    s.zu = xc(Bq, 2, kp) + 0.5 * Bq.dx[2];
   };
 
 #ifdef JB_TIMING  // scratch diagnostics: CNT_PASSES / CNT_SERVICE carry cycles / 1024 instead
@@ -444,11 +451,12 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
       }
     }
     if (ls == LS_DONE) {
+      if constexpr (kReloadBlock) load_block(M, b, B);
       if constexpr (DDMC) {
         if (resample) {  // transport_utils.hpp:265-276, once per history
           Step s;
           s.vv = vv;
-          cell_faces(s);
+          cell_faces(s, B);
           ddmc_census_resample(s, rng);
           x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
           resample = false;
@@ -590,8 +598,11 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
       if (ls == LS_RUN) {
         ++c_ev;
         Step s;
-        s.t_start = t_start; s.dt = dt; s.vv = vv; s.dx_push = B.dx_push;
-        cell_faces(s);
+        Blk Bl;
+        if constexpr (kReloadBlock) load_block(M, b, Bl);
+        const Blk &Bp = kReloadBlock ? Bl : B;
+        s.t_start = t_start; s.dt = dt; s.vv = vv; s.dx_push = Bp.dx_push;
+        cell_faces(s, Bp);
         const long long q = cidx(M, kp, jp, ip);
         s.t = t; s.x = x; s.y = y; s.z = z; s.vx = vx; s.vy = vy; s.vz = vz;
         s.ip = ip; s.jp = jp; s.kp = kp;
@@ -608,7 +619,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           const v4d r0 = rec[0];
           const v4d r1 = rec[1];  // (same cache line; requested before r0 is looked at)
           s.ffaa = r0.x; s.sig = r0.y;
-          is_ddmc_step = B.dx_push * s.sig > P.tau_ddmc;  // transport_ddmc.cpp:135
+          is_ddmc_step = Bp.dx_push * s.sig > P.tau_ddmc;  // transport_ddmc.cpp:135
           if (is_ddmc_step) {
             s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
             ptcl_ddmc_albedo<NDIM>(s, rng);
@@ -624,7 +635,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           s.aa = opac_absorption(P, rho, temp, ee);
           s.ffaa = s.ff * s.aa;
           s.sig = s.aa + s.ss;
-          if constexpr (DDMC) is_ddmc_step = B.dx_push * s.sig > P.tau_ddmc;
+          if constexpr (DDMC) is_ddmc_step = Bp.dx_push * s.sig > P.tau_ddmc;
           if (DDMC && is_ddmc_step) {
             // transport_ddmc.cpp:137-179
             s.Px_l = M.P1[b][q];
@@ -653,7 +664,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           if constexpr (multi_d) jp += (int)(y > s.yu) - (int)(y < s.yl);
           if constexpr (three_d) kp += (int)(z > s.zu) - (int)(z < s.zl);
         } else {
-          xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);
+          xtoijk<NDIM>(M, Bp, x, y, z, ip, jp, kp);
         }
 
         if (!on_block(M, ip, jp, kp)) {
