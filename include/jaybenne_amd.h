@@ -238,6 +238,28 @@ jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *
 jb_status jb_unpack_incoming(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm,
                              const int64_t *records_dev, int64_t nrecords);
 
+/* Ghost-zone / halo refresh of one host field -- the role of Parthenon's boundary exchange on
+ * the host's FillGhost fields (mcblock.cpp:66-70: density, internal_energy; driven from
+ * McblockDriver::HostUpdateTasks, mcblock_driver.cpp:58-74, after UpdateFluid changed
+ * internal_energy).  `field` names a member of jb_mesh_view (enum jb_field).
+ *   jb_gather_cells: out_dev[i] = field[blk_dev[i]][cell_dev[i]] -- packs the cells another rank
+ *     asked for (cell = flat index into the block's [nk][nj][ni] array, ghosts included).
+ *   jb_fill_cells: field[dst_blk_dev[i]][dst_cell_dev[i]] = mean of nsamples (a power of two)
+ *     source values, summed pairwise (exact when the samples are equal); source s of destination
+ *     i is field[src_blk_dev[i*nsamples+s]][src_cell_dev[i*nsamples+s]], or, when that src_blk is
+ *     -1, remote_dev[src_cell_dev[i*nsamples+s]] (values received from other ranks).
+ * Sources must not be destinations of the same call. */
+typedef enum jb_field {
+  JB_FIELD_RHO = 0, JB_FIELD_SIE = 1, JB_FIELD_U = 2, JB_FIELD_FLECK = 3, JB_FIELD_TALLY = 4,
+  JB_FIELD_EDELTA = 5
+} jb_field;
+jb_status jb_gather_cells(jb_context *ctx, jb_mesh *mesh, int field, int64_t n,
+                          const int32_t *blk_dev, const int32_t *cell_dev, double *out_dev);
+jb_status jb_fill_cells(jb_context *ctx, jb_mesh *mesh, int field, int64_t n, int nsamples,
+                        const int32_t *dst_blk_dev, const int32_t *dst_cell_dev,
+                        const int32_t *src_blk_dev, const int32_t *src_cell_dev,
+                        const double *remote_dev);
+
 /* EstimateTimestepMesh(md) -- jaybenne.hpp:75, jaybenne.cpp:271-275 */
 double jb_estimate_timestep(const jb_context *ctx);
 

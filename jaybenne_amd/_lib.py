@@ -46,6 +46,7 @@ class Scattering(C.Structure):
                 ("apm", C.c_double)]
 
 
+FIELD_IDS = {"rho": 0, "sie": 1, "u": 2, "fleck": 3, "tally": 4, "edelta": 5}   # enum jb_field
 FIELD_NAMES = ("rho", "sie", "u", "fleck", "tally", "edelta", "src_ew", "src_num", "P1", "P2", "P3")
 
 
@@ -116,6 +117,8 @@ PROTOTYPES = {
     "jb_remove_marked_particles": (_int, [_vp, C.POINTER(SwarmView)]),
     "jb_pack_outgoing": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, _i64, _int, _vp, _i64, _vp]),
     "jb_unpack_incoming": (_int, [_vp, _vp, C.POINTER(SwarmView), _vp, _i64]),
+    "jb_gather_cells": (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp]),
+    "jb_fill_cells": (_int, [_vp, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "jb_estimate_timestep": (_f64, [_vp]),
     "jb_radiation_step": (_int, [_vp, _vp, C.POINTER(SwarmView), _f64, _f64,
                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), _vp]),

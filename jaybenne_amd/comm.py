@@ -93,3 +93,31 @@ class Comm:
         if nrecv == 0:
             return None
         return recv.to(out_device)
+
+    # -- field halo exchange (jaybenne_amd/halo.py)
+    def exchange_int64_lists(self, lists) -> list:
+        """lists[r]: int64 array for rank r.  Returns what every rank addressed to this one, as
+        a list indexed by source rank (set-up time only)."""
+        counts = np.array([len(a) for a in lists], dtype=np.int64)
+        recv_counts = self.exchange_counts(counts)
+        send = torch.from_numpy(np.ascontiguousarray(np.concatenate(lists) if len(lists) else
+                                                     np.zeros(0, dtype=np.int64))).to(self.device)
+        recv = torch.empty(int(recv_counts.sum()), dtype=torch.int64, device=self.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=[int(c) for c in recv_counts],
+                               input_split_sizes=[int(c) for c in counts], group=self.group)
+        out = recv.cpu().numpy()
+        bounds = np.concatenate(([0], np.cumsum(recv_counts)))
+        return [out[bounds[r]:bounds[r + 1]] for r in range(self.nranks)]
+
+    def exchange_values(self, send: torch.Tensor, send_counts: np.ndarray, recv: torch.Tensor,
+                        recv_counts: np.ndarray) -> None:
+        """All-to-all-v of float64 values with split sizes known to both sides (static plan);
+        ``recv`` is filled in place (device tensors with RCCL, staged through the host with gloo)."""
+        s = send.to(self.device).contiguous()
+        r = recv if recv.device == self.device else torch.empty(recv.shape, dtype=recv.dtype,
+                                                                 device=self.device)
+        dist.all_to_all_single(r, s, output_split_sizes=[int(c) for c in recv_counts],
+                               input_split_sizes=[int(c) for c in send_counts], group=self.group)
+        if r is not recv:
+            recv.copy_(r)
+

@@ -693,6 +693,60 @@ extern "C" jb_status jb_unpack_incoming(jb_context *ctx, jb_mesh *mesh, jb_swarm
 }
 
 // ------------------------------------------------------------------------------------------------
+static double *const *field_table(const DevMesh &M, int field) {
+  switch (field) {
+    case JB_FIELD_RHO: return M.rho;
+    case JB_FIELD_SIE: return M.sie;
+    case JB_FIELD_U: return M.u;
+    case JB_FIELD_FLECK: return M.fleck;
+    case JB_FIELD_TALLY: return M.tally;
+    case JB_FIELD_EDELTA: return M.edelta;
+    default: return nullptr;
+  }
+}
+
+extern "C" jb_status jb_gather_cells(jb_context *ctx, jb_mesh *mesh, int field, int64_t n,
+                                     const int32_t *blk_dev, const int32_t *cell_dev,
+                                     double *out_dev) {
+  if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  double *const *F = field_table(mesh->dm, field);
+  if (!F) return fail(JB_ERR_INVALID, "jb_gather_cells: unknown field %d", field);
+  if (n < 0) return fail(JB_ERR_INVALID, "negative cell count");
+  if (n == 0) return JB_COMPLETE;
+  if (!blk_dev || !cell_dev || !out_dev) return fail(JB_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(k_gather_cells, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, F,
+                     (long long)n, blk_dev, cell_dev, out_dev);
+  JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_fill_cells(jb_context *ctx, jb_mesh *mesh, int field, int64_t n,
+                                   int nsamples, const int32_t *dst_blk_dev,
+                                   const int32_t *dst_cell_dev, const int32_t *src_blk_dev,
+                                   const int32_t *src_cell_dev, const double *remote_dev) {
+  if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  double *const *F = field_table(mesh->dm, field);
+  if (!F) return fail(JB_ERR_INVALID, "jb_fill_cells: unknown field %d", field);
+  if (n < 0) return fail(JB_ERR_INVALID, "negative cell count");
+  if (n == 0) return JB_COMPLETE;
+  if (!dst_blk_dev || !dst_cell_dev || !src_blk_dev || !src_cell_dev)
+    return fail(JB_ERR_INVALID, "null argument");
+#define JB_FILL(NS)                                                                              \
+  hipLaunchKernelGGL(k_fill_cells<NS>, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, F,   \
+                     (long long)n, dst_blk_dev, dst_cell_dev, src_blk_dev, src_cell_dev, remote_dev)
+  switch (nsamples) {
+    case 1: JB_FILL(1); break;
+    case 2: JB_FILL(2); break;
+    case 4: JB_FILL(4); break;
+    case 8: JB_FILL(8); break;
+    default: return fail(JB_ERR_INVALID, "jb_fill_cells: nsamples must be 1, 2, 4 or 8");
+  }
+#undef JB_FILL
+  JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
+// ------------------------------------------------------------------------------------------------
 // RadiationStep for a mesh held entirely by this rank: the task list of jaybenne.cpp:104-138 with
 // the iterate-sublist collapsed to one launch (every block crossing is resolved in flight).
 extern "C" jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm,

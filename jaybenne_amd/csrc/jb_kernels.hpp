@@ -957,4 +957,34 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// Ghost-zone / halo refresh of a host field (see jb_gather_cells / jb_fill_cells in the header).
+__global__ void __launch_bounds__(kBlock)
+    k_gather_cells(double *const *F, long long n, const int *blk, const int *cell, double *out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = F[blk[i]][cell[i]];
+}
+
+template <int NS>
+__global__ void __launch_bounds__(kBlock)
+    k_fill_cells(double *const *F, long long n, const int *dst_blk, const int *dst_cell,
+                 const int *src_blk, const int *src_cell, const double *remote) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    double v[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int sb = src_blk[i * NS + s];
+      const int sc = src_cell[i * NS + s];
+      v[s] = sb >= 0 ? F[sb][sc] : remote[sc];
+    }
+#pragma unroll
+    for (int w = NS; w > 1; w >>= 1)
+#pragma unroll
+      for (int s = 0; s < w / 2; ++s) v[s] = v[2 * s] + v[2 * s + 1];
+    F[dst_blk[i]][dst_cell[i]] = v[0] / (double)NS;
+  }
+}
+
 }  // namespace jb

@@ -155,8 +155,6 @@ class MeshData:
         # jaybenne.cpp:113-131).  HBM is plentiful: one ring costs a few GB at most.
         halo = (mesh.neighbours(self.gids, halo_rings) if (nranks > 1 and halo_rings > 0)
                 else np.zeros(0, dtype=np.int32))
-        if pkg.Param("do_feedback") and len(halo):
-            halo = np.zeros(0, dtype=np.int32)   # halo fields would need a per-cycle refresh
         self.resident_gids = np.concatenate([self.gids, halo]).astype(np.int32)
         self.owned_flags = np.concatenate([np.ones(self.nowned, dtype=np.int32),
                                            np.zeros(len(halo), dtype=np.int32)])
@@ -191,6 +189,7 @@ class MeshData:
         self.epoch = 0       # source-call counter (keys the per-cell rounding streams)
         self.events = 0
         self.kernel_events = None   # set to [] to time every transport launch with HIP events
+        self._exchange = None       # halo.FieldExchange, built on first use
         self._make_mesh_handle(owner)
 
     def reserve(self, nslots: int) -> None:
@@ -246,6 +245,14 @@ class MeshData:
         self._sync_stream()
         _lib.check(self.lib.jb_mesh_create(self.pkg.ctx, C.byref(v), C.byref(handle)))
         self.handle = handle
+
+    @property
+    def exchange(self):
+        """Ghost-zone / halo refresh plan for the host fields (built once per mesh)."""
+        if self._exchange is None:
+            from .halo import FieldExchange
+            self._exchange = FieldExchange(self)
+        return self._exchange
 
     def _sync_stream(self) -> None:
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -318,7 +325,7 @@ def SourcePhotons(md: MeshData, source_type: SourceType, t_start: float, dt: flo
         return TaskStatus.complete
     md._sync_stream()
     nper = np.zeros(md.nblocks, dtype=np.int32)
-    blocks_in_call = 1 if per_block else md.nblocks
+    blocks_in_call = 1 if per_block else md.nowned   # vmesh.GetNBlocks() of this rank's MeshData
     _lib.check(md.lib.jb_source_photons_count(pkg.ctx, md.handle, int(source_type), dt,
                                               blocks_in_call, md.epoch, nper.ctypes.data,
                                               md.prefix.data_ptr()))

@@ -190,12 +190,9 @@ class McblockDriver:
         """Ghost exchange of density / internal energy, sie = u / rho, new dt."""
         md = self.md
         if self.pkg.Param("do_feedback"):
-            if md.nranks > 1:
-                raise NotImplementedError("material feedback with several ranks needs a field "
-                                          "halo exchange, which is not built")
-            u = md.get_field("u")
-            self.mesh.fill_ghosts(u)
-            md.set_field("u", u)
+            # UpdateFluid changed internal_energy in the owned blocks' interiors: refresh the
+            # ghost zones and the halo copies (Parthenon's boundary exchange, mcblock_driver.cpp:68)
+            md.exchange.refresh("u")
         md.fields["sie"].copy_(md.fields["u"] / md.fields["rho"])
         self.dt = self.jb.EstimateTimestepMesh(md)
 

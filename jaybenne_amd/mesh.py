@@ -267,56 +267,76 @@ class Mesh:
         return np.full(self.field_shape, fill, dtype=np.float64)
 
     # ------------------------------------------------------------------ ghost zones
-    def fill_ghosts(self, f: np.ndarray) -> None:
-        """Fill ghost cells of a cell-centred field from the leaf that owns each ghost's
-        location: copy (same level), volume average (finer neighbour), injection (coarser
-        neighbour); periodic wrap or nearest-interior copy (outflow) at the domain boundary.
-        This stands in for Parthenon's ``AddBoundaryExchangeTasks`` on ``FillGhost`` fields
-        (reference mcblock_driver.cpp:68, mcblock.cpp:68-71).  Parthenon prolongates coarse
-        data with limited linear interpolation; injection differs from it only where the
-        field varies inside a coarse cell's neighbourhood."""
-        src = f.copy()
+    def ghost_sources(self, b: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """For every ghost cell of block ``b``: where its value comes from.  Returns
+        ``(dst, src_gid, src_cell)``: ``dst[n]`` is the ghost cell (flat index into the block's
+        ``[nk][nj][ni]`` array), ``src_gid[n, s]`` / ``src_cell[n, s]`` the interior cell of the
+        leaf block that owns sample point ``s`` (2^ndim points at +-dx/4 around the ghost's
+        centre): all equal for a same-level or coarser neighbour (copy / injection), the 2^ndim
+        children for a finer one (volume average).  Periodic wrap or nearest-interior copy
+        (outflow) at the domain boundary.  This is the static part of Parthenon's
+        ``AddBoundaryExchangeTasks`` on ``FillGhost`` fields (reference mcblock_driver.cpp:68,
+        mcblock.cpp:68-71); Parthenon prolongates coarse data with limited linear interpolation,
+        injection differs from it only where the field varies inside a coarse cell's
+        neighbourhood."""
         offs = list(itertools.product(*[(-0.25, 0.25) if d < self.ndim else (0.0,)
                                         for d in range(3)]))
-        for b in range(self.nblocks):
-            xs = [self.cell_centers(b, d) for d in range(3)]
-            K, J, I = np.meshgrid(np.arange(self.ntot_dim[2]), np.arange(self.ntot_dim[1]),
-                                  np.arange(self.ntot_dim[0]), indexing="ij")
-            ghost = np.zeros(K.shape, dtype=bool)
-            for d, idx in ((0, I), (1, J), (2, K)):
+        xs = [self.cell_centers(b, d) for d in range(3)]
+        K, J, I = np.meshgrid(np.arange(self.ntot_dim[2]), np.arange(self.ntot_dim[1]),
+                              np.arange(self.ntot_dim[0]), indexing="ij")
+        ghost = np.zeros(K.shape, dtype=bool)
+        for d, idx in ((0, I), (1, J), (2, K)):
+            if d < self.ndim:
+                ghost |= (idx < self.is_[d]) | (idx >= self.is_[d] + self.nx[d])
+        kk, jj, ii = K[ghost], J[ghost], I[ghost]
+        ni, nj = self.ntot_dim[0], self.ntot_dim[1]
+        dst = (kk * nj + jj) * ni + ii
+        src_gid = np.empty((len(ii), len(offs)), dtype=np.int64)
+        src_cell = np.empty((len(ii), len(offs)), dtype=np.int64)
+        if len(ii) == 0:
+            return dst.astype(np.int64), src_gid, src_cell
+        base = np.stack([xs[0][ii], xs[1][jj], xs[2][kk]], axis=1)
+        for q, o in enumerate(offs):
+            pt = base + np.asarray(o) * self.blk_dx[b]
+            for d in range(self.ndim):
+                ext = self.gmax[d] - self.gmin[d]
+                if self.mesh_bc[2 * d] == BC_PERIODIC:
+                    pt[:, d] = np.where(pt[:, d] < self.gmin[d], pt[:, d] + ext, pt[:, d])
+                else:
+                    pt[:, d] = np.maximum(pt[:, d], self.gmin[d] + 0.25 * self.blk_dx[b, d])
+                if self.mesh_bc[2 * d + 1] == BC_PERIODIC:
+                    pt[:, d] = np.where(pt[:, d] > self.gmax[d], pt[:, d] - ext, pt[:, d])
+                else:
+                    pt[:, d] = np.minimum(pt[:, d], self.gmax[d] - 0.25 * self.blk_dx[b, d])
+            nbk = self.find_block(pt)
+            c = []
+            for d in range(3):
                 if d < self.ndim:
-                    ghost |= (idx < self.is_[d]) | (idx >= self.is_[d] + self.nx[d])
-            if not ghost.any():
+                    cd = np.floor((pt[:, d] - self.blk_xmin[nbk, d]) / self.blk_dx[nbk, d])
+                    cd = np.clip(cd.astype(np.int64), 0, self.nx[d] - 1) + self.is_[d]
+                else:
+                    cd = np.zeros(len(ii), dtype=np.int64)
+                c.append(cd)
+            src_gid[:, q] = nbk
+            src_cell[:, q] = (c[2] * nj + c[1]) * ni + c[0]
+        return dst.astype(np.int64), src_gid, src_cell
+
+    def fill_ghosts(self, f: np.ndarray) -> None:
+        """Fill the ghost cells of a cell-centred field (whole mesh, host arrays) from the
+        source map of ``ghost_sources``; the samples are summed pairwise, which is exact when
+        they are equal (same-level or coarser neighbour)."""
+        if not f.flags.c_contiguous:
+            raise ValueError("fill_ghosts needs a C-contiguous field")
+        src = f.reshape(self.nblocks, -1).copy()
+        out = f.reshape(self.nblocks, -1)
+        for b in range(self.nblocks):
+            dst, gid, cell = self.ghost_sources(b)
+            if len(dst) == 0:
                 continue
-            kk, jj, ii = K[ghost], J[ghost], I[ghost]
-            base = np.stack([xs[0][ii], xs[1][jj], xs[2][kk]], axis=1)
-            samples = []
-            for o in offs:
-                p = base + np.asarray(o) * self.blk_dx[b]
-                for d in range(self.ndim):
-                    ext = self.gmax[d] - self.gmin[d]
-                    if self.mesh_bc[2 * d] == BC_PERIODIC:
-                        p[:, d] = np.where(p[:, d] < self.gmin[d], p[:, d] + ext, p[:, d])
-                    else:
-                        p[:, d] = np.maximum(p[:, d], self.gmin[d] + 0.25 * self.blk_dx[b, d])
-                    if self.mesh_bc[2 * d + 1] == BC_PERIODIC:
-                        p[:, d] = np.where(p[:, d] > self.gmax[d], p[:, d] - ext, p[:, d])
-                    else:
-                        p[:, d] = np.minimum(p[:, d], self.gmax[d] - 0.25 * self.blk_dx[b, d])
-                nbk = self.find_block(p)
-                cidx = []
-                for d in range(3):
-                    if d < self.ndim:
-                        c = np.floor((p[:, d] - self.blk_xmin[nbk, d]) / self.blk_dx[nbk, d])
-                        c = np.clip(c.astype(np.int64), 0, self.nx[d] - 1) + self.is_[d]
-                    else:
-                        c = np.zeros(len(ii), dtype=np.int64)
-                    cidx.append(c)
-                samples.append(src[nbk, cidx[2], cidx[1], cidx[0]])
-            # pairwise sum: exact when the samples are equal (same-level or coarser neighbour)
+            samples = [src[gid[:, q], cell[:, q]] for q in range(gid.shape[1])]
             while len(samples) > 1:
                 samples = [samples[q] + samples[q + 1] for q in range(0, len(samples), 2)]
-            f[b][ghost] = samples[0] / len(offs)
+            out[b, dst] = samples[0] / gid.shape[1]
 
     # ------------------------------------------------------------------ halo
     def neighbours(self, gids: Sequence[int], rings: int = 1) -> np.ndarray:

@@ -354,7 +354,9 @@ class Oracle:
     def RadiationStep(self, t_start: float, dt: float) -> None:
         """Task order of reference jaybenne.cpp:104-138."""
         self.UpdateDerivedTransportFields(dt)
-        self.SourcePhotons(SRC_EMISSION, t_start, dt)
+        # emission_blocks_in_call: blocks in the calling rank's MeshData (quirk of
+        # sourcing.cpp:68-69: the per-cell count scales with 1 / that number); None = whole mesh
+        self.SourcePhotons(SRC_EMISSION, t_start, dt, getattr(self, "emission_blocks_in_call", None))
         self.TransportPhotons(t_start, dt)
         self.RemoveMarkedParticles()
         assert self.CheckCompletion(t_start + dt) == 0

@@ -60,7 +60,9 @@ def run_oracle_cycles(O, pin, ncycles: int):
     t = 0.0
     for _ in range(ncycles):
         O.RadiationStep(t, dt)
-        # HostUpdateTasks: sie = u / rho (u only changes with do_feedback)
+        # HostUpdateTasks: ghost exchange of u, then sie = u / rho (u only changes with do_feedback)
+        if pin.GetOrAddBoolean("jaybenne", "do_feedback", True):
+            O.mesh.fill_ghosts(O.fields["u"])
         O.fields["sie"][...] = O.fields["u"] / O.fields["rho"]
         t += dt
     return t

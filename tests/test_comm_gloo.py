@@ -96,3 +96,88 @@ def test_two_rank_gloo_handoff():
         assert p.exitcode == 0
     res = dict(out.get(timeout=5) for _ in range(2))
     assert res == {0: "ok", 1: "ok"}
+
+
+# ------------------------------------------------------------------------------------------------
+class _StubMeshData:
+    """The attributes halo.FieldExchange reads from a MeshData, without a device."""
+
+    def __init__(self, mesh, rank, nranks, comm, halo_rings=1):
+        owner = np.asarray(mesh.owner)
+        self.mesh, self.rank, self.nranks, self.comm = mesh, rank, nranks, comm
+        self.device = torch.device("cpu")
+        self.gids = np.nonzero(owner == rank)[0].astype(np.int32)
+        halo = mesh.neighbours(self.gids, halo_rings) if nranks > 1 else np.zeros(0, dtype=np.int32)
+        self.resident_gids = np.concatenate([self.gids, halo]).astype(np.int32)
+        self.owned_flags = np.concatenate([np.ones(len(self.gids), dtype=np.int32),
+                                           np.zeros(len(halo), dtype=np.int32)])
+        self.local_index = np.full(mesh.nblocks, -1, dtype=np.int32)
+        self.local_index[self.resident_gids] = np.arange(len(self.resident_gids), dtype=np.int32)
+
+
+HALO_CASES = [("stepdiff", {"parthenon/mesh/nx1": 16, "parthenon/meshblock/nx1": 4}),   # 1-D, reflecting
+              ("stepdiff_smr", {"parthenon/mesh/nx1": 32, "parthenon/mesh/nx2": 16,
+                                "parthenon/meshblock/nx1": 8, "parthenon/meshblock/nx2": 8}),  # 2-D, 2 levels
+              ("inf", {"parthenon/mesh/nx1": 8, "parthenon/mesh/nx2": 8, "parthenon/mesh/nx3": 8,
+                       "parthenon/meshblock/nx1": 4, "parthenon/meshblock/nx2": 4,
+                       "parthenon/meshblock/nx3": 4})]                                  # 3-D, periodic
+
+
+def _halo_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import load_deck
+        from jaybenne_amd.comm import Comm
+        from jaybenne_amd.halo import FieldExchange
+        from jaybenne_amd.mesh import Mesh
+        comm = Comm()
+        for deck, ov in HALO_CASES:
+            mesh = Mesh.from_deck(load_deck(deck, ov))
+            mesh.partition(world)
+            md = _StubMeshData(mesh, rank, world, comm)
+            ex = FieldExchange(md)
+            # the truth: a global field with ghost zones filled by the single-process routine
+            rng = np.random.default_rng(7)
+            glob = rng.random(mesh.field_shape)
+            want = glob.copy()
+            mesh.fill_ghosts(want)
+            # this rank's copy: owned interiors only, everything else poisoned
+            mine = np.full((len(md.resident_gids),) + mesh.field_shape[1:], np.nan)
+            sl = mesh.interior()
+            nown = len(md.gids)
+            mine[:nown][sl] = glob[md.gids][sl]
+            # what refresh() does, with numpy standing in for the two kernels
+            flat = mine.reshape(mine.shape[0], -1)
+            send = torch.from_numpy(flat[ex.serve_blk.numpy(), ex.serve_cell.numpy()].copy())
+            assert not torch.isnan(send).any()            # only owned interior cells are served
+            remote = torch.empty(ex.nremote, dtype=torch.float64)
+            comm.exchange_values(send, ex.send_counts, remote, ex.recv_counts)
+            ex.refresh_numpy(mine, remote.numpy())
+            got_ok = np.array_equal(mine, want[md.resident_gids])
+            assert got_ok, (deck, rank, np.argwhere(mine != want[md.resident_gids])[:5])
+            assert ex.nremote > 0 and len(md.resident_gids) > nown
+        out.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        out.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_field_halo_exchange():
+    """Ghost zones and halo copies refreshed across two ranks equal the single-process ghost
+    fill bit for bit (1-D reflecting, 2-D two-level SMR, 3-D periodic)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = dict(out.get(timeout=5) for _ in range(2))
+    assert res == {0: "ok", 1: "ok"}

@@ -90,3 +90,71 @@ def test_two_ranks_equal_the_oracle(gpu_device, case, tmp_path):
         b = O.fields["tally"][p["gids"]][sl]
         np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)
     assert sum(int(p["events"][0]) for p in parts) == O.events
+
+
+FEEDBACK = dict(SMR, **{"jaybenne/num_particles": 30000, "jaybenne/do_emission": "true",
+                        "jaybenne/do_feedback": "true", "mcblock/opacity_model": "constant",
+                        "mcblock/opacity_constant_value": 20.0})
+
+
+def _feedback_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from jaybenne_amd import mcblock
+        from jaybenne_amd.comm import Comm
+        drv = mcblock.McblockDriver(load_deck("stepdiff_smr_hybrid", FEEDBACK), rank=rank,
+                                    nranks=world, comm=Comm(), device=torch.device("cuda", 0),
+                                    capacity_factor=8.0)
+        assert len(drv.md.resident_gids) > drv.md.nowned        # halo copies are in use
+        for _ in range(3):
+            drv.Step()
+        g = drv.md.get_swarm()
+        g["gblk"] = drv.md.gids[g["blk"]]
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), gids=drv.md.gids,
+                 u=drv.md.fields["u"].cpu().numpy(), resident=drv.md.resident_gids,
+                 tally=drv.md.get_field("tally"), fleck=drv.md.get_field("fleck"), **g)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_with_material_feedback(gpu_device, tmp_path):
+    """Absorbing / emitting hybrid IMC-DDMC problem on a two-level mesh with the material energy
+    fed back every cycle: internal_energy is refreshed in the ghost zones and in the halo copies
+    through jb_gather_cells / all-to-all / jb_fill_cells.  Cycle 1 is independent of the order
+    of the absorption atomics; afterwards u carries it in its last bits (1e-11 on attributes)."""
+    from oracle import orc
+    sys.path.insert(0, os.path.dirname(__file__))
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_feedback_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    pin = load_deck("stepdiff_smr_hybrid", FEEDBACK)
+    O, mesh, _ = make_oracle(pin, orc.MATH_PORTABLE, capacity_factor=8.0)
+    # the emission count per cell scales with 1 / (blocks in the calling rank's MeshData)
+    # (sourcing.cpp:68-69): 20 blocks over 2 ranks
+    O.emission_blocks_in_call = mesh.nblocks // 2
+    run_oracle_cycles(O, pin, 3)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    assert all(len(p["gids"]) == mesh.nblocks // 2 for p in parts)
+    ids = np.concatenate([p["id"] for p in parts])
+    order = np.argsort(ids)
+    oo = np.argsort(O.sw["id"][:O.n])
+    assert len(ids) == O.n and np.array_equal(ids[order], O.sw["id"][:O.n][oo])
+    for k in ("ip", "jp", "kp", "rng"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts])[order], O.sw[k][:O.n][oo]), k
+    for k in ("x", "y", "z", "vx", "vy", "vz", "t", "w", "e"):
+        got = np.concatenate([p[k] for p in parts])[order]
+        np.testing.assert_allclose(got, O.sw[k][:O.n][oo], rtol=1e-11, atol=0, err_msg=k)
+    for p in parts:
+        # owned blocks and halo copies alike, ghost zones included
+        np.testing.assert_allclose(p["u"], O.fields["u"][p["resident"]], rtol=1e-12, atol=0)
+        sl = mesh.interior()
+        np.testing.assert_allclose(p["fleck"][sl], O.fields["fleck"][p["gids"]][sl], rtol=1e-12)
+        np.testing.assert_allclose(p["tally"][sl], O.fields["tally"][p["gids"]][sl], rtol=1e-11)
