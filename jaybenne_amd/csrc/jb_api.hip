@@ -446,10 +446,19 @@ static void launch_transport(jb_context *ctx, const DevMesh &M, const DevSwarm &
 #define JB_LAUNCH(T, G)                                                                            \
   hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G>), dim3(g), dim3(kBlock), 0, ctx->stream, M,    \
                      ctx->dp, S, t_start, dt, first, last, ctx->counters_d)
-  if (tally && gray) JB_LAUNCH(true, true);
-  else if (tally) JB_LAUNCH(true, false);
-  else if (gray) JB_LAUNCH(false, true);
-  else JB_LAUNCH(false, false);
+  // gray opacity with kappa = 0 (opacity_model = none): sigma_a = rho * 0 in every cell
+  const bool noabs = gray && !DDMC && ctx->dp.kappa_a == 0.0;
+  if constexpr (!DDMC) {
+    if (noabs) {
+      if (tally) JB_LAUNCH(true, 2);
+      else JB_LAUNCH(false, 2);
+      return;
+    }
+  }
+  if (tally && gray) JB_LAUNCH(true, 1);
+  else if (tally) JB_LAUNCH(true, 0);
+  else if (gray) JB_LAUNCH(false, 1);
+  else JB_LAUNCH(false, 0);
 #undef JB_LAUNCH
 }
 

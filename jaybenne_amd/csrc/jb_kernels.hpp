@@ -342,7 +342,10 @@ enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
 #ifndef JB_DDMC_WAVES_PER_SIMD
 #define JB_DDMC_WAVES_PER_SIMD 3
 #endif
-template <int NDIM, bool DDMC, bool TALLY, bool GRAY>
+// GRAY: 0 = opacities evaluated per event from rho, sie (frequency dependent in general);
+// 1 = gray: per-cell mean free paths / DDMC records precomputed by UpdateDerivedTransportFields;
+// 2 = gray and no absorption opacity at all (IMC kernels only; see imc_step_core).
+template <int NDIM, bool DDMC, bool TALLY, int GRAY>
 __global__ void
 __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER_SIMD)
     k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
@@ -358,8 +361,9 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   }
   load_math_tables();  // (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
-  constexpr bool kFastGray = GRAY && !DDMC;
-  constexpr bool kPackedDdmc = GRAY && DDMC;
+  constexpr bool kFastGray = GRAY != 0 && !DDMC;
+  constexpr bool kNoAbs = GRAY == 2 && !DDMC;
+  constexpr bool kPackedDdmc = GRAY != 0 && DDMC;
   // DDMC kernels re-read the block geometry (10 cached doubles) at the top of every event pass
   // instead of carrying it in 26 registers per lane across the whole loop: that is what lets
   // three waves instead of two share a SIMD.
@@ -611,7 +615,8 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         if constexpr (kFastGray) {
           // per-cell mean free paths precomputed by k_fleck: two gathers instead of three, and
           // no division (same values: same operations on the same operands)
-          imc_step_core<NDIM>(s, f0[q], f1[q], rng);
+          if constexpr (kNoAbs) imc_step_core<NDIM, true>(s, 0.0, f1[q], rng);
+          else imc_step_core<NDIM, false>(s, f0[q], f1[q], rng);
         } else if constexpr (kPackedDdmc) {
           typedef double v4d __attribute__((ext_vector_type(4)));
           typedef const v4d __attribute__((address_space(1))) *grec;
@@ -625,7 +630,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
             ptcl_ddmc_albedo<NDIM>(s, rng);
             if (!s.is_rejected) resample = ddmc_step_event<NDIM, true>(s, rng);
           } else {
-            imc_step_core<NDIM>(s, f1[q], f2[q], rng);
+            imc_step_core<NDIM, false>(s, f1[q], f2[q], rng);
           }
         } else {
           const double rho = f0[q];
@@ -649,7 +654,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           } else {
             double lam_abs, lam_sc;
             imc_cell_mfp(s.ff, s.aa, s.ss, lam_abs, lam_sc);
-            imc_step_core<NDIM>(s, lam_abs, lam_sc, rng);
+            imc_step_core<NDIM, false>(s, lam_abs, lam_sc, rng);
           }
         }
         t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;

@@ -107,10 +107,16 @@ __device__ __forceinline__ void imc_cell_mfp(double ff, double aa, double ss, do
 }
 
 // reference transport_utils.hpp:118-159 -- the rest of one IMC tracking step, 2 draws
-template <int NDIM, class Rng>
+// NOABS: the material has no absorption opacity anywhere (opacity_model = none: sigma_a = 0, so
+// lam_abs = 1 / DBL_MIN = 4.5e307).  Then dx_abs = -lam_abs ln(xi) >= 4.5e307 * 2^-53 = 5e291
+// for every possible draw, never the smallest distance: the draw is consumed, its logarithm is
+// not evaluated, and is_absorbed is false -- the same results as the general path, bit for bit.
+template <int NDIM, bool NOABS = false, class Rng>
 __device__ __forceinline__ void imc_step_core(Step &s, double lam_abs, double lam_sc, Rng &rng) {
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
-  const double dx_abs = -lam_abs * m_log(rng.drand());
+  double dx_abs = 0.0;
+  if constexpr (NOABS) rng.skip();
+  else dx_abs = -lam_abs * m_log(rng.drand());
   const double dx_sc = -lam_sc * m_log(rng.drand());
   const double dx_end = s.vv * ((s.t_start + s.dt) - s.t);
   double dx_push = dmin(s.dx_push, dx_end);
@@ -129,7 +135,7 @@ __device__ __forceinline__ void imc_step_core(Step &s, double lam_abs, double la
     dx_push = (s.vz != 0.0) ? dmin(dx_push, d) : dx_push;
   }
 
-  s.is_absorbed = (dx_abs < dx_push) && (dx_abs < dx_sc);
+  s.is_absorbed = NOABS ? false : (dx_abs < dx_push) && (dx_abs < dx_sc);
   s.is_scattered = !s.is_absorbed && (dx_sc < dx_push);
 
   const double dt_push = (s.is_absorbed ? dx_abs : (s.is_scattered ? dx_sc : dx_push)) / s.vv;
@@ -155,7 +161,7 @@ template <int NDIM, class Rng>
 __device__ __forceinline__ void ptcl_transport_step(Step &s, Rng &rng) {
   double lam_abs, lam_sc;
   imc_cell_mfp(s.ff, s.aa, s.ss, lam_abs, lam_sc);
-  imc_step_core<NDIM>(s, lam_abs, lam_sc, rng);
+  imc_step_core<NDIM, false>(s, lam_abs, lam_sc, rng);
 }
 
 // Cyclic assignment (axis, axis+1, axis+2) <- (v1, v2, v3): the component order the reference

@@ -69,6 +69,8 @@ struct LcgRng {
     s = s * 6364136223846793005ull + 1442695040888963407ull;
     return u52_to_double(s >> 12);
   }
+  // consume one draw whose value cannot influence the result
+  __device__ __forceinline__ void skip() { s = s * 6364136223846793005ull + 1442695040888963407ull; }
 };
 
 // Replays a caller-supplied list of uniforms (debug entry points / golden-vector tests only).
@@ -82,6 +84,7 @@ struct TapeRng {
     ++ctr;
     return v;
   }
+  __device__ __forceinline__ void skip() { ++ctr; }
 };
 
 }  // namespace jb
