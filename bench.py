@@ -159,11 +159,11 @@ def main() -> None:
         achieved = k_bytes / k_time / 1e9 if k_time > 0 else 0.0
         fp64 = k_hist * ev_per_hist * FLOPS_PER_EVENT / k_time / 1e12 if k_time > 0 else 0.0
         # HBM bytes per launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
-        # passes of this very command; profiles/r01_c_hbm_traffic.json) -- valid for the workload
-        # and particle count they were collected on
+        # passes of this very command; profiles/r01_d_hbm_traffic_<workload>.json) -- valid for
+        # the workload and particle count they were collected on
         traffic = None
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", f"r01_d_hbm_traffic_{args.workload}.json")))
             if (tr["workload"] == args.workload and tr["particles_per_gpu"] == args.particles_per_gpu
                     and args.block_nx == 64 and args.gpus == 1):
                 traffic = tr["hbm_bytes_per_launch"]
@@ -177,11 +177,18 @@ def main() -> None:
             "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("" if args.workload == "c2" else f"[{args.workload}] ") +
-                                   "stepdiff pure-IMC, uniform 3-D mesh, "
-                                   f"{md.mesh.nblocks} meshblocks of {args.block_nx}^3 cells, "
-                                   f"{args.particles_per_gpu * args.gpus:.3g} particles, 1 cycle per step "
-                                   "(BASELINE.json configs[1] per GPU)",
+            "config": {"workload": {
+                "c2": "stepdiff pure-IMC, uniform 3-D mesh, "
+                      f"{md.mesh.nblocks} meshblocks of {args.block_nx}^3 cells, "
+                      f"{args.particles_per_gpu * args.gpus:.3g} particles, 1 cycle per step "
+                      "(BASELINE.json configs[1] per GPU)",
+                "c3": "[c3] stepdiff_ddmc (all-DDMC, tau_ddmc = 5), uniform 3-D mesh, "
+                      f"{md.mesh.nblocks} meshblocks of {args.block_nx}^3 cells, "
+                      f"{args.particles_per_gpu * args.gpus:.3g} particles, 1 cycle per step "
+                      "(BASELINE.json configs[2], SURVEY 8d C3b)",
+                "c3-1d": "[c3-1d] stepdiff_ddmc deck geometry (1-D, 128 cells, all-DDMC), "
+                         f"{args.particles_per_gpu * args.gpus:.3g} particles, 1 cycle per step "
+                         "(SURVEY 8d C3a)"}[args.workload],
                        "blocks_per_gpu": md.nowned, "halo_blocks_per_gpu": md.nblocks - md.nowned, "particles_per_gpu": args.particles_per_gpu,
                        "parallelism": f"meshblocks over {args.gpus} rank(s), RCCL particle hand-off"},
             "events_per_s": events / wall,
@@ -190,17 +197,22 @@ def main() -> None:
             "events_per_history": ev_per_hist,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_transport<3,false,true,true>" if args.workload == "c2"
-                                   else "k_transport<NDIM,true,true,true>",
+                         "kernel": {"c2": "k_transport<3, false, true, 2>", "c3": "k_transport<3, true, true, 1>",
+                                    "c3-1d": "k_transport<1, true, true, 1>"}[args.workload],
                          "kernel_ms_avg": 1e3 * k_time / max(len(kt), 1),
                          "launches": len(kt),
                          "algorithmic_bytes_per_history": BYTES_PER_HISTORY + per_event * ev_per_hist,
                          "fp64_valu": {"achieved_tflops": fp64, "peak_tflops": FP64_VALU_PEAK_TF,
                                        "frac": fp64 / FP64_VALU_PEAK_TF,
                                        "note": "IMC regime is VALU-issue bound, not HBM bound (SURVEY "
-                                               "8d): PMC shows the SIMDs 98 % busy issuing VALU at 359 "
-                                               "instructions per 64-lane event, L2 hit rate 98.8 %, "
-                                               "162 GB/s of HBM traffic (profiles/r01_c_pmc_*.json)"}},
+                                               "8d): PMC shows the SIMDs 98 % busy issuing VALU at 316 "
+                                               "instructions per 64-lane event, L2 hit rate 99.4 %, "
+                                               "69 GB/s of HBM traffic (profiles/r01_d_pmc_c2_*.json)"
+                                       if args.workload == "c2" else
+                                               "DDMC regime (3-D, 1e8 particles): SIMDs 58 % busy issuing "
+                                               "VALU at 3 waves/SIMD, 428 instructions per 64-lane event at "
+                                               "71 % lane use, L2 hit rate 84 %, 690 GB/s of HBM traffic "
+                                               "(profiles/r01_d_pmc_c3_*.json)"}},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.block_nx)
