@@ -1,0 +1,80 @@
+"""The collectives of jaybenne_amd/comm.py on the production backend (RCCL, ``"nccl"``), as far as
+one GPU allows: a one-rank process group.  Checks that every call shape the multi-rank path uses
+is accepted by RCCL for these dtypes (int64 / float64 all-to-all-v with empty and non-empty
+splits, flat all-gather, all-reduce) and that a driver handed a communicator steps correctly.
+Multi-rank semantics are covered with gloo (tests/test_comm_gloo.py, tests/test_gpu_multirank.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        from helpers import load_deck
+        from jaybenne_amd import mcblock
+        from jaybenne_amd.comm import RECORD_WORDS, Comm
+        comm = Comm(device=device)
+        assert comm.device.type == "cuda" and comm.nranks == 1
+        assert comm.allreduce_sum_int64(np.array([3, 4], dtype=np.int64)).tolist() == [3, 4]
+        assert comm.allreduce_max_float(2.5) == 2.5
+        assert comm.gather_count_matrix(np.array([0], dtype=np.int64)).tolist() == [[0]]
+        assert comm.exchange_counts(np.array([7], dtype=np.int64)).tolist() == [7]
+        # nothing to send and nothing to receive: the all-to-all-v with empty splits
+        assert comm.exchange_records(None, np.zeros(1, dtype=np.int64), device) is None
+        empty = torch.empty((0, RECORD_WORDS), dtype=torch.int64, device=device)
+        assert comm.exchange_records(empty, np.zeros(1, dtype=np.int64), device,
+                                     recv_counts=np.zeros(1, dtype=np.int64)) is None
+        # float64 / int64 payloads (a rank may address values to itself in exchange_values)
+        send = torch.arange(5, dtype=torch.float64, device=device) + 0.5
+        recv = torch.empty(5, dtype=torch.float64, device=device)
+        comm.exchange_values(send, np.array([5]), recv, np.array([5]))
+        assert torch.equal(send, recv)
+        got = comm.exchange_int64_lists([np.arange(4, dtype=np.int64)])
+        assert got[0].tolist() == [0, 1, 2, 3]
+        comm.barrier()
+        # a driver with a communicator (one rank) equals a driver without
+        ov = {"jaybenne/num_particles": 4000}
+        a = mcblock.McblockDriver(load_deck("stepdiff", ov), rank=0, nranks=1, comm=comm, device=device)
+        b = mcblock.McblockDriver(load_deck("stepdiff", ov), device=device)
+        for d in (a, b):
+            d.Step()
+        ga, gb = a.md.get_swarm(), b.md.get_swarm()
+        for k in ga:
+            assert np.array_equal(ga[k], gb[k]), k
+        out.put("ok")
+    except Exception as e:  # pragma: no cover
+        out.put(repr(e))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_one_rank_group(gpu_device):
+    sys.path.insert(0, os.path.dirname(__file__))
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(_free_port(), out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert out.get(timeout=5) == "ok"
