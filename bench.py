@@ -51,6 +51,13 @@ def make_deck(ngpus: int, particles_per_gpu: int, block_nx: int = 64, workload: 
             ov[f"parthenon/mesh/nx{d + 1}"] = 128
             ov[f"parthenon/meshblock/nx{d + 1}"] = 64
         return load_deck("stepdiff_ddmc", ov)
+    if workload == "c4":     # stepdiff_smr.in as shipped: 2-D, 20 blocks of 32^2, 2 levels, pure IMC
+        return load_deck("stepdiff_smr", {"jaybenne/num_particles": particles_per_gpu * ngpus})
+    if workload == "c5":     # stepdiff_smr_hybrid.in + a nested level-2 region
+        pin = load_deck("stepdiff_smr_hybrid", {"jaybenne/num_particles": particles_per_gpu * ngpus})
+        pin.load_string("<parthenon/static_refinement2>\nlevel = 2\nx1min = -0.125\nx1max = 0.125\n"
+                        "x2min = -0.125\nx2max = 0.125\nx3min = -0.25\nx3max = 0.25\n")
+        return pin
     nb = block_grid(ngpus)
     ov = {"jaybenne/num_particles": particles_per_gpu * ngpus}
     for d in range(3):
@@ -90,7 +97,7 @@ def main() -> None:
     ap.add_argument("--block-nx", type=int, default=64)
     ap.add_argument("--cpu-sample", type=int, default=2_500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3-1d"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3-1d", "c4", "c5"],
                     help="c2 = headline (BASELINE configs[1]); c3* = DDMC side measurements")
     args = ap.parse_args()
 
@@ -188,7 +195,13 @@ def main() -> None:
                       "(BASELINE.json configs[2], SURVEY 8d C3b)",
                 "c3-1d": "[c3-1d] stepdiff_ddmc deck geometry (1-D, 128 cells, all-DDMC), "
                          f"{args.particles_per_gpu * args.gpus:.3g} particles, 1 cycle per step "
-                         "(SURVEY 8d C3a)"}[args.workload],
+                         "(SURVEY 8d C3a)",
+                "c4": "[c4] stepdiff_smr as shipped (2-D, 2 levels, pure IMC), "
+                      f"{md.mesh.nblocks} meshblocks, {args.particles_per_gpu * args.gpus:.3g} particles "
+                      "(BASELINE.json configs[3])",
+                "c5": "[c5] stepdiff_smr_hybrid + nested level-2 region (2-D, 3 levels, IMC/DDMC hybrid), "
+                      f"{md.mesh.nblocks} meshblocks, {args.particles_per_gpu * args.gpus:.3g} particles "
+                      "(BASELINE.json configs[4])"}[args.workload],
                        "blocks_per_gpu": md.nowned, "halo_blocks_per_gpu": md.nblocks - md.nowned, "particles_per_gpu": args.particles_per_gpu,
                        "parallelism": f"meshblocks over {args.gpus} rank(s), RCCL particle hand-off"},
             "events_per_s": events / wall,
@@ -198,7 +211,8 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": {"c2": "k_transport<3, false, true, 2>", "c3": "k_transport<3, true, true, 1>",
-                                    "c3-1d": "k_transport<1, true, true, 1>"}[args.workload],
+                                    "c3-1d": "k_transport<1, true, true, 1>", "c4": "k_transport<2, false, true, 2>",
+                                    "c5": "k_transport<2, true, true, 1>"}[args.workload],
                          "kernel_ms_avg": 1e3 * k_time / max(len(kt), 1),
                          "launches": len(kt),
                          "algorithmic_bytes_per_history": BYTES_PER_HISTORY + per_event * ev_per_hist,

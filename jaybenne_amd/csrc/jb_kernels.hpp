@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 // once per history or once per block crossing: relocation of particles that left their block
 // (swarm boundary conditions, destination-block lookup, DDMC block-face resampling), DDMC census
 // resampling, write-back, tallies, and handing the next particles to idle lanes.  The event loop
-// runs until kServiceAfter lanes have left it; keeping the rare, long code paths out of it keeps
+// runs until enough lanes have left it (see kServiceBudget); keeping the rare, long code paths out of it keeps
 // its 64 lanes on one instruction stream.
 //
 // Particles are dealt from 8 queues, each over one contiguous eighth of the (cell-ordered) swarm
@@ -330,11 +330,8 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 #ifndef JB_TRANSPORT_WAVES_PER_SIMD
 #define JB_TRANSPORT_WAVES_PER_SIMD 1
 #endif
-#ifndef JB_SERVICE_AFTER
-#define JB_SERVICE_AFTER 4
-#endif
-#ifndef JB_SERVICE_AFTER_DDMC
-#define JB_SERVICE_AFTER_DDMC 24
+#ifndef JB_SERVICE_BUDGET
+#define JB_SERVICE_BUDGET 144
 #endif
 
 enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
@@ -371,7 +368,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
 #define JB_RELOAD_BLOCK DDMC
 #endif
   constexpr bool kReloadBlock = JB_RELOAD_BLOCK;
-  constexpr int kServiceAfter = DDMC ? JB_SERVICE_AFTER_DDMC : JB_SERVICE_AFTER;
+  constexpr int kServiceBudget = JB_SERVICE_BUDGET;
   const double vv = P.c;
   const double t_end = t_start + dt;  // the reference re-evaluates t_start + dt: same double
   const int lane = threadIdx.x & 63;
@@ -587,16 +584,18 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
       if (__ballot(ls != LS_IDLE) != 0ull || more) continue;  // pending service / more to load
       break;
     }
-    // leave the event loop once kServiceAfter lanes have left it (while the queues still hold
-    // particles every lane is running here, so this is 64 - kServiceAfter + 1)
-    int thresh = running - kServiceAfter + 1;
-    if (thresh < 1) thresh = 1;
+    // Leave the event loop when the lane-passes idled away by lanes that have dropped out of it
+    // add up to the price of a service phase (kServiceBudget lane-passes): with long IMC histories
+    // that is after ~4 lanes have left, with short DDMC histories after ~24, and a hybrid deck
+    // finds its own balance.
+    int waste = 0;
 
     // ================================ EVENTS =================================
     // (no `continue` / `break` below: every lane must reach the ballot of the loop condition)
 #ifdef JB_TIMING
     { const unsigned long long now = __builtin_readcyclecounter(); cyc_sv += now - cyc_mark; cyc_mark = now; }
 #endif
+    int thresh = 1;
     while (__popcll(__ballot(ls == LS_RUN)) >= thresh) {
       ++c_pass;
       if (ls == LS_RUN) {
@@ -691,6 +690,8 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           if (!(t < t_end)) ls = LS_DONE;                    // census
         }
       }
+      waste += running - __popcll(__ballot(ls == LS_RUN));
+      if (waste >= kServiceBudget) thresh = 65;  // wave-uniform: ends the loop
     }
   }
 
