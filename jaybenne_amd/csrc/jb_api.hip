@@ -447,13 +447,11 @@ static void launch_transport(jb_context *ctx, const DevMesh &M, const DevSwarm &
   hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G>), dim3(g), dim3(kBlock), 0, ctx->stream, M,    \
                      ctx->dp, S, t_start, dt, first, last, ctx->counters_d)
   // gray opacity with kappa = 0 (opacity_model = none): sigma_a = rho * 0 in every cell
-  const bool noabs = gray && !DDMC && ctx->dp.kappa_a == 0.0;
-  if constexpr (!DDMC) {
-    if (noabs) {
-      if (tally) JB_LAUNCH(true, 2);
-      else JB_LAUNCH(false, 2);
-      return;
-    }
+  const bool noabs = gray && ctx->dp.kappa_a == 0.0;
+  if (noabs) {
+    if (tally) JB_LAUNCH(true, 2);
+    else JB_LAUNCH(false, 2);
+    return;
   }
   if (tally && gray) JB_LAUNCH(true, 1);
   else if (tally) JB_LAUNCH(true, 0);

@@ -341,7 +341,8 @@ enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
 #endif
 // GRAY: 0 = opacities evaluated per event from rho, sie (frequency dependent in general);
 // 1 = gray: per-cell mean free paths / DDMC records precomputed by UpdateDerivedTransportFields;
-// 2 = gray and no absorption opacity at all (IMC kernels only; see imc_step_core).
+// 2 = gray and no absorption opacity at all (see imc_step_core; in a DDMC kernel it applies to
+//     the IMC steps of a hybrid deck).
 template <int NDIM, bool DDMC, bool TALLY, int GRAY>
 __global__ void
 __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER_SIMD)
@@ -359,7 +360,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   load_math_tables();  // (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   constexpr bool kFastGray = GRAY != 0 && !DDMC;
-  constexpr bool kNoAbs = GRAY == 2 && !DDMC;
+  constexpr bool kNoAbs = GRAY == 2;
   constexpr bool kPackedDdmc = GRAY != 0 && DDMC;
   // DDMC kernels re-read the block geometry (10 cached doubles) at the top of every event pass
   // instead of carrying it in 26 registers per lane across the whole loop: that is what lets
@@ -629,7 +630,8 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
             ptcl_ddmc_albedo<NDIM>(s, rng);
             if (!s.is_rejected) resample = ddmc_step_event<NDIM, true>(s, rng);
           } else {
-            imc_step_core<NDIM, false>(s, f1[q], f2[q], rng);
+            if constexpr (kNoAbs) imc_step_core<NDIM, true>(s, 0.0, f2[q], rng);
+            else imc_step_core<NDIM, false>(s, f1[q], f2[q], rng);
           }
         } else {
           const double rho = f0[q];
