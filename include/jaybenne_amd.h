@@ -278,7 +278,8 @@ jb_status jb_debug_seed_state(jb_context *ctx, uint32_t seed, uint32_t domain, u
                               uint64_t *state);
 jb_status jb_debug_draw_stream(jb_context *ctx, uint64_t state, int n, double *out_host,
                                uint64_t *final_state);
-/* which: 0 log, 1 sin, 2 cos, 3 acos, 4 sqrt, 5 reciprocal */
+/* which: 0 log, 1 sin, 2 cos, 3 acos, 4 sqrt, 5 reciprocal, 6 lean sqrt, 7 lean x[i] / x[i+1],
+ * 8 lean x[i] / c */
 jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n, double *out_host);
 /* step functions on a tape of uniforms.  st: jb_debug_step record (see below); which:
  * 0 ptcl_transport_step, 1 ptcl_ddmc_step, 2 ptcl_ddmc_albedo */

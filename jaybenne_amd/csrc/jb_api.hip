@@ -63,6 +63,8 @@ struct jb_mesh {
   int nranks_seen = 1;
 };
 
+__global__ void k_rcp_refined(double b, double *out) { *out = m_rcp_refined(b); }
+
 extern "C" const char *jb_last_error(void) { return g_err; }
 extern "C" const char *jb_version(void) { return "jaybenne_amd 0.1 (gfx950)"; }
 
@@ -128,6 +130,11 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   JB_HIP(hipMalloc(&ctx->counters_d, kCounterWords * sizeof(unsigned long long)));
   JB_HIP(hipMemset(ctx->counters_d, 0, kCounterWords * sizeof(unsigned long long)));
   JB_HIP(hipHostMalloc(&ctx->counters_h, kCounterWords * sizeof(unsigned long long)));
+  // the refined reciprocal of c that the step functions divide with (jb_math.hpp, m_div_r): one
+  // device evaluation, so that it is the v_rcp_f64-seeded value the kernels would compute
+  hipLaunchKernelGGL(k_rcp_refined, dim3(1), dim3(1), 0, 0, ctx->dp.c, (double *)ctx->counters_d);
+  JB_HIP(hipMemcpy(&ctx->dp.rc, ctx->counters_d, sizeof(double), hipMemcpyDeviceToHost));
+  JB_HIP(hipMemset(ctx->counters_d, 0, sizeof(double)));
   *out = ctx;
   return JB_COMPLETE;
 }
@@ -842,7 +849,10 @@ __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
     case 2: m_sincos(x[i], s, c); out[i] = c; break;
     case 3: out[i] = m_acos(x[i]); break;
     case 4: out[i] = sqrt(x[i]); break;
-    default: out[i] = 1.0 / x[i]; break;
+    case 5: out[i] = 1.0 / x[i]; break;
+    case 6: out[i] = m_sqrt(x[i]); break;
+    case 7: out[i] = m_div(x[i], x[(i + 1) % n]); break;
+    default: out[i] = m_div_r(x[i], 2.99792458e10, m_rcp_refined(2.99792458e10)); break;
     }
   }
 }
@@ -850,7 +860,7 @@ __global__ void k_dbg_step(int which, jb_debug_step *d, const double *tape, int 
   load_math_tables();
   TapeRng rng(tape, ntape);
   Step s;
-  s.t_start = d->t_start; s.dt = d->dt; s.ff = d->ff; s.aa = d->aa; s.ss = d->ss; s.vv = d->vv;
+  s.t_start = d->t_start; s.dt = d->dt; s.ff = d->ff; s.aa = d->aa; s.ss = d->ss; s.vv = d->vv; s.rvv = m_rcp_refined(d->vv);
   s.dx_push = d->dx_push;
   s.ffaa = s.ff * s.aa;
   s.sig = s.aa + s.ss;

@@ -40,6 +40,7 @@ struct DevParams {
   int use_ddmc, do_feedback;
   double tau_ddmc;
   double c, sb;       // speed of light, Stefan-Boltzmann
+  double rc;          // m_rcp_refined(c), evaluated on the device at jb_initialize
   double cv;          // IdealGas
   double kappa_a;     // Gray
   double kappa_s, apm;  // GrayS

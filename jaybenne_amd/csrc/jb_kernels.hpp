@@ -605,7 +605,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         Blk Bl;
         if constexpr (kReloadBlock) load_block(M, b, Bl);
         const Blk &Bp = kReloadBlock ? Bl : B;
-        s.t_start = t_start; s.dt = dt; s.vv = vv; s.dx_push = Bp.dx_push;
+        s.t_start = t_start; s.dt = dt; s.vv = vv; s.rvv = P.rc; s.dx_push = Bp.dx_push;
         cell_faces(s, Bp);
         const long long q = cidx(M, kp, jp, ip);
         s.t = t; s.x = x; s.y = y; s.z = z; s.vx = vx; s.vy = vy; s.vz = vz;

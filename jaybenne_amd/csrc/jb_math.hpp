@@ -58,6 +58,28 @@ __device__ __forceinline__ double m_sqrt(double x) {
   return fma(d1, h, g);
 }
 
+// IEEE division a / b without the range handling: the sequence the compiler emits for `a / b`
+// (v_rcp_f64 seed, two Newton steps on the reciprocal, quotient, one fused residual correction)
+// minus v_div_scale / v_div_fmas / v_div_fixup, which only act when an operand or the quotient
+// is denormal, the exponents are more than 2^768 apart, or b is 0 / inf / NaN.  Distances,
+// speeds and opacities are nowhere near that, so the result is the correctly rounded quotient,
+// bit-identical to `/` (tests/test_gpu_parity.py::test_device_math_bit_exact).  b = 0 gives NaN,
+// not inf: callers that can see a zero divisor discard the quotient by a select.
+// With a divisor that is constant over a kernel the refined reciprocal is computed once.
+__device__ __forceinline__ double m_rcp_refined(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  double e = fma(-b, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-b, y, 1.0);
+  return fma(y, e, y);
+}
+__device__ __forceinline__ double m_div_r(double a, double b, double y) {  // y = m_rcp_refined(b)
+  const double q = a * y;
+  const double r = fma(-b, q, a);
+  return fma(r, y, q);
+}
+__device__ __forceinline__ double m_div(double a, double b) { return m_div_r(a, b, m_rcp_refined(b)); }
+
 __device__ __forceinline__ double m_log(double x) {  // x positive, finite, normal
   constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const uint64_t ix = (uint64_t)__double_as_longlong(x);

@@ -88,6 +88,7 @@ __device__ __forceinline__ double sample_planck_energy(Rng &rng, double sb, doub
 struct Step {
   double t_start, dt;
   double ff, aa, ss, vv, dx_push;
+  double rvv;        // m_rcp_refined(vv): set by the caller (a per-context constant)
   double ffaa, sig;  // ff * aa and aa + ss (DDMC functions read these; set by the caller)
   double xl, yl, zl, xu, yu, zu;
   double Px_l, Py_l, Pz_l, Px_u, Py_u, Pz_u;
@@ -123,22 +124,24 @@ __device__ __forceinline__ void imc_step_core(Step &s, double lam_abs, double la
   // distance to the face the velocity points at (transport_utils.hpp:123-133): one division per
   // axis, selected operands instead of two divergent branches
   {
-    const double d = s.vv * ((s.vx > 0.0 ? s.xu : s.xl) - s.x) / s.vx;
+    const double d = m_div(s.vv * ((s.vx > 0.0 ? s.xu : s.xl) - s.x), s.vx);
     dx_push = (s.vx != 0.0) ? dmin(dx_push, d) : dx_push;
   }
   if (multi_d) {
-    const double d = s.vv * ((s.vy > 0.0 ? s.yu : s.yl) - s.y) / s.vy;
+    const double d = m_div(s.vv * ((s.vy > 0.0 ? s.yu : s.yl) - s.y), s.vy);
     dx_push = (s.vy != 0.0) ? dmin(dx_push, d) : dx_push;
   }
   if (three_d) {
-    const double d = s.vv * ((s.vz > 0.0 ? s.zu : s.zl) - s.z) / s.vz;
+    const double d = m_div(s.vv * ((s.vz > 0.0 ? s.zu : s.zl) - s.z), s.vz);
     dx_push = (s.vz != 0.0) ? dmin(dx_push, d) : dx_push;
   }
 
   s.is_absorbed = NOABS ? false : (dx_abs < dx_push) && (dx_abs < dx_sc);
   s.is_scattered = !s.is_absorbed && (dx_sc < dx_push);
 
-  const double dt_push = (s.is_absorbed ? dx_abs : (s.is_scattered ? dx_sc : dx_push)) / s.vv;
+  // (the refined reciprocal of the speed of light is computed once per context)
+  const double dt_push = m_div_r(s.is_absorbed ? dx_abs : (s.is_scattered ? dx_sc : dx_push), s.vv,
+                                 s.rvv);
 
   s.t += dt_push;
   s.x += s.vx * dt_push;

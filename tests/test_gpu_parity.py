@@ -101,6 +101,16 @@ def test_device_math_bit_exact(ctx):
     # IEEE sqrt and divide on the device are correctly rounded (the host's are)
     assert np.array_equal(_dev_math(ctx, 4, u), np.sqrt(u))
     assert np.array_equal(_dev_math(ctx, 5, u), 1.0 / u)
+    # the range-restricted sqrt and divide of jb_math.hpp are the same correctly rounded results
+    assert np.array_equal(_dev_math(ctx, 6, u), np.sqrt(u))
+    for scale_a, scale_b in ((1.0, 1.0), (3.0e8, 3.0e10), (1.0e-9, 1.0e-12), (40.0, 3.0e13)):
+        x = u[:100001].copy()
+        x[0::2] *= scale_a      # numerators: distances x speed, -log(xi)
+        x[1::2] *= scale_b      # denominators: velocity components, c x opacity
+        want = x / np.roll(x, -1)
+        assert np.array_equal(_dev_math(ctx, 7, x), want), (scale_a, scale_b)
+    d = np.concatenate([u * 1.0e-2, u * 1.0e4, [0.0]])
+    assert np.array_equal(_dev_math(ctx, 8, d), d / 2.99792458e10)
 
 
 # ------------------------------------------------------------------------------------------------
