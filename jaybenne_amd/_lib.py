@@ -150,6 +150,10 @@ def load():
                 f"{LIB_PATH} not found: the HIP extension has not been built "
                 "(run __graft_entry__.build() or make -C jaybenne_amd/csrc). "
                 "There is no CPU fallback for the product path.")
+        # PyTorch-ROCm ships its own HIP runtime; it has to be in the process before this library
+        # is, so that both resolve libamdhip64 to the same copy (two runtimes in one process do
+        # not see each other's devices or allocations)
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)
