@@ -140,6 +140,8 @@ def main() -> None:
 
     for _ in range(args.warmup):
         drv.Step()
+    if os.environ.get("JB_PHASE_TIMES"):     # diagnostic: per-phase wall time (adds syncs)
+        md.phase_times = {}
     sync_all()
     ev0 = md.events
     md.kernel_events = []
@@ -228,6 +230,8 @@ def main() -> None:
                                                "67 % lane use, L2 hit rate 82 %, 744 GB/s of HBM traffic "
                                                "(profiles/r01_e_pmc_c3_*.json)"}},
         }
+        if md.phase_times is not None:
+            out["phase_ms_per_step"] = {k: 1e3 * v / args.steps for k, v in md.phase_times.items()}
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.block_nx)
         print(json.dumps(out), flush=True)

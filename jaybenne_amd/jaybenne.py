@@ -9,6 +9,7 @@ stream and ``torch.distributed``; every field / particle update runs in the HIP 
 from __future__ import annotations
 
 import ctypes as C
+import time
 import enum
 import sys
 from typing import Dict, Optional
@@ -190,6 +191,7 @@ class MeshData:
         self.events = 0
         self.kernel_events = None   # set to [] to time every transport launch with HIP events
         self._exchange = None       # halo.FieldExchange, built on first use
+        self.phase_times = None     # set to {} to account wall time per phase of RadiationStep
         self._make_mesh_handle(owner)
 
     def reserve(self, nslots: int) -> None:
@@ -478,6 +480,27 @@ def _exchange(md: MeshData, first: int, last: int):
     return nrecv, total
 
 
+class _Phase:
+    """Optional wall-clock accounting of the phases of RadiationStep (``md.phase_times = {}`` to
+    switch it on; each phase then ends with a device synchronisation, so leave it off when
+    measuring throughput)."""
+
+    def __init__(self, md, name):
+        self.md, self.name = md, name
+
+    def __enter__(self):
+        if self.md.phase_times is not None:
+            torch.cuda.synchronize(self.md.device)
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if self.md.phase_times is not None:
+            torch.cuda.synchronize(self.md.device)
+            self.md.phase_times[self.name] = (self.md.phase_times.get(self.name, 0.0)
+                                              + time.perf_counter() - self.t0)
+        return False
+
+
 def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
     """One radiation cycle: the task list of ``jaybenne::RadiationStep`` (reference
     jaybenne.cpp:68-151) for this rank's blocks.
@@ -490,34 +513,39 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
     pkg = md.pkg
     use_ddmc = bool(pkg.Param("use_ddmc"))
     transport = TransportPhotons_DDMC if use_ddmc else TransportPhotons
-    UpdateDerivedTransportFields(md, dt)
-    SourcePhotons(md, SourceType.emission, t_start, dt)
-    # (the ddmc_face_prob ghost exchange of jaybenne.cpp:108-110 has no consumer: every face the
-    # transport and resampling kernels read belongs to the block itself)
-    md._sync_stream()
-    _lib.check(md.lib.jb_zero_energy_tally(pkg.ctx, md.handle))
-    before = md.stats()
+    with _Phase(md, "derived+source"):
+        UpdateDerivedTransportFields(md, dt)
+        SourcePhotons(md, SourceType.emission, t_start, dt)
+        # (the ddmc_face_prob ghost exchange of jaybenne.cpp:108-110 has no consumer: every face
+        # the transport and resampling kernels read belongs to the block itself)
+        md._sync_stream()
+        _lib.check(md.lib.jb_zero_energy_tally(pkg.ctx, md.handle))
+        before = md.stats()
     first = 0
     md.transport_iterations = 0
     for it in range(int(pkg.Param("max_transport_iterations"))):
         last = md.n
-        transport(md, t_start, dt, first, last, fuse_census_tally=True)
+        with _Phase(md, f"transport[{min(it, 2)}]"):
+            transport(md, t_start, dt, first, last, fuse_census_tally=True)
         md.transport_iterations += 1
         if md.nranks == 1:
             break
-        nrecv, moved = _exchange(md, first, last)
+        with _Phase(md, "exchange"):
+            nrecv, moved = _exchange(md, first, last)
         if moved == 0:
             break
         first = md.n - nrecv        # the arrivals, appended at the end of the swarm
         if use_ddmc and nrecv:
-            SampleDDMCBlockFace(md, first, md.n)
+            with _Phase(md, "block_face"):
+                SampleDDMCBlockFace(md, first, md.n)
     else:
         return TaskStatus.iterate
-    after = md.stats()
-    if md.nranks == 1 and after["n_outgoing"] != before["n_outgoing"]:
-        raise RuntimeError("particles left for another rank in a single-rank step")
-    if any(after[k] != before[k] for k in ("n_absorbed", "n_escaped", "n_outgoing")):
-        RemoveMarkedParticles(md)
-    md.events += after["n_events"] - before["n_events"]
-    UpdateFluid(md)
+    with _Phase(md, "compaction+fluid"):
+        after = md.stats()
+        if md.nranks == 1 and after["n_outgoing"] != before["n_outgoing"]:
+            raise RuntimeError("particles left for another rank in a single-rank step")
+        if any(after[k] != before[k] for k in ("n_absorbed", "n_escaped", "n_outgoing")):
+            RemoveMarkedParticles(md)
+        md.events += after["n_events"] - before["n_events"]
+        UpdateFluid(md)
     return TaskStatus.complete
