@@ -290,7 +290,12 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   D.lam_abs = nullptr;
   D.lam_sc = nullptr;
   D.ddmc_cell = nullptr;
-  if (ctx->opac.model == JB_OPAC_GRAY && ctx->scat.model == JB_SCAT_GRAY) {
+  // JB_PER_EVENT_OPACITY=1 keeps the general path -- EOS and opacities evaluated per event from
+  // rho, sie and the photon energy, as the reference does (transport.cpp:122-127) -- also for gray
+  // models; it is what a frequency-dependent opacity would run, and the tests exercise it
+  const char *general = getenv("JB_PER_EVENT_OPACITY");
+  const bool per_event = general && general[0] == '1';
+  if (!per_event && ctx->opac.model == JB_OPAC_GRAY && ctx->scat.model == JB_SCAT_GRAY) {
     const size_t per = (size_t)D.ntot;
     double *base = nullptr;
     hipError_t e = hipMalloc(&base, sizeof(double) * per * 2 * (size_t)v->nblocks);
