@@ -1,0 +1,14 @@
+import sys, time, json, os
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import torch
+import bench
+from jaybenne_amd import mcblock
+wl = sys.argv[1]; n = int(sys.argv[2]); steps = int(sys.argv[3])
+pin = bench.make_deck(1, n, 64, wl)
+drv = mcblock.McblockDriver(pin, device=torch.device("cuda", 0), capacity_factor=1.5)
+out = []
+for s in range(steps):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    drv.Step()
+    torch.cuda.synchronize(); out.append(round(1e3 * (time.perf_counter() - t0), 2))
+print(wl, out)
