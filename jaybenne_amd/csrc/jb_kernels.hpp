@@ -379,8 +379,12 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   int tried = 0;                   // queues found drained so far
   bool more = true;                // wave-uniform: some queue may still hold particles
   // DDMC: slots [chunk_pos, chunk_end) of the swarm are this wave's to deal out (wave-uniform);
-  // short DDMC histories claim 256 at a time (one contended atomic per ~10 service phases)
-  constexpr long long kChunk = 256;
+  // short DDMC histories claim 128 at a time (one contended atomic per ~5 service phases); larger
+  // chunks lengthen the tail of a hybrid launch whose IMC histories are ~1e3 events long
+#ifndef JB_DDMC_CHUNK
+#define JB_DDMC_CHUNK 128
+#endif
+  constexpr long long kChunk = JB_DDMC_CHUNK;
   long long chunk_pos = 0, chunk_end = 0;
 
   unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0, c_ev = 0;
