@@ -24,6 +24,9 @@ CASES = [
     ("stepdiff", {"parthenon/mesh/nx2": 8, "parthenon/mesh/nx3": 8, "parthenon/mesh/nx1": 16,
                   "parthenon/meshblock/nx1": 8, "parthenon/meshblock/nx2": 4,
                   "parthenon/meshblock/nx3": 4, "jaybenne/num_particles": 3000}, 1),
+    ("stepdiff_smr_ddmc", {"parthenon/mesh/nx1": 32, "parthenon/mesh/nx2": 16, "parthenon/mesh/nx3": 16,
+                           "parthenon/meshblock/nx1": 8, "parthenon/meshblock/nx2": 8,
+                           "parthenon/meshblock/nx3": 8, "jaybenne/num_particles": 40000}, 2),  # 3-D SMR DDMC
 ]
 
 

@@ -19,6 +19,10 @@ SMR_OVERRIDES = {"parthenon/mesh/nx1": 64, "parthenon/mesh/nx2": 32,
                  "parthenon/meshblock/nx1": 16, "parthenon/meshblock/nx2": 16}
 
 
+SMR3D = {"parthenon/mesh/nx1": 32, "parthenon/mesh/nx2": 16, "parthenon/mesh/nx3": 16,
+         "parthenon/meshblock/nx1": 8, "parthenon/meshblock/nx2": 8, "parthenon/meshblock/nx3": 8}
+
+
 @pytest.fixture(scope="module")
 def ctx(gpu_device):
     """A bare package context for the debug entry points."""
@@ -251,6 +255,10 @@ CASES = [
                        "parthenon/meshblock/nx1": 32, "parthenon/meshblock/nx2": 8,
                        "parthenon/meshblock/nx3": 8, "jaybenne/num_particles": 40000,
                        "jaybenne/tau_ddmc": 5.0}, 2),                          # 3-D DDMC, 16 blocks
+    ("stepdiff_smr_ddmc", dict(SMR3D, **{"jaybenne/num_particles": 40000}), 2),   # 3-D SMR (72 blocks,
+    # 2 levels), all DDMC: coarse -> fine crossings pick one of 4 fine faces (SampleFace3D)
+    ("stepdiff_smr_hybrid", dict(SMR3D, **{"jaybenne/num_particles": 30000,
+                                           "jaybenne/tau_ddmc": 20.0}), 1),      # 3-D SMR, coarse DDMC / fine IMC
 ]
 
 
