@@ -364,6 +364,30 @@ def test_infinite_medium_decks_bit_exact(gpu_device, deck, cycles):
     assert drv.md.events == O.events
 
 
+@pytest.mark.parametrize("deck,overrides", [
+    ("stepdiff", {"parthenon/swarm/ix1_bc": "outflow", "parthenon/swarm/ox1_bc": "outflow",
+                  "jaybenne/num_particles": 20000, "mcblock/scattering_constant_value": 20.0}),
+    ("stepdiff_ddmc", {"parthenon/swarm/ix1_bc": "outflow", "parthenon/swarm/ox1_bc": "outflow",
+                       "parthenon/swarm/ox2_bc": "outflow", "parthenon/mesh/nx2": 16,
+                       "parthenon/mesh/nx1": 32, "parthenon/meshblock/nx1": 16,
+                       "parthenon/meshblock/nx2": 8, "jaybenne/num_particles": 20000,
+                       "mcblock/scattering_constant_value": 400.0})])
+def test_outflow_boundaries_bit_exact(gpu_device, deck, overrides):
+    """Photons that leave through an `outflow` swarm boundary are removed (status ESCAPED,
+    compaction); the survivors equal the oracle's, 1-D IMC and 2-D DDMC."""
+    from oracle import orc
+    pin = load_deck(deck, overrides)
+    drv = _gpu_problem(pin, gpu_device)
+    O, _, _ = make_oracle(load_deck(deck, overrides), orc.MATH_PORTABLE)
+    n0 = drv.md.n
+    for _ in range(2):
+        drv.Step()
+    run_oracle_cycles(O, pin, 2)
+    assert drv.md.stats()["n_escaped"] > 100 and drv.md.n < n0
+    _compare_swarm_by_id(drv.md, O, exact=True)
+    _compare_fields(drv.md, O, ("tally",))
+
+
 def test_erf_gate_on_gpu(gpu_device):
     """The reference's own acceptance test (tst/stepdiff.py): 128 cells, 1 block, 1e5 particles,
     10 cycles, solution-weighted mean fractional error of energy_tally <= 0.05."""

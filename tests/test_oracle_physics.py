@@ -113,3 +113,21 @@ def test_infinite_medium_equilibrium(deck, cycles, capacity_factor, tol):
         ratio.append(float(O.fields["tally"][sl].mean()) / ur)
     assert abs(np.mean(ratio) - 1.0) < tol, ratio
     assert O.n > 0 and np.all(O.sw["t"][:O.n] >= cycles * dt * (1 - 1e-12))
+
+
+def test_outflow_boundary_removes_escaping_particles():
+    """Swarm boundary `outflow` (Parthenon's default swarm boundary; the decks override it with
+    jaybenne_reflecting): a photon that leaves the domain is gone.  Energy bookkeeping: what is
+    left plus what escaped is what was there (sigma_a = 0)."""
+    ov = {"parthenon/swarm/ix1_bc": "outflow", "parthenon/swarm/ox1_bc": "outflow",
+          "jaybenne/num_particles": 20000, "mcblock/scattering_constant_value": 20.0}
+    pin = load_deck("stepdiff", ov)
+    O, mesh, _ = make_oracle(pin, orc.MATH_LIBM, threads=4)
+    n0, e0 = O.n, O.sw["w"][:O.n].sum()
+    ids0 = set(O.sw["id"][:O.n].tolist())
+    run_oracle_cycles(O, pin, 2)
+    assert 0 < O.n < n0                                  # optically thin slab: many escape
+    assert set(O.sw["id"][:O.n].tolist()) <= ids0
+    x = O.sw["x"][:O.n]
+    assert np.all((x > mesh.gmin[0]) & (x < mesh.gmax[0]))
+    assert O.sw["w"][:O.n].sum() < e0
