@@ -515,8 +515,8 @@ def test_c_abi_error_paths(gpu_device):
     st = lib.jb_transport_photons_ddmc(md.pkg.ctx, md.handle, C.byref(md.sv), 0.0, 1e-11, 0, md.n, 0)
     assert st == _lib.JB_ERR_INVALID
     # capacity: arrivals that do not fit
-    rec = np.zeros((md.capacity, _lib.JB_RECORD_WORDS), dtype=np.int64)
     import torch
+    rec = np.zeros((md.capacity, _lib.JB_RECORD_WORDS), dtype=np.int64)
     t = torch.from_numpy(rec).to(gpu_device)
     st = lib.jb_unpack_incoming(md.pkg.ctx, md.handle, C.byref(md.sv), t.data_ptr(), md.capacity)
     assert st == _lib.JB_ERR_CAPACITY
@@ -524,6 +524,15 @@ def test_c_abi_error_paths(gpu_device):
         _lib.check(st)
     # bad face
     assert lib.jb_photon_reflect_bc(md.pkg.ctx, md.handle, C.byref(md.sv), 7) == _lib.JB_ERR_INVALID
+    # field refresh: unknown field, sample count that is not 1 / 2 / 4 / 8, empty request
+    idx = torch.zeros(4, dtype=torch.int32, device=gpu_device)
+    val = torch.zeros(4, dtype=torch.float64, device=gpu_device)
+    assert lib.jb_gather_cells(md.pkg.ctx, md.handle, 99, 4, idx.data_ptr(), idx.data_ptr(),
+                               val.data_ptr()) == _lib.JB_ERR_INVALID
+    assert lib.jb_fill_cells(md.pkg.ctx, md.handle, _lib.FIELD_IDS["u"], 1, 3, idx.data_ptr(),
+                             idx.data_ptr(), idx.data_ptr(), idx.data_ptr(), None) == _lib.JB_ERR_INVALID
+    assert lib.jb_fill_cells(md.pkg.ctx, md.handle, _lib.FIELD_IDS["u"], 0, 2, None, None, None,
+                             None, None) == _lib.JB_COMPLETE
     # unsupported opacity model is rejected at Initialize
     p, e = _lib.Params(num_particles=10, dt=1.0), _lib.Eos(model=0, gm1=0.6, cv=1.5)
     o, s = _lib.Opacity(model=1, kappa=0.0, c=3e10, sb=5.67e-5), _lib.Scattering(model=0, kappa_s=1.0, apm=1.0)
