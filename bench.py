@@ -83,9 +83,23 @@ def cpu_baseline(sample_particles: int, block_nx: int):
     t0 = time.perf_counter()
     O.RadiationStep(0.0, dt)
     wall = time.perf_counter() - t0
-    return {"value": n0 / wall, "unit": "particle-histories/s", "cores": threads, "kind": "port",
-            "sample": f"1 cycle of the same mesh with {n0} particles (OpenMP over particles, "
-                      f"{O.events / wall:.3e} events/s, {wall:.1f} s)"}
+    out = {"value": n0 / wall, "unit": "particle-histories/s", "cores": threads, "kind": "port",
+           "sample": f"1 cycle of the same mesh with {n0} particles (OpenMP over particles, "
+                     f"{O.events / wall:.3e} events/s, {wall:.1f} s)"}
+    # BASELINE configs[0] (the reference's own CPU-runnable case: stepdiff, 1-D,
+    # 128 cells in one block, 1e5 particles) on ONE thread -- the analogue of mcblock with one MPI
+    # rank on Kokkos Serial, the reference's default build
+    from helpers import load_deck
+    pin1 = load_deck("stepdiff", {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128})
+    O1, _, _ = make_oracle(pin1, orc.MATH_LIBM, threads=1)
+    n1 = O1.n
+    t0 = time.perf_counter()
+    O1.RadiationStep(0.0, pin1.GetReal("jaybenne", "dt"))
+    w1 = time.perf_counter() - t0
+    out["serial_c1"] = {"value": n1 / w1, "unit": "particle-histories/s", "cores": 1,
+                        "sample": f"configs[0]: 1 cycle, {n1} particles, 1 thread "
+                                  f"({O1.events / w1:.3e} events/s, {w1:.1f} s)"}
+    return out
 
 
 def main() -> None:
