@@ -399,6 +399,9 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   double t = 0, x = 0, y = 0, z = 0, vx = 0, vy = 0, vz = 0, ee = 0;
   Blk B;
   gcptr f0 = nullptr, f1 = nullptr, f2 = nullptr;  // this block's cell arrays
+  // deferred direction of the last DDMC leak (packed-record DDMC kernels; see ddmc_step_event)
+  int pend = -1;
+  double pz1 = 0.0, pz2 = 0.0;
 
   auto bind_block = [&](int blk) {
     load_block(M, blk, B);
@@ -458,6 +461,16 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
     }
     if (ls == LS_DONE) {
       if constexpr (kReloadBlock) load_block(M, b, B);
+      if constexpr (kPackedDdmc) {
+        if (pend >= 0 && !resample) {  // (absorbed right after a leak: the record still gets it)
+          Step s;
+          s.vv = vv; s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
+          s.vx = vx; s.vy = vy; s.vz = vz;
+          materialise_dir(s);
+          vx = s.vx; vy = s.vy; vz = s.vz;
+        }
+        pend = -1;
+      }
       if constexpr (DDMC) {
         if (resample) {  // transport_utils.hpp:265-276, once per history
           Step s;
@@ -615,6 +628,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         s.t = t; s.x = x; s.y = y; s.z = z; s.vx = vx; s.vy = vy; s.vz = vz;
         s.ip = ip; s.jp = jp; s.kp = kp;
         s.is_absorbed = false; s.is_scattered = false; s.is_rejected = false;
+        s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
         bool is_ddmc_step = false;
         if constexpr (kFastGray) {
           // per-cell mean free paths precomputed by k_fleck: two gathers instead of three, and
@@ -631,9 +645,10 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           is_ddmc_step = Bp.dx_push * s.sig > P.tau_ddmc;  // transport_ddmc.cpp:135
           if (is_ddmc_step) {
             s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
-            ptcl_ddmc_albedo<NDIM>(s, rng);
-            if (!s.is_rejected) resample = ddmc_step_event<NDIM, true>(s, rng);
+            ptcl_ddmc_albedo<NDIM, true>(s, rng);
+            if (!s.is_rejected) resample = ddmc_step_event<NDIM, true, true>(s, rng);
           } else {
+            if (s.pend >= 0) materialise_dir(s);  // an IMC step reads the direction
             if constexpr (kNoAbs) imc_step_core<NDIM, true>(s, 0.0, f2[q], rng);
             else imc_step_core<NDIM, false>(s, f1[q], f2[q], rng);
           }
@@ -655,7 +670,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
             s.Pz_l = three_d ? M.P3[b][q] : 0.0;
             s.Pz_u = three_d ? M.P3[b][cidx(M, kp + 1, jp, ip)] : 0.0;
             ptcl_ddmc_albedo<NDIM>(s, rng);
-            if (!s.is_rejected) resample = ddmc_step_event<NDIM, false>(s, rng);
+            if (!s.is_rejected) resample = ddmc_step_event<NDIM, false, false>(s, rng);
           } else {
             double lam_abs, lam_sc;
             imc_cell_mfp(s.ff, s.aa, s.ss, lam_abs, lam_sc);
@@ -663,6 +678,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           }
         }
         t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
+        if constexpr (kPackedDdmc) { pend = s.pend; pz1 = s.pz1; pz2 = s.pz2; }
 
         // Xtoijk (transport.cpp:146)
         if constexpr (kFastGray) {
@@ -679,7 +695,15 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
 
         if (!on_block(M, ip, jp, kp)) {
           if constexpr (DDMC) {  // transport_ddmc.cpp:203-211: zero velocity flags a DDMC leak
-            const double vmask = (is_ddmc_step && multi_d && !s.is_rejected) ? 0.0 : 1.0;
+            const bool flag = is_ddmc_step && multi_d && !s.is_rejected;
+            if constexpr (kPackedDdmc) {
+              if (pend >= 0 && !flag) {  // (1-D: the direction travels with the particle)
+                materialise_dir(s);
+                vx = s.vx; vy = s.vy; vz = s.vz;
+              }
+              pend = -1;
+            }
+            const double vmask = flag ? 0.0 : 1.0;
             vx *= vmask; vy *= vmask; vz *= vmask;
           }
           ls = LS_RELOC;  // comm phase: in the service phase

@@ -30,19 +30,27 @@ __device__ __forceinline__ bool fuzzy_equal(double a, double b, double c, double
   return fabs(a - b) < c * eps;
 }
 
-// reference transport_utils.hpp:27-39 -- 2 draws
-template <class Rng>
-__device__ __forceinline__ void sample_face_iso_dir(double vv, Rng &rng, double &v1, double &v2,
-                                                    double &v3) {
-  const double mu = m_sqrt(rng.drand());
+// reference transport_utils.hpp:27-39 -- the arithmetic on its two uniforms
+__device__ __forceinline__ void face_iso_dir(double vv, double xi1, double xi2, double &v1,
+                                             double &v2, double &v3) {
+  const double mu = m_sqrt(xi1);
   const double om = 1.0 - mu * mu;  // exactly 0 when mu rounds to 1, else >= 2^-53
   const double nu = (om > 0.0) ? m_sqrt(om > 0.0 ? om : 1.0) : 0.0;
-  const double phi = kTwoPi * rng.drand();
+  const double phi = kTwoPi * xi2;
   double sn, cs;
   m_sincos(phi, sn, cs);
   v1 = vv * mu;
   v2 = vv * nu * cs;
   v3 = vv * nu * sn;
+}
+
+// reference transport_utils.hpp:27-39 -- 2 draws
+template <class Rng>
+__device__ __forceinline__ void sample_face_iso_dir(double vv, Rng &rng, double &v1, double &v2,
+                                                    double &v3) {
+  const double xi1 = rng.drand();
+  const double xi2 = rng.drand();
+  face_iso_dir(vv, xi1, xi2, v1, v2, v3);
 }
 
 // reference scattering.hpp:21-29 -- 2 draws
@@ -95,6 +103,10 @@ struct Step {
   double t, x, y, z, vx, vy, vz;
   int ip, jp, kp;
   bool is_absorbed, is_scattered, is_rejected;
+  // Deferred direction of a DDMC leak (LAZY): channel 0..5 (x-, x+, y-, y+, z-, z+) or -1, and
+  // the two uniforms sample_face_iso_dir drew for it.  vx, vy, vz are stale while pend >= 0.
+  int pend;
+  double pz1, pz2;
 };
 
 // reference transport_utils.hpp:115-117: mean free paths of a cell.  They depend on the cell
@@ -176,6 +188,17 @@ __device__ __forceinline__ void assign_cyclic(int axis, double v1, double v2, do
   vz = (axis == 0) ? v3 : (axis == 1 ? v2 : v1);
 }
 
+// The direction a DDMC leak through channel s.pend gives the particle
+// (transport_utils.hpp:217,235,253), from the uniforms drawn at the time of the leak.
+__device__ __forceinline__ void materialise_dir(Step &s) {
+  const int axis = s.pend >> 1;
+  const bool up = (s.pend & 1) != 0;
+  double v1, v2, v3;
+  face_iso_dir(up ? s.vv : -s.vv, s.pz1, s.pz2, v1, v2, v3);
+  assign_cyclic(axis, v1, v2, v3, s.vx, s.vy, s.vz);
+  s.pend = -1;
+}
+
 // reference transport_utils.hpp:163-277 -- one DDMC step
 // draws: 1 (time); event: +1 (channel), leak: +2 (direction); census: +5
 // The reference's six leak branches differ only in which face / axis they act on; here the
@@ -185,7 +208,11 @@ __device__ __forceinline__ void assign_cyclic(int axis, double v1, double v2, do
 // Returns true when the particle reached census without an event (the caller then resamples it).
 // LEAK_READY: s.P*_* already hold the leak opacities P_face / dx_d (lines 175-181), formed per
 // cell by k_ddmc_pack from the same operands, instead of the face probabilities.
-template <int NDIM, bool LEAK_READY = false, class Rng>
+// LAZY: a leak draws the two direction uniforms (same order) but only records them (s.pend,
+// s.pz1, s.pz2).  While a particle stays in DDMC cells its direction is never read -- the next
+// leak, the census resampling or a block crossing (zero-velocity flag) overwrites it -- so the
+// square roots and the sincos are evaluated only where a consumer appears (materialise_dir).
+template <int NDIM, bool LEAK_READY = false, bool LAZY = false, class Rng>
 __device__ __forceinline__ bool ddmc_step_event(Step &s, Rng &rng) {
   constexpr int multi_d = NDIM >= 2 ? 1 : 0, three_d = NDIM == 3 ? 1 : 0;
   const double rmin = DBL_MIN;
@@ -234,9 +261,15 @@ __device__ __forceinline__ bool ddmc_step_event(Step &s, Rng &rng) {
         s.x = (axis == 0) ? (up ? s.xu + eps * dx : s.xl - eps * dx) : s.xl + 0.5 * dx;
         s.y = (axis == 1) ? (up ? s.yu + eps * dy : s.yl - eps * dy) : s.yl + 0.5 * dy;
         s.z = (axis == 2) ? (up ? s.zu + eps * dz : s.zl - eps * dz) : s.zl + 0.5 * dz;
-        double v1, v2, v3;
-        sample_face_iso_dir(up ? s.vv : -s.vv, rng, v1, v2, v3);
-        assign_cyclic(axis, v1, v2, v3, s.vx, s.vy, s.vz);
+        if constexpr (LAZY) {
+          s.pz1 = rng.drand();
+          s.pz2 = rng.drand();
+          s.pend = ch;
+        } else {
+          double v1, v2, v3;
+          sample_face_iso_dir(up ? s.vv : -s.vv, rng, v1, v2, v3);
+          assign_cyclic(axis, v1, v2, v3, s.vx, s.vy, s.vz);
+        }
       }
     }
   }
@@ -268,13 +301,13 @@ __device__ __forceinline__ void ddmc_census_resample(Step &s, Rng &rng) {
 // reference transport_utils.hpp:163-277 -- one DDMC step (event part + census resampling)
 template <int NDIM, class Rng>
 __device__ __forceinline__ void ptcl_ddmc_step(Step &s, Rng &rng) {
-  if (ddmc_step_event<NDIM, false>(s, rng)) ddmc_census_resample(s, rng);
+  if (ddmc_step_event<NDIM, false, false>(s, rng)) ddmc_census_resample(s, rng);
 }
 
 // reference transport_utils.hpp:279-397 -- 0..3 draws.  The six face branches of the reference
 // (x-, x+, y-, y+, z-, z+, in that order, y / z gated by dimensionality) are folded into "which
 // face, if any" followed by one copy of the albedo arithmetic.
-template <int NDIM, class Rng>
+template <int NDIM, bool LAZY = false, class Rng>
 __device__ __forceinline__ void ptcl_ddmc_albedo(Step &s, Rng &rng) {
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   const double dx = s.xu - s.xl;
@@ -291,6 +324,9 @@ __device__ __forceinline__ void ptcl_ddmc_albedo(Step &s, Rng &rng) {
   else if (three_d && fuzzy_equal(s.z, s.zu, dz, tol)) face = 5;
 
   if (face >= 0) {
+    if constexpr (LAZY) {
+      if (s.pend >= 0) materialise_dir(s);  // the albedo reads the normal velocity component
+    }
     const int axis = face >> 1;
     const double sgn = (face & 1) ? -1.0 : 1.0;  // +1 lower face, -1 upper face
     // (copies first: `c ? s.a : s.b` on members is an lvalue conditional, i.e. a select of
