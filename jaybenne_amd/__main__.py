@@ -26,6 +26,11 @@ def main(argv=None) -> int:
     ap.add_argument("--tolerance", type=float, default=None,
                     help="pass/fail bound on the chosen error (0.05 stepdiff, 0.3 SMR decks in the reference)")
     ap.add_argument("--comparison", default="weighted_mean", choices=["mean", "pointwise", "weighted_mean"])
+    ap.add_argument("--transverse-average", action="store_true",
+                    help="average the tally over cells of equal x before comparing (uniform meshes)")
+    ap.add_argument("--match-total-energy", action="store_true",
+                    help="with --transverse-average: scale the solution to the tally's total energy "
+                         "(fewer than one source particle per cell under-samples the energy)")
     ap.add_argument("--output", default=None, help="write tally / coordinates to this .npz")
     ap.add_argument("overrides", nargs="*", help="block/key=value")
     args = ap.parse_args(argv)
@@ -67,7 +72,9 @@ def main(argv=None) -> int:
               f"{float(np.mean(np.asarray(tally)[drv.mesh.interior()])) / float(solution(0.0, 0.0)):.4f}")
     else:
         solution = analysis.ur_solution
-    err = analysis.analytic_errors(drv.mesh, tally, drv.time, solution)
+    err = analysis.analytic_errors(drv.mesh, tally, drv.time, solution,
+                                   transverse_average=args.transverse_average,
+                                   match_total_energy=args.match_total_energy)
     print(f"Mean error:                     {err['mean_error']:.2e}")
     print(f"Mean fractional error:          {err['mean_frac_error']:.2e}")
     print(f"Mean weighted fractional error: {err['mean_frac_error_weighted']:.2e}")
