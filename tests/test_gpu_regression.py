@@ -86,3 +86,17 @@ def test_full_size_c2_profile(gpu_device, capsys):
                "--transverse-average", "--match-total-energy"] + ov)
     out = capsys.readouterr().out
     assert rc == 0 and "TEST PASSED" in out, out
+
+
+def test_full_size_c3_profile(gpu_device, capsys):
+    """BASELINE configs[2] (stepdiff_ddmc, 3-D 128^3 cells in 8 blocks, every step DDMC) with 2e7
+    photons, 10 cycles: plane-averaged profile against the analytic solution and the reference's
+    stepdiff gate."""
+    from jaybenne_amd.__main__ import main
+    ov = ["jaybenne/num_particles=20000000"]
+    for d in (1, 2, 3):
+        ov += [f"parthenon/mesh/nx{d}=128", f"parthenon/meshblock/nx{d}=64"]
+    rc = main(["-i", os.path.join(DECKS, "stepdiff_ddmc.in"), "--tolerance", "0.05",
+               "--transverse-average"] + ov)
+    out = capsys.readouterr().out
+    assert rc == 0 and "TEST PASSED" in out, out
