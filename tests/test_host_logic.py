@@ -219,3 +219,29 @@ def test_halo_ring_of_a_partition():
     m3 = Mesh(3, [64, 64, 64], [8, 8, 8], [-0.5] * 3, [0.5] * 3)
     own = np.nonzero(m3.partition(8) == 0)[0]
     assert len(m3.neighbours(own, 2)) > len(m3.neighbours(own, 1)) > 0
+
+
+def test_transverse_average_and_energy_matching():
+    """analysis.analytic_errors: plane averaging leaves an x-only field unchanged, removes
+    zero-mean transverse noise, and energy matching removes a global factor."""
+    from jaybenne_amd import analysis
+    mesh = Mesh.from_deck(load_deck("stepdiff", {"parthenon/mesh/nx1": 32, "parthenon/mesh/nx2": 8,
+                                                 "parthenon/mesh/nx3": 8, "parthenon/meshblock/nx1": 16,
+                                                 "parthenon/meshblock/nx2": 4, "parthenon/meshblock/nx3": 4}))
+    t = 3.0e-10
+    f = mesh.new_field()
+    for b in range(mesh.nblocks):
+        f[b] = analysis.ur_solution(t, mesh.cell_centers(b, 0))[None, None, :]
+    exact = analysis.analytic_errors(mesh, f, t, transverse_average=True)
+    assert exact["mean_frac_error_weighted"] < 1e-14
+    rng = np.random.default_rng(3)
+    noisy = f * (1.0 + 0.5 * (rng.random(f.shape) - 0.5))
+    assert analysis.analytic_errors(mesh, noisy, t)["mean_frac_error_weighted"] > 0.1
+    assert analysis.analytic_errors(mesh, noisy, t, transverse_average=True)["mean_frac_error_weighted"] < 0.03
+    scaled = analysis.analytic_errors(mesh, 0.6 * f, t, transverse_average=True)
+    assert scaled["mean_frac_error_weighted"] > 0.4
+    matched = analysis.analytic_errors(mesh, 0.6 * f, t, transverse_average=True, match_total_energy=True)
+    assert matched["mean_frac_error_weighted"] < 1e-14
+    smr = Mesh.from_deck(load_deck("stepdiff_smr"))
+    with pytest.raises(ValueError):
+        analysis.analytic_errors(smr, smr.new_field(1.0), t, transverse_average=True)
