@@ -19,6 +19,7 @@ SMR = {"parthenon/mesh/nx1": 64, "parthenon/mesh/nx2": 32,
        "parthenon/meshblock/nx1": 16, "parthenon/meshblock/nx2": 16}
 CASES = [
     ("stepdiff", {"jaybenne/num_particles": 4000}, 2),
+    ("stepdiff_ddmc", {"jaybenne/num_particles": 20000, "parthenon/meshblock/nx1": 25}, 2),  # 1-D DDMC, 4 blocks
     ("stepdiff_smr_ddmc", dict(SMR, **{"jaybenne/num_particles": 30000}), 2),
     ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 20000}, 1),
     ("stepdiff", {"parthenon/mesh/nx2": 8, "parthenon/mesh/nx3": 8, "parthenon/mesh/nx1": 16,
