@@ -1,0 +1,201 @@
+// jaybenne_amd.hpp -- C++ host-side mirror of the reference's package / task interface
+// (reference src/jaybenne/jaybenne.hpp:48-78) over the C ABI of jaybenne_amd.h.
+//
+// The reference is a C++ package driven by a C++ host application (src/mcblock).  This header
+// is what such a host includes: the task functions keep the reference's names, argument order
+// and TaskStatus results; PARTHENON_REQUIRE / PARTHENON_FAIL conditions surface as
+// jaybenne_amd::Error.  It needs nothing but the C ABI (no HIP headers, no Parthenon): the host
+// owns every device buffer and hands raw device pointers over, exactly as Parthenon's packs do
+// for the reference.  examples/mcblock_amd.cpp is a complete host application written on it;
+// jaybenne_amd/jaybenne.py is the same mirror in Python (and adds the multi-rank hand-off).
+//
+// Single rank only: RadiationStep here is the task list of jaybenne.cpp:104-138 for a mesh held
+// by one rank, where one transport launch resolves every block crossing in flight.
+#ifndef JAYBENNE_AMD_HPP_
+#define JAYBENNE_AMD_HPP_
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "jaybenne_amd.h"
+
+namespace jaybenne_amd {
+
+using Real = double;
+
+// parthenon::TaskStatus as the reference's tasks return it (jaybenne.cpp:34,55-56)
+enum class TaskStatus { complete, incomplete, iterate };
+enum class SourceType { thermal, emission };     // jaybenne.hpp:56
+enum class SourceStrategy { uniform, energy };   // jaybenne.hpp:55
+
+struct Error : std::runtime_error {
+  jb_status status;
+  Error(jb_status st, const std::string &what) : std::runtime_error(what), status(st) {}
+};
+
+inline TaskStatus Check(jb_status st) {
+  if (st < 0) throw Error(st, jb_last_error());
+  return st == JB_ITERATE ? TaskStatus::iterate
+                          : (st == JB_INCOMPLETE ? TaskStatus::incomplete : TaskStatus::complete);
+}
+
+// The StateDescriptor role (jaybenne.cpp:158-266): owns the package context; parameters by name.
+class StateDescriptor {
+ public:
+  StateDescriptor(const jb_params &p, const jb_opacity &opacity, const jb_scattering &scattering,
+                  const jb_eos &eos, int device = 0)
+      : params_(p) {
+    Check(jb_initialize(&p, &eos, &opacity, &scattering, device, &ctx_));
+  }
+  ~StateDescriptor() { jb_finalize(ctx_); }
+  StateDescriptor(const StateDescriptor &) = delete;
+  StateDescriptor &operator=(const StateDescriptor &) = delete;
+
+  jb_context *ctx() const { return ctx_; }
+  const jb_params &params() const { return params_; }
+  int seed() const { return jb_param_seed(ctx_); }  // Param<int>("seed"), jaybenne.cpp:187-190
+
+ private:
+  jb_context *ctx_ = nullptr;
+  jb_params params_;
+};
+
+// jaybenne::Initialize(pin, opacity, scattering, eos) -- jaybenne.hpp:50-52
+inline std::shared_ptr<StateDescriptor> Initialize(const jb_params &p, const jb_opacity &opacity,
+                                                   const jb_scattering &scattering,
+                                                   const jb_eos &eos, int device = 0) {
+  return std::make_shared<StateDescriptor>(p, opacity, scattering, eos, device);
+}
+
+// The MeshData<Real> + swarm role: what one rank's tasks operate on.  The host fills `view`
+// (host arrays of per-block DEVICE pointers) and `swarm` (device arrays it allocated);
+// `reserve(n)` is the host's pool growth (Swarm::AddEmptyParticles, sourcing.cpp:123-131): it
+// must leave swarm.capacity >= n with the first swarm.n particles preserved.
+class MeshData {
+ public:
+  MeshData(std::shared_ptr<StateDescriptor> pkg, const jb_mesh_view &view, int32_t *prefix_dev,
+           std::function<void(jb_swarm_view &, int64_t)> reserve)
+      : pkg_(std::move(pkg)), nblocks_(view.nblocks), prefix_dev_(prefix_dev),
+        reserve_(std::move(reserve)) {
+    Check(jb_mesh_create(pkg_->ctx(), &view, &mesh_));
+  }
+  ~MeshData() { jb_mesh_destroy(mesh_); }
+  MeshData(const MeshData &) = delete;
+  MeshData &operator=(const MeshData &) = delete;
+
+  StateDescriptor &pkg() const { return *pkg_; }
+  jb_context *ctx() const { return pkg_->ctx(); }
+  jb_mesh *mesh() const { return mesh_; }
+  int nblocks() const { return nblocks_; }
+  int32_t *prefix_dev() const { return prefix_dev_; }
+  void Reserve(int64_t n) {
+    if (n > swarm.capacity) reserve_(swarm, n);
+    if (n > swarm.capacity) throw Error(JB_ERR_CAPACITY, "swarm pool could not be grown");
+  }
+
+  jb_swarm_view swarm{};   // n, capacity and the device arrays
+  uint64_t next_id = 0;    // first unused random-stream id
+  uint32_t epoch = 0;      // source-call counter (keys the per-cell rounding streams)
+  int64_t events = 0;      // tracking events so far
+
+ private:
+  std::shared_ptr<StateDescriptor> pkg_;
+  jb_mesh *mesh_ = nullptr;
+  int nblocks_;
+  int32_t *prefix_dev_;
+  std::function<void(jb_swarm_view &, int64_t)> reserve_;
+};
+
+// ---- tasks (jaybenne.hpp:59-76) ----------------------------------------------------------------
+inline TaskStatus UpdateDerivedTransportFields(MeshData *md, const Real dt) {
+  return Check(jb_update_derived_transport_fields(md->ctx(), md->mesh(), dt));
+}
+
+// SourcePhotons<T, ST>(md, t_start, dt): per_block = the MeshBlockData instantiation used at
+// initialisation (one call per block, sourcing.cpp:68-69)
+inline TaskStatus SourcePhotons(MeshData *md, SourceType st, const Real t_start, const Real dt,
+                                bool per_block = false) {
+  const jb_params &p = md->pkg().params();
+  if (p.source_strategy == JB_STRATEGY_ENERGY)  // sourcing.cpp:38
+    throw Error(JB_ERR_INVALID, "Energy source strategy not implemented!");
+  if (st == SourceType::emission && !p.do_emission) return TaskStatus::complete;
+  const int type = st == SourceType::thermal ? JB_SOURCE_THERMAL : JB_SOURCE_EMISSION;
+  const int nb = md->nblocks();
+  std::vector<int32_t> nper(nb, 0);
+  Check(jb_source_photons_count(md->ctx(), md->mesh(), type, dt, per_block ? 1 : nb, md->epoch,
+                                nper.data(), md->prefix_dev()));
+  md->epoch += 1;
+  std::vector<int64_t> slot_base(nb);
+  std::vector<uint64_t> id_base(nb);
+  int64_t tot = 0;
+  for (int b = 0; b < nb; ++b) {
+    slot_base[b] = md->swarm.n + tot;
+    id_base[b] = md->next_id + (uint64_t)tot;
+    tot += nper[b];
+  }
+  md->Reserve(md->swarm.n + tot);
+  Check(jb_source_photons_fill(md->ctx(), md->mesh(), &md->swarm, type, t_start, dt, nper.data(),
+                               md->prefix_dev(), slot_base.data(), id_base.data()));
+  md->swarm.n += tot;
+  md->next_id += (uint64_t)tot;
+  return TaskStatus::complete;
+}
+
+inline TaskStatus TransportPhotons(MeshData *md, const Real t_start, const Real dt,
+                                   bool fuse_census_tally = false) {
+  return Check(jb_transport_photons(md->ctx(), md->mesh(), &md->swarm, t_start, dt, 0,
+                                    md->swarm.n, fuse_census_tally ? 1 : 0));
+}
+inline TaskStatus TransportPhotons_DDMC(MeshData *md, const Real t_start, const Real dt,
+                                        bool fuse_census_tally = false) {
+  return Check(jb_transport_photons_ddmc(md->ctx(), md->mesh(), &md->swarm, t_start, dt, 0,
+                                         md->swarm.n, fuse_census_tally ? 1 : 0));
+}
+inline TaskStatus SampleDDMCBlockFace(MeshData *md) {
+  return Check(jb_sample_ddmc_block_face(md->ctx(), md->mesh(), &md->swarm, 0, md->swarm.n));
+}
+inline TaskStatus CheckCompletion(MeshData *md, const Real t_end) {
+  int64_t unfinished = 0;
+  return Check(jb_check_completion(md->ctx(), &md->swarm, t_end, &unfinished));
+}
+inline TaskStatus EvaluateRadiationEnergy(MeshData *md) {
+  return Check(jb_evaluate_radiation_energy(md->ctx(), md->mesh(), &md->swarm));
+}
+inline TaskStatus UpdateFluid(MeshData *md) { return Check(jb_update_fluid(md->ctx(), md->mesh())); }
+inline Real EstimateTimestepMesh(MeshData *md) { return jb_estimate_timestep(md->ctx()); }
+
+// jaybenne::InitializeRadiation(mbd, is_thermal) -- jaybenne.cpp:570-578
+inline void InitializeRadiation(MeshData *md, bool is_thermal) {
+  if (is_thermal) SourcePhotons(md, SourceType::thermal, 0.0, 0.0, /*per_block=*/true);
+  EvaluateRadiationEnergy(md);
+}
+
+// jaybenne::RadiationStep(pmesh, t_start, dt) for one rank -- jaybenne.cpp:68-151
+inline TaskStatus RadiationStep(MeshData *md, const Real t_start, const Real dt) {
+  const jb_params &p = md->pkg().params();
+  UpdateDerivedTransportFields(md, dt);
+  SourcePhotons(md, SourceType::emission, t_start, dt);
+  Check(jb_zero_energy_tally(md->ctx(), md->mesh()));
+  jb_transport_stats before{}, after{};
+  Check(jb_get_transport_stats(md->ctx(), &before, 0));
+  if (p.use_ddmc) TransportPhotons_DDMC(md, t_start, dt, /*fuse_census_tally=*/true);
+  else TransportPhotons(md, t_start, dt, /*fuse_census_tally=*/true);
+  Check(jb_get_transport_stats(md->ctx(), &after, 0));
+  if (after.n_outgoing != before.n_outgoing)
+    throw Error(JB_ERR_INVALID, "particles left for another rank in a single-rank step");
+  if (after.n_absorbed != before.n_absorbed || after.n_escaped != before.n_escaped)
+    Check(jb_remove_marked_particles(md->ctx(), &md->swarm));
+  md->events += after.n_events - before.n_events;
+  if (CheckCompletion(md, t_start + dt) != TaskStatus::complete) return TaskStatus::iterate;
+  UpdateFluid(md);
+  return TaskStatus::complete;
+}
+
+}  // namespace jaybenne_amd
+
+#endif  // JAYBENNE_AMD_HPP_

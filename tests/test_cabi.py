@@ -81,3 +81,20 @@ def test_plain_c_program_links_and_gets_reference_style_errors(tmp_path):
     res = subprocess.run([str(exe)], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "jaybenne_amd" in res.stdout and "swarm occupancy" in res.stdout
+
+
+def test_cpp_mirror_header_is_self_contained():
+    """include/jaybenne_amd.hpp (the C++ host-side mirror of jaybenne.hpp:48-78) compiles with a
+    plain C++17 compiler: it needs the C ABI header only, no HIP, no Parthenon."""
+    import subprocess
+    src = "#include \"jaybenne_amd.hpp\"\nint main() { return (int)jaybenne_amd::TaskStatus::complete; }\n"
+    res = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++",
+                          "-I", os.path.join(ROOT, "include"), "-"], input=src, text=True,
+                         capture_output=True)
+    assert res.returncode == 0, res.stderr
+    text = open(os.path.join(ROOT, "include", "jaybenne_amd.hpp")).read()
+    for task in ("UpdateDerivedTransportFields", "SourcePhotons", "TransportPhotons",
+                 "TransportPhotons_DDMC", "SampleDDMCBlockFace", "CheckCompletion",
+                 "EvaluateRadiationEnergy", "UpdateFluid", "InitializeRadiation", "RadiationStep",
+                 "EstimateTimestepMesh", "Initialize"):
+        assert f" {task}(" in text, task

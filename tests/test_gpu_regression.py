@@ -100,3 +100,38 @@ def test_full_size_c3_profile(gpu_device, capsys):
                "--transverse-average"] + ov)
     out = capsys.readouterr().out
     assert rc == 0 and "TEST PASSED" in out, out
+
+
+@pytest.mark.parametrize("deck,overrides", [
+    ("stepdiff", ["parthenon/mesh/nx1=128", "parthenon/meshblock/nx1=64", "jaybenne/num_particles=20000"]),
+    ("stepdiff_ddmc", ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=8", "parthenon/mesh/nx3=8",
+                       "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=4",
+                       "parthenon/meshblock/nx3=4", "jaybenne/num_particles=30000"])])
+def test_native_cpp_host_application(gpu_device, tmp_path, deck, overrides):
+    """examples/mcblock_amd: the C++ host application on include/jaybenne_amd.hpp (deck parser,
+    uniform mesh, device buffers through the HIP runtime, cycle loop) -- no Python, no PyTorch in
+    that process.  Its particles and tally equal the Python driver's on the same deck."""
+    import subprocess
+    from helpers import ROOT, load_deck
+    from jaybenne_amd import mcblock
+    exe = os.path.join(ROOT, "examples", "mcblock_amd")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    dump = tmp_path / "native.bin"
+    res = subprocess.run([exe, "-i", os.path.join(DECKS, deck + ".in"), "--dump", str(dump)] + overrides,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    raw = dump.read_bytes()
+    ncell, n, events = np.frombuffer(raw, dtype=np.int64, count=3)
+    off = 24
+    tally = np.frombuffer(raw, dtype=np.float64, count=ncell, offset=off); off += 8 * ncell
+    ids = np.frombuffer(raw, dtype=np.uint64, count=n, offset=off); off += 8 * n
+    xs = np.frombuffer(raw, dtype=np.float64, count=n, offset=off)
+    drv = mcblock.McblockDriver(load_deck(deck, dict(o.split("=") for o in overrides)), device=gpu_device)
+    drv.Execute()
+    g = drv.md.get_swarm()
+    assert n == drv.md.n and events == drv.md.events
+    assert np.array_equal(np.sort(ids), np.sort(g["id"]))
+    assert np.array_equal(xs[np.argsort(ids)], g["x"][np.argsort(g["id"])])
+    want = drv.md.get_field("tally")[drv.mesh.interior()].ravel()
+    np.testing.assert_allclose(tally, want, rtol=1e-12, atol=0)
