@@ -1,6 +1,6 @@
 // mcblock_amd.cpp -- a native host application on the C++ mirror (include/jaybenne_amd.hpp):
-// what the reference's src/mcblock does around the jaybenne package, for uniform (single-level)
-// meshes on one GPU, with no Python and no PyTorch in the process.
+// what the reference's src/mcblock does around the jaybenne package, on one GPU, with no Python
+// and no PyTorch in the process.
 //
 //   mcblock_amd -i <deck> [block/key=value ...] [--tolerance X] [--dump file]
 //
@@ -12,9 +12,10 @@
 // of tst/stepdiff.py:33-46 (stepdiff) or a T0^4 (inf decks).  Exit code 0 iff the solution-
 // weighted mean fractional error is within --tolerance (when given).
 //
-// Not covered here (the Python driver jaybenne_amd/mcblock.py does them): static mesh
-// refinement, several ranks, material feedback (needs the ghost-zone refresh of
-// jaybenne_amd/halo.py).
+// Static mesh refinement (<parthenon/static_refinementN> regions, 2:1 balanced block tree in
+// Z-order) is built the way jaybenne_amd/mesh.py builds it, so all seven decks of the reference's
+// inputs/ run.  Not covered here (the Python driver jaybenne_amd/mcblock.py does them): several
+// ranks, and material feedback (needs the ghost-zone refresh of jaybenne_amd/halo.py).
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -24,7 +25,9 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <set>
 #include <sstream>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -235,7 +238,7 @@ int main(int argc, char **argv) {
       throw std::runtime_error("material feedback needs the ghost-zone refresh of the Python driver");
     auto pkg = jb::Initialize(p, opacity, scattering, eos, 0);
 
-    // ---- uniform mesh: blocks in Z-order, geometry as jaybenne_amd/mesh.py forms it ----------
+    // ---- block tree: leaves in Z-order, geometry as jaybenne_amd/mesh.py forms it ------------
     const std::string mb = "parthenon/mesh";
     int mesh_nx[3], nx[3], nroot[3], ndim = 1;
     double gmin[3], gmax[3];
@@ -249,8 +252,6 @@ int main(int argc, char **argv) {
       nroot[d] = mesh_nx[d] / nx[d];
       if (mesh_nx[d] > 1) ndim = d + 1;
     }
-    if (pin.GetOrAddString(mb, "refinement", "none") != "none")
-      throw std::runtime_error("static refinement: use the Python driver");
     const int ng = (int)pin.GetOrAddInteger(mb, "nghost", 2);
     auto bc_code = [&](const std::string &block, const std::string &key) {
       const std::string v = pin.GetOrAddString(block, key, "periodic");
@@ -259,31 +260,188 @@ int main(int argc, char **argv) {
       if (v == "outflow") return (int)JB_BC_OUTFLOW;
       throw std::runtime_error("unsupported boundary condition '" + v + "'");
     };
-    const int nb = nroot[0] * nroot[1] * nroot[2];
-    int bits = 1;
-    while ((1 << bits) < std::max({nroot[0], nroot[1], nroot[2]}) + 1) ++bits;
-    struct Loc { int l[3]; uint64_t key; };
-    std::vector<Loc> locs;
+    bool mesh_periodic[6];
+    for (int d = 0; d < 3; ++d) {
+      mesh_periodic[2 * d] = bc_code(mb, "ix" + std::to_string(d + 1) + "_bc") == JB_BC_PERIODIC;
+      mesh_periodic[2 * d + 1] = bc_code(mb, "ox" + std::to_string(d + 1) + "_bc") == JB_BC_PERIODIC;
+    }
+    struct Region { int level; double lo[3], hi[3]; };
+    std::vector<Region> regions;
+    if (pin.GetOrAddString(mb, "refinement", "none") == "static") {
+      for (int n = 1; pin.blocks.count("parthenon/static_refinement" + std::to_string(n)); ++n) {
+        const std::string rb = "parthenon/static_refinement" + std::to_string(n);
+        Region r;
+        r.level = (int)pin.GetInteger(rb, "level");
+        for (int d = 0; d < 3; ++d) {
+          r.lo[d] = pin.GetOrAddReal(rb, "x" + std::to_string(d + 1) + "min", gmin[d]);
+          r.hi[d] = pin.GetOrAddReal(rb, "x" + std::to_string(d + 1) + "max", gmax[d]);
+        }
+        regions.push_back(r);
+      }
+    }
+    struct Leaf {
+      int level, l[3];
+      bool operator<(const Leaf &o) const {
+        return std::tie(level, l[0], l[1], l[2]) < std::tie(o.level, o.l[0], o.l[1], o.l[2]);
+      }
+    };
+    auto bounds = [&](const Leaf &L, double lo[3], double hi[3]) {
+      for (int d = 0; d < 3; ++d) {
+        const int nbd = nroot[d] * (d < ndim ? (1 << L.level) : 1);
+        const double ext = gmax[d] - gmin[d];
+        lo[d] = gmin[d] + ext * ((double)L.l[d] / nbd);
+        hi[d] = gmin[d] + ext * ((double)(L.l[d] + 1) / nbd);
+      }
+    };
+    auto children = [&](const Leaf &L) {
+      std::vector<Leaf> out;
+      for (int c = 0; c < (1 << ndim); ++c) {
+        Leaf ch{L.level + 1, {L.l[0], L.l[1], L.l[2]}};
+        for (int d = 0; d < ndim; ++d) ch.l[d] = 2 * L.l[d] + ((c >> d) & 1);
+        out.push_back(ch);
+      }
+      return out;
+    };
+    std::set<Leaf> leaves;
     for (int k = 0; k < nroot[2]; ++k)
       for (int j = 0; j < nroot[1]; ++j)
-        for (int i = 0; i < nroot[0]; ++i) {
-          Loc L{{i, j, k}, 0};
-          L.key = Morton(L.l, bits);
-          locs.push_back(L);
+        for (int i = 0; i < nroot[0]; ++i) leaves.insert(Leaf{0, {i, j, k}});
+    int max_level = 0;
+    for (const auto &r : regions) max_level = std::max(max_level, r.level);
+    for (int target = 1; target <= max_level; ++target) {  // refine what overlaps a finer region
+      const std::vector<Leaf> snapshot(leaves.begin(), leaves.end());
+      for (const Leaf &L : snapshot) {
+        if (L.level != target - 1) continue;
+        double lo[3], hi[3];
+        bounds(L, lo, hi);
+        for (const auto &r : regions) {
+          if (r.level < target) continue;
+          bool overlap = true;
+          for (int d = 0; d < ndim; ++d) overlap = overlap && lo[d] < r.hi[d] && hi[d] > r.lo[d];
+          if (overlap) {
+            leaves.erase(L);
+            for (const Leaf &c : children(L)) leaves.insert(c);
+            break;
+          }
         }
+      }
+    }
+    // which leaf covers a block position of the finest level
+    auto finest_extent = [&](int lev, int d) { return nroot[d] * (d < ndim ? (1 << lev) : 1); };
+    auto build_leaf_grid = [&](int lev, std::vector<Leaf> &grid) {
+      const int e0 = finest_extent(lev, 0), e1 = finest_extent(lev, 1), e2 = finest_extent(lev, 2);
+      grid.assign((size_t)e0 * e1 * e2, Leaf{-1, {0, 0, 0}});
+      for (const Leaf &L : leaves) {
+        const int sft = lev - L.level;
+        int r0[3], r1[3];
+        for (int d = 0; d < 3; ++d) {
+          r0[d] = d < ndim ? L.l[d] << sft : 0;
+          r1[d] = d < ndim ? (L.l[d] + 1) << sft : 1;
+        }
+        for (int k = r0[2]; k < r1[2]; ++k)
+          for (int j = r0[1]; j < r1[1]; ++j)
+            for (int i = r0[0]; i < r1[0]; ++i) grid[((size_t)k * e1 + j) * e0 + i] = L;
+      }
+    };
+    for (bool changed = true; changed;) {  // 2:1 balance across faces, edges and corners
+      changed = false;
+      int ml = 0;
+      for (const Leaf &L : leaves) ml = std::max(ml, L.level);
+      std::vector<Leaf> grid;
+      build_leaf_grid(ml, grid);
+      const int e0 = finest_extent(ml, 0), e1 = finest_extent(ml, 1), e2 = finest_extent(ml, 2);
+      const int ext[3] = {e0, e1, e2};
+      const std::vector<Leaf> snapshot(leaves.begin(), leaves.end());
+      for (const Leaf &L : snapshot) {
+        if (L.level < 2) continue;
+        const int scale = 1 << (ml - L.level);
+        for (int oz = (ndim > 2 ? -1 : 0); oz <= (ndim > 2 ? 1 : 0) && !changed; ++oz)
+          for (int oy = (ndim > 1 ? -1 : 0); oy <= (ndim > 1 ? 1 : 0) && !changed; ++oy)
+            for (int ox = -1; ox <= 1 && !changed; ++ox) {
+              const int o[3] = {ox, oy, oz};
+              int q[3];
+              bool ok = true;
+              for (int d = 0; d < 3; ++d) {
+                int c = d < ndim ? (L.l[d] + o[d]) * scale : 0;
+                if (c < 0 || c >= ext[d]) {
+                  if (mesh_periodic[2 * d]) c = ((c % ext[d]) + ext[d]) % ext[d];
+                  else ok = false;
+                }
+                q[d] = c;
+              }
+              if (!ok) continue;
+              const Leaf nbl = grid[((size_t)q[2] * e1 + q[1]) * e0 + q[0]];
+              if (nbl.level < L.level - 1 && leaves.count(nbl)) {
+                leaves.erase(nbl);
+                for (const Leaf &c : children(nbl)) leaves.insert(c);
+                changed = true;
+              }
+            }
+        if (changed) break;
+      }
+    }
+    max_level = 0;
+    for (const Leaf &L : leaves) max_level = std::max(max_level, L.level);
+    const int nb = (int)leaves.size();
+    int bits = 1;
+    while ((1 << bits) < std::max({nroot[0], nroot[1], nroot[2]}) * (1 << max_level) + 1) ++bits;
+    struct Loc { Leaf leaf; uint64_t key; };
+    std::vector<Loc> locs;
+    for (const Leaf &L : leaves) {
+      int fl[3];
+      for (int d = 0; d < 3; ++d) fl[d] = d < ndim ? L.l[d] << (max_level - L.level) : 0;
+      locs.push_back(Loc{L, Morton(fl, bits)});
+    }
     std::sort(locs.begin(), locs.end(), [](const Loc &a, const Loc &b) { return a.key < b.key; });
+    int nleaf[3];
+    for (int d = 0; d < 3; ++d) nleaf[d] = finest_extent(max_level, d);
     std::vector<double> xmin(3 * nb), xmax(3 * nb), dx(3 * nb);
-    std::vector<int32_t> leaf_map(nb), owner(nb, 0), ident(nb), level(nb, 0), nbr_lev(6 * nb, 0);
+    std::vector<int32_t> leaf_map((size_t)nleaf[0] * nleaf[1] * nleaf[2]), owner(nb, 0), ident(nb),
+        level(nb, 0), nbr_lev(6 * nb, 0);
     for (int b = 0; b < nb; ++b) {
       ident[b] = b;
+      level[b] = locs[b].leaf.level;
+      double lo[3], hi[3];
+      bounds(locs[b].leaf, lo, hi);
       for (int d = 0; d < 3; ++d) {
-        const double ext = gmax[d] - gmin[d];
-        xmin[3 * b + d] = gmin[d] + ext * ((double)locs[b].l[d] / nroot[d]);
-        xmax[3 * b + d] = gmin[d] + ext * ((double)(locs[b].l[d] + 1) / nroot[d]);
-        dx[3 * b + d] = (xmax[3 * b + d] - xmin[3 * b + d]) / (double)nx[d];
+        xmin[3 * b + d] = lo[d];
+        xmax[3 * b + d] = hi[d];
+        dx[3 * b + d] = (hi[d] - lo[d]) / (double)nx[d];
       }
-      leaf_map[(locs[b].l[2] * nroot[1] + locs[b].l[1]) * nroot[0] + locs[b].l[0]] = b;
+      const int sft = max_level - level[b];
+      for (int k = (ndim > 2 ? locs[b].leaf.l[2] << sft : 0); k < (ndim > 2 ? (locs[b].leaf.l[2] + 1) << sft : 1); ++k)
+        for (int j = (ndim > 1 ? locs[b].leaf.l[1] << sft : 0); j < (ndim > 1 ? (locs[b].leaf.l[1] + 1) << sft : 1); ++j)
+          for (int i = locs[b].leaf.l[0] << sft; i < (locs[b].leaf.l[0] + 1) << sft; ++i)
+            leaf_map[((size_t)k * nleaf[1] + j) * nleaf[0] + i] = b;
     }
+    auto find_block = [&](const double pt[3]) {
+      int q[3];
+      for (int d = 0; d < 3; ++d) {
+        const double ln = (gmax[d] - gmin[d]) / nleaf[d];
+        q[d] = (int)std::floor((pt[d] - gmin[d]) / ln);
+        q[d] = std::min(std::max(q[d], 0), nleaf[d] - 1);
+      }
+      return leaf_map[((size_t)q[2] * nleaf[1] + q[1]) * nleaf[0] + q[0]];
+    };
+    for (int b = 0; b < nb; ++b)  // neighbour level per face; own level at a physical boundary
+      for (int d = 0; d < 3; ++d)
+        for (int side = 0; side < 2; ++side) {
+          int &out = nbr_lev[6 * b + 2 * d + side];
+          out = level[b];
+          if (d >= ndim) continue;
+          double pt[3];
+          for (int dd = 0; dd < 3; ++dd) {
+            const double fine = (gmax[dd] - gmin[dd]) / nleaf[dd];
+            pt[dd] = 0.5 * (xmin[3 * b + dd] + xmax[3 * b + dd]) + 0.25 * fine * (dd < ndim ? 1.0 : 0.0);
+          }
+          const double fine_d = (gmax[d] - gmin[d]) / nleaf[d];
+          pt[d] = side == 0 ? xmin[3 * b + d] - 0.25 * fine_d : xmax[3 * b + d] + 0.25 * fine_d;
+          if (pt[d] < gmin[d] || pt[d] > gmax[d]) {
+            if (!mesh_periodic[2 * d + side]) continue;
+            pt[d] += (gmax[d] - gmin[d]) * (side == 0 ? 1 : -1);
+          }
+          out = level[find_block(pt)];
+        }
     int is[3], ntot_dim[3];
     for (int d = 0; d < 3; ++d) {
       is[d] = d < ndim ? ng : 0;
@@ -330,7 +488,7 @@ int main(int argc, char **argv) {
     std::memset(&view, 0, sizeof view);
     view.ndim = ndim; view.ng = ng; view.nblocks = nb; view.nblocks_total = nb; view.rank = 0;
     for (int d = 0; d < 3; ++d) {
-      view.nx[d] = nx[d]; view.nleaf[d] = nroot[d]; view.gmin[d] = gmin[d]; view.gmax[d] = gmax[d];
+      view.nx[d] = nx[d]; view.nleaf[d] = nleaf[d]; view.gmin[d] = gmin[d]; view.gmax[d] = gmax[d];
       view.bc[2 * d] = bc_code("parthenon/swarm", "ix" + std::to_string(d + 1) + "_bc");
       view.bc[2 * d + 1] = bc_code("parthenon/swarm", "ox" + std::to_string(d + 1) + "_bc");
     }
@@ -352,8 +510,8 @@ int main(int argc, char **argv) {
     pool.Grow(md.swarm, (int64_t)(0.65 * (double)p.num_particles) + 2048);
 
     jb::InitializeRadiation(&md, initial_radiation == "thermal");
-    std::printf("problem %s: %d-D, %d meshblocks, %lld photons\n", problem_id.c_str(), ndim, nb,
-                (long long)md.swarm.n);
+    std::printf("problem %s: %d-D, %d meshblocks, %d level(s), %lld photons\n", problem_id.c_str(), ndim,
+                nb, max_level + 1, (long long)md.swarm.n);
 
     // ---- McblockDriver::Execute (mcblock_driver.cpp:38-74) --------------------------------------
     const double tlim = pin.GetReal("parthenon/time", "tlim");
