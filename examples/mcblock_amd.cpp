@@ -14,9 +14,12 @@
 //
 // Static mesh refinement (<parthenon/static_refinementN> regions, 2:1 balanced block tree in
 // Z-order) is built the way jaybenne_amd/mesh.py builds it, so all seven decks of the reference's
-// inputs/ run.  Not covered here (the Python driver jaybenne_amd/mcblock.py does them): several
-// ranks, and material feedback (needs the ghost-zone refresh of jaybenne_amd/halo.py).
-#include <hip/hip_runtime_api.h>
+// inputs/ run.  With do_feedback the host update tasks of mcblock_driver.cpp:58-74 follow every
+// step: ghost zones of internal_energy refreshed through jb_fill_cells (the source map is the one
+// of jaybenne_amd/mesh.py: copy / injection / 2^ndim-cell average), then UpdateDerived
+// (sie = u / rho, mcblock.cpp:208-232) as this application's own kernel.
+// Not covered here (the Python driver jaybenne_amd/mcblock.py does it): several ranks.
+#include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
@@ -169,6 +172,12 @@ struct Swarm {
   }
 };
 
+// mcblock::UpdateDerived (mcblock.cpp:208-232): sie = u / rho over entire blocks
+__global__ void UpdateDerivedKernel(const double *rho, const double *u, double *sie, size_t n) {
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x)
+    sie[q] = u[q] / rho[q];
+}
+
 static uint64_t Morton(const int l[3], int bits) {
   uint64_t key = 0;
   for (int b = 0; b < bits; ++b)
@@ -234,8 +243,6 @@ int main(int argc, char **argv) {
     p.source_strategy = strategy == "uniform" ? JB_STRATEGY_UNIFORM : JB_STRATEGY_ENERGY;
     p.do_emission = pin.GetOrAddBoolean("jaybenne", "do_emission", true);
     p.do_feedback = pin.GetOrAddBoolean("jaybenne", "do_feedback", true);
-    if (p.do_feedback)
-      throw std::runtime_error("material feedback needs the ghost-zone refresh of the Python driver");
     auto pkg = jb::Initialize(p, opacity, scattering, eos, 0);
 
     // ---- block tree: leaves in Z-order, geometry as jaybenne_amd/mesh.py forms it ------------
@@ -509,6 +516,57 @@ int main(int argc, char **argv) {
     md.swarm.n = 0;
     pool.Grow(md.swarm, (int64_t)(0.65 * (double)p.num_particles) + 2048);
 
+    // ---- ghost-zone source map of internal_energy (only needed with feedback) -----------------
+    DeviceArray<int32_t> g_dst_blk, g_dst_cell, g_src_blk, g_src_cell;
+    int64_t g_n = 0;
+    const int nsamples = 1 << ndim;
+    if (p.do_feedback) {
+      std::vector<int32_t> dblk, dcell, sblk, scell;
+      for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < ntot_dim[2]; ++k)
+          for (int j = 0; j < ntot_dim[1]; ++j)
+            for (int i = 0; i < ntot_dim[0]; ++i) {
+              const int idx[3] = {i, j, k};
+              bool ghost = false;
+              for (int d = 0; d < ndim; ++d) ghost = ghost || idx[d] < is[d] || idx[d] >= is[d] + nx[d];
+              if (!ghost) continue;
+              dblk.push_back(b);
+              dcell.push_back((k * ntot_dim[1] + j) * ntot_dim[0] + i);
+              double base[3];
+              for (int d = 0; d < 3; ++d)
+                base[d] = (xmin[3 * b + d] - is[d] * dx[3 * b + d]) + (idx[d] + 0.5) * dx[3 * b + d];
+              for (int q = 0; q < nsamples; ++q) {  // dimension 0 varies slowest (itertools.product)
+                double pt[3];
+                int bit = ndim - 1;
+                for (int d = 0; d < 3; ++d) {
+                  double off = 0.0;
+                  if (d < ndim) off = ((q >> (bit--)) & 1) ? 0.25 : -0.25;
+                  pt[d] = base[d] + off * dx[3 * b + d];
+                }
+                for (int d = 0; d < ndim; ++d) {
+                  const double ext = gmax[d] - gmin[d];
+                  if (mesh_periodic[2 * d]) { if (pt[d] < gmin[d]) pt[d] += ext; }
+                  else pt[d] = std::max(pt[d], gmin[d] + 0.25 * dx[3 * b + d]);
+                  if (mesh_periodic[2 * d + 1]) { if (pt[d] > gmax[d]) pt[d] -= ext; }
+                  else pt[d] = std::min(pt[d], gmax[d] - 0.25 * dx[3 * b + d]);
+                }
+                const int nbk = find_block(pt);
+                int c[3] = {0, 0, 0};
+                for (int d = 0; d < ndim; ++d) {
+                  int cd = (int)std::floor((pt[d] - xmin[3 * nbk + d]) / dx[3 * nbk + d]);
+                  c[d] = std::min(std::max(cd, 0), nx[d] - 1) + is[d];
+                }
+                sblk.push_back(nbk);
+                scell.push_back((c[2] * ntot_dim[1] + c[1]) * ntot_dim[0] + c[0]);
+              }
+            }
+      g_n = (int64_t)dblk.size();
+      g_dst_blk.Alloc(dblk.size()); g_dst_blk.Upload(dblk);
+      g_dst_cell.Alloc(dcell.size()); g_dst_cell.Upload(dcell);
+      g_src_blk.Alloc(sblk.size()); g_src_blk.Upload(sblk);
+      g_src_cell.Alloc(scell.size()); g_src_cell.Upload(scell);
+    }
+
     jb::InitializeRadiation(&md, initial_radiation == "thermal");
     std::printf("problem %s: %d-D, %d meshblocks, %d level(s), %lld photons\n", problem_id.c_str(), ndim,
                 nb, max_level + 1, (long long)md.swarm.n);
@@ -522,6 +580,14 @@ int main(int argc, char **argv) {
       const double dt = jb::EstimateTimestepMesh(&md);
       if (jb::RadiationStep(&md, time, dt) != jb::TaskStatus::complete)
         throw std::runtime_error("radiation step did not complete");
+      if (p.do_feedback) {  // HostUpdateTasks: boundary exchange of u, FillDerived -> UpdateDerived
+        jb::Check(jb_fill_cells(md.ctx(), md.mesh(), JB_FIELD_U, g_n, nsamples, g_dst_blk.d, g_dst_cell.d,
+                                g_src_blk.d, g_src_cell.d, nullptr));
+        jb::Check(jb_synchronize(md.ctx()));
+        hipLaunchKernelGGL(UpdateDerivedKernel, dim3(1024), dim3(256), 0, 0, fields[0].d, fields[2].d,
+                           fields[1].d, (size_t)nb * ntot);
+        HIP_OK(hipDeviceSynchronize());
+      }
       time += dt;
       ++ncycle;
       std::printf("cycle=%ld time=%.6e dt=%.6e photons=%lld events=%lld\n", ncycle, time, dt,

@@ -140,3 +140,43 @@ def test_native_cpp_host_application(gpu_device, tmp_path, deck, overrides):
     assert np.array_equal(xs[np.argsort(ids)], g["x"][np.argsort(g["id"])])
     want = drv.md.get_field("tally")[drv.mesh.interior()].ravel()
     np.testing.assert_allclose(tally, want, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("deck,overrides", [
+    ("stepdiff", ["parthenon/mesh/nx1=16", "parthenon/meshblock/nx1=8", "jaybenne/num_particles=20000",
+                  "jaybenne/do_emission=true", "jaybenne/do_feedback=true", "mcblock/opacity_model=constant",
+                  "mcblock/opacity_constant_value=40.0", "mcblock/scattering_constant_value=20.0",
+                  "mcblock/initial_temperature=1.0e6", "parthenon/time/nlim=3"]),
+    ("stepdiff_smr_hybrid", ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "parthenon/meshblock/nx1=16",
+                             "parthenon/meshblock/nx2=16", "jaybenne/num_particles=30000",
+                             "jaybenne/do_emission=true", "jaybenne/do_feedback=true",
+                             "mcblock/opacity_model=constant", "mcblock/opacity_constant_value=20.0",
+                             "parthenon/time/nlim=3"])])
+def test_native_cpp_host_application_with_feedback(gpu_device, tmp_path, deck, overrides):
+    """The native application's host update tasks (ghost-zone refresh of internal_energy through
+    jb_fill_cells from its own source map, UpdateDerived as its own kernel) against the Python
+    driver's: absorbing / emitting material with feedback, 3 cycles (1e-11 on attributes: from
+    cycle 2 on u carries the order of the absorption atomics in its last bits)."""
+    import subprocess
+    from helpers import ROOT, load_deck
+    from jaybenne_amd import mcblock
+    exe = os.path.join(ROOT, "examples", "mcblock_amd")
+    dump = tmp_path / "native.bin"
+    res = subprocess.run([exe, "-i", os.path.join(DECKS, deck + ".in"), "--dump", str(dump)] + overrides,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    raw = dump.read_bytes()
+    ncell, n, events = np.frombuffer(raw, dtype=np.int64, count=3)
+    off = 24
+    tally = np.frombuffer(raw, dtype=np.float64, count=ncell, offset=off); off += 8 * ncell
+    ids = np.frombuffer(raw, dtype=np.uint64, count=n, offset=off); off += 8 * n
+    xs = np.frombuffer(raw, dtype=np.float64, count=n, offset=off)
+    drv = mcblock.McblockDriver(load_deck(deck, dict(o.split("=") for o in overrides)), device=gpu_device,
+                                capacity_factor=8.0)
+    drv.Execute()
+    g = drv.md.get_swarm()
+    assert n == drv.md.n and events == drv.md.events
+    assert np.array_equal(np.sort(ids), np.sort(g["id"]))
+    np.testing.assert_allclose(xs[np.argsort(ids)], g["x"][np.argsort(g["id"])], rtol=1e-11, atol=0)
+    want = drv.md.get_field("tally")[drv.mesh.interior()].ravel()
+    np.testing.assert_allclose(tally, want, rtol=1e-11, atol=0)
