@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs of tools/scratch/prof_r01*.sh (under gpurun_out/) into the small
+"""Turn the rocprofv3 outputs of tools/dev/prof_r01*.sh (under gpurun_out/) into the small
 summaries committed under profiles/: per-pass PMC sums for the transport kernel, the kernel-stats
 table, the bench lines, and the HBM-traffic file bench.py reads for roofline.traffic.
 
