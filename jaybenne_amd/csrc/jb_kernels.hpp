@@ -318,8 +318,8 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 // once per history or once per block crossing: relocation of particles that left their block
 // (swarm boundary conditions, destination-block lookup, DDMC block-face resampling), DDMC census
 // resampling, write-back, tallies, and handing the next particles to idle lanes.  The event loop
-// runs until enough lanes have left it (see kServiceBudget); keeping the rare, long code paths out of it keeps
-// its 64 lanes on one instruction stream.
+// runs until enough lanes have left it (see kServiceBudget); keeping the rare, long code paths
+// out of it keeps its 64 lanes on one instruction stream.
 //
 // Particles are dealt from 8 queues, each over one contiguous eighth of the (cell-ordered) swarm
 // (ballot + popcount prefix over the idle mask, one returning atomic per wave).  A workgroup
