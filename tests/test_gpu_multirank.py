@@ -63,11 +63,22 @@ def _worker(rank, world, port, case, outdir):
 
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_two_ranks_equal_the_oracle(gpu_device, case, tmp_path):
+    _ranks_equal_the_oracle(case, 2, tmp_path)
+
+
+@pytest.mark.parametrize("case", [3, 5])     # 2-D hybrid SMR deck (20 blocks), 3-D SMR DDMC (72 blocks)
+def test_four_ranks_equal_the_oracle(gpu_device, case, tmp_path):
+    """Four ranks (still one card, gloo): every rank hands particles to several others, the
+    count matrix is 4 x 4, halo copies come from up to three neighbours."""
+    _ranks_equal_the_oracle(case, 4, tmp_path)
+
+
+def _ranks_equal_the_oracle(case, world, tmp_path):
     from oracle import orc
     sys.path.insert(0, os.path.dirname(__file__))
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -77,7 +88,7 @@ def test_two_ranks_equal_the_oracle(gpu_device, case, tmp_path):
     pin = load_deck(deck, ov)
     O, mesh, _ = make_oracle(pin, orc.MATH_PORTABLE)
     run_oracle_cycles(O, pin, cycles)
-    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     assert sum(int(p["outgoing"][0]) for p in parts) > 0, "the case must exercise the hand-off"
     ids = np.concatenate([p["id"] for p in parts])
     order = np.argsort(ids)
