@@ -229,6 +229,10 @@ def main() -> None:
                          "kernel": {"c2": "k_transport<3, false, true, 2>", "c3": "k_transport<3, true, true, 2>",
                                     "c3-1d": "k_transport<1, true, true, 2>", "c4": "k_transport<2, false, true, 2>",
                                     "c5": "k_transport<2, true, true, 2>"}[args.workload],
+                         "kernel_variant": "GRAY = 2: gray opacities with kappa_a = 0 (the deck's "
+                                           "opacity_model = none); the absorption draw is consumed, its "
+                                           "logarithm is not evaluated -- bit-identical to the general "
+                                           "kernels (DESIGN.md section 4, tests/test_gpu_parity.py)",
                          "kernel_ms_avg": 1e3 * k_time / max(len(kt), 1),
                          "launches": len(kt),
                          "algorithmic_bytes_per_history": BYTES_PER_HISTORY + per_event * ev_per_hist,
