@@ -330,8 +330,11 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 #ifndef JB_TRANSPORT_WAVES_PER_SIMD
 #define JB_TRANSPORT_WAVES_PER_SIMD 1
 #endif
-#ifndef JB_SERVICE_BUDGET
-#define JB_SERVICE_BUDGET 144
+#ifndef JB_SERVICE_BUDGET        // idle lane-passes that buy a service phase: IMC kernels
+#define JB_SERVICE_BUDGET 96
+#endif
+#ifndef JB_SERVICE_BUDGET_DDMC   // ... DDMC / hybrid kernels (their service phase costs more)
+#define JB_SERVICE_BUDGET_DDMC 128
 #endif
 
 enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
@@ -369,7 +372,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
 #define JB_RELOAD_BLOCK DDMC
 #endif
   constexpr bool kReloadBlock = JB_RELOAD_BLOCK;
-  constexpr int kServiceBudget = JB_SERVICE_BUDGET;
+  constexpr int kServiceBudget = DDMC ? JB_SERVICE_BUDGET_DDMC : JB_SERVICE_BUDGET;
   const double vv = P.c;
   const double t_end = t_start + dt;  // the reference re-evaluates t_start + dt: same double
   const int lane = threadIdx.x & 63;
