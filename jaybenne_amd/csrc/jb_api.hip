@@ -450,14 +450,23 @@ extern "C" jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh,
 template <int NDIM, bool DDMC>
 static void launch_transport(jb_context *ctx, const DevMesh &M, const DevSwarm &S, double t_start,
                              double dt, long long first, long long last, bool tally) {
-  int per_cu = 8;
-  if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 8;  // tuning aid
-  const int g = grid_for(ctx, last - first, per_cu);
+  // The kernel is persistent (waves draw particles from queues until they are empty), so the grid
+  // is exactly what the chip holds at once: more workgroups would only start when the queues
+  // are already drained.  JB_TRANSPORT_BLOCKS_PER_CU overrides the occupancy query (tuning aid).
+  int per_cu_env = 0;
+  if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) per_cu_env = atoi(e);
   const bool gray = M.lam_abs != nullptr;
   (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream);
 #define JB_LAUNCH(T, G)                                                                            \
-  hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G>), dim3(g), dim3(kBlock), 0, ctx->stream, M,    \
-                     ctx->dp, S, t_start, dt, first, last, ctx->counters_d)
+  do {                                                                                             \
+    int occ = 0;                                                                                   \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_transport<NDIM, DDMC, T, G>, kBlock,  \
+                                                     0) != hipSuccess || occ < 1)                  \
+      occ = 3;                                                                                     \
+    const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
+    hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G>), dim3(g), dim3(kBlock), 0, ctx->stream, M,  \
+                       ctx->dp, S, t_start, dt, first, last, ctx->counters_d);                     \
+  } while (0)
   // gray opacity with kappa = 0 (opacity_model = none): sigma_a = rho * 0 in every cell
   const bool noabs = gray && ctx->dp.kappa_a == 0.0;
   if (noabs) {
