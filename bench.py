@@ -182,11 +182,11 @@ def main() -> None:
         achieved = k_bytes / k_time / 1e9 if k_time > 0 else 0.0
         fp64 = k_hist * ev_per_hist * FLOPS_PER_EVENT / k_time / 1e12 if k_time > 0 else 0.0
         # HBM bytes per launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
-        # passes of this very command; profiles/r01_f_hbm_traffic_<workload>.json) -- valid for
+        # passes of this very command; profiles/r01_g_hbm_traffic_<workload>.json) -- valid for
         # the workload and particle count they were collected on
         traffic = None
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", f"r01_f_hbm_traffic_{args.workload}.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", f"r01_g_hbm_traffic_{args.workload}.json")))
             if (tr["workload"] == args.workload and tr["particles_per_gpu"] == args.particles_per_gpu
                     and args.block_nx == 64 and args.gpus == 1):
                 traffic = tr["hbm_bytes_per_launch"]
@@ -239,14 +239,14 @@ def main() -> None:
                          "fp64_valu": {"achieved_tflops": fp64, "peak_tflops": FP64_VALU_PEAK_TF,
                                        "frac": fp64 / FP64_VALU_PEAK_TF,
                                        "note": "IMC regime is VALU-issue bound, not HBM bound (SURVEY "
-                                               "8d): PMC shows the SIMDs 99 % busy issuing VALU at 296 "
-                                               "instructions per 64-lane event, L2 hit rate 99.3 %, "
-                                               "75 GB/s of HBM traffic (profiles/r01_f_pmc_c2_*.json)"
+                                               "8d): PMC shows the SIMDs 99 % busy issuing VALU at 292 "
+                                               "instructions per 64-lane event, L2 hit rate 99.4 %, "
+                                               "76 GB/s of HBM traffic (profiles/r01_g_pmc_c2_*.json)"
                                        if args.workload == "c2" else
                                                "DDMC regime (3-D, 1e8 particles): SIMDs 54 % busy issuing "
                                                "VALU at 3 waves/SIMD, 366 instructions per 64-lane event at "
                                                "64 % lane use, L2 hit rate 84 %, 930 GB/s of HBM traffic "
-                                               "(profiles/r01_f_pmc_c3_*.json)"}},
+                                               "(profiles/r01_g_pmc_c3_*.json)"}},
         }
         if md.phase_times is not None:
             out["phase_ms_per_step"] = {k: 1e3 * v / args.steps for k, v in md.phase_times.items()}
