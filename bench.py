@@ -42,6 +42,9 @@ def make_deck(ngpus: int, particles_per_gpu: int, block_nx: int = 64, workload: 
     c3: stepdiff_ddmc.in, 3-D 128^3 cells in 8 x 64^3 blocks (sigma dx = 7.8: every step DDMC).
     c3-1d: stepdiff_ddmc.in as shipped but 128 cells in one block (tally-contention stress)."""
     from helpers import load_deck
+    if workload == "c1":     # BASELINE configs[0]: the reference's own regression case (tst/stepdiff.py)
+        return load_deck("stepdiff", {"jaybenne/num_particles": particles_per_gpu * ngpus,
+                                      "parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128})
     if workload == "c3-1d":
         return load_deck("stepdiff_ddmc", {"jaybenne/num_particles": particles_per_gpu * ngpus,
                                            "parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128})
@@ -111,7 +114,7 @@ def main() -> None:
     ap.add_argument("--block-nx", type=int, default=64)
     ap.add_argument("--cpu-sample", type=int, default=2_500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3-1d", "c4", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c3-1d", "c4", "c5"],
                     help="c2 = headline (BASELINE configs[1]); c3* = DDMC side measurements")
     args = ap.parse_args()
 
@@ -177,7 +180,7 @@ def main() -> None:
         k_time = sum(t for t, _ in kt)
         k_hist = sum(n for _, n in kt)
         ev_per_hist = events / max(histories, 1)
-        per_event = BYTES_PER_EVENT_IMC if args.workload == "c2" else 72.0
+        per_event = BYTES_PER_EVENT_IMC if args.workload in ("c1", "c2", "c4") else 72.0
         k_bytes = k_hist * (BYTES_PER_HISTORY + per_event * ev_per_hist)
         achieved = k_bytes / k_time / 1e9 if k_time > 0 else 0.0
         fp64 = k_hist * ev_per_hist * FLOPS_PER_EVENT / k_time / 1e12 if k_time > 0 else 0.0
@@ -205,6 +208,8 @@ def main() -> None:
                       f"{md.mesh.nblocks} meshblocks of {args.block_nx}^3 cells, "
                       f"{args.particles_per_gpu * args.gpus:.3g} particles, 1 cycle per step "
                       "(BASELINE.json configs[1] per GPU)",
+                "c1": "[c1] stepdiff as the reference's test runs it (1-D, 128 cells, 1 block), "
+                      f"{args.particles_per_gpu * args.gpus:.3g} particles (BASELINE.json configs[0])",
                 "c3": "[c3] stepdiff_ddmc (all-DDMC, tau_ddmc = 5), uniform 3-D mesh, "
                       f"{md.mesh.nblocks} meshblocks of {args.block_nx}^3 cells, "
                       f"{args.particles_per_gpu * args.gpus:.3g} particles, 1 cycle per step "
@@ -226,7 +231,7 @@ def main() -> None:
             "events_per_history": ev_per_hist,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {"c2": "k_transport<3, false, true, 2>", "c3": "k_transport<3, true, true, 2>",
+                         "kernel": {"c1": "k_transport<1, false, true, 2>", "c2": "k_transport<3, false, true, 2>", "c3": "k_transport<3, true, true, 2>",
                                     "c3-1d": "k_transport<1, true, true, 2>", "c4": "k_transport<2, false, true, 2>",
                                     "c5": "k_transport<2, true, true, 2>"}[args.workload],
                          "kernel_variant": "GRAY = 2: gray opacities with kappa_a = 0 (the deck's "
