@@ -161,6 +161,8 @@ def test_native_cpp_host_application_with_feedback(gpu_device, tmp_path, deck, o
     from helpers import ROOT, load_deck
     from jaybenne_amd import mcblock
     exe = os.path.join(ROOT, "examples", "mcblock_amd")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
     dump = tmp_path / "native.bin"
     res = subprocess.run([exe, "-i", os.path.join(DECKS, deck + ".in"), "--dump", str(dump)] + overrides,
                          capture_output=True, text=True, timeout=300)
