@@ -10,6 +10,11 @@ are handed over through RCCL -- weak scaling.  A step = one RadiationStep (refer
 jaybenne.cpp:68-151): derived fields, transport of every photon to census incl. hand-off and the
 completion test, census tally.  Inputs are resident in HBM before the timed region.
 
+`python bench.py --gpus N` works as typed: for N > 1 without a launcher environment it starts
+N fresh rank processes itself (python -m torch.distributed.run, rendezvous on 127.0.0.1) BEFORE
+anything in this process touches the GPU, relays rank 0's line and exits with the children's
+code.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is a rank.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -105,6 +110,71 @@ def cpu_baseline(sample_particles: int, block_nx: int):
     return out
 
 
+def accuracy(device, threads: int):
+    """north_star's accuracy clause on BASELINE configs[0] (the reference's own regression case,
+    tst/stepdiff.py: 1-D, 128 cells, 1e5 photons, 10 cycles): the HIP path and the CPU restatement
+    with the reference's libm arithmetic run the same streams; both are scored with the
+    reference's metric (tst/regression_test.py:383-406) against the analytic erf profile, and
+    against each other in units of the Monte Carlo noise of a cell."""
+    from helpers import load_deck, make_oracle, run_oracle_cycles
+    from jaybenne_amd import analysis, mcblock
+    from oracle import orc
+    ov = {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128}
+    drv = mcblock.McblockDriver(load_deck("stepdiff", ov), device=device)
+    drv.Execute()
+    sl = drv.mesh.interior()
+    g = drv.md.get_field("tally")
+    e_gpu = analysis.analytic_errors(drv.mesh, g, drv.time)["mean_frac_error_weighted"]
+    pin = load_deck("stepdiff", ov)
+    O, mesh, _ = make_oracle(pin, orc.MATH_LIBM, threads=threads)
+    t_end = run_oracle_cycles(O, pin, drv.ncycle)
+    c = O.fields["tally"]
+    e_cpu = analysis.analytic_errors(mesh, c, t_end)["mean_frac_error_weighted"]
+    # per-cell noise: n census photons of equal weight w in a cell -> sigma = w sqrt(n) / dV
+    w = float(O.sw["w"][:O.n].max())
+    dv = float(mesh.cell_volume(0))
+    sigma = np.sqrt(np.maximum(c[sl] * dv / w, 1.0)) * w / dv
+    z = np.abs(g[sl] - c[sl]) / sigma
+    return {"config": "BASELINE configs[0]: stepdiff 1-D, 128 cells, 1e5 photons, 10 cycles",
+            "metric": "weighted mean fractional error vs the analytic erf profile "
+                      "(tst/regression_test.py:383-406), gate 0.05",
+            "gpu_error": e_gpu, "cpu_libm_error": e_cpu, "gate": 0.05,
+            "gpu_minus_cpu": e_gpu - e_cpu,
+            "max_cell_difference_in_sigma": float(z.max()),
+            "rms_cell_difference_in_sigma": float(np.sqrt((z * z).mean())),
+            "note": "same random streams; the HIP path evaluates log / sincos by table, the CPU "
+                    "path by libm (<= 1 ulp, <= 8e-16 apart), so histories part ways at "
+                    "last-bit branch decisions: two realisations of one problem.  Stated "
+                    "tolerance (tests/test_gpu_accuracy.py): gpu_error <= cpu_libm_error + 0.01 "
+                    "and every cell within 6 sigma of Monte Carlo noise."}
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 from a plain `python bench.py`: N fresh rank processes, started before this
+    process has imported torch or made any HIP call (re-executing a process that has initialised
+    the GPU is not allowed on this pool)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if (proc.returncode != 0 or line is not None) else 1
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,7 +186,11 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c3-1d", "c4", "c5"],
                     help="c2 = headline (BASELINE configs[1]); c3* = DDMC side measurements")
+    ap.add_argument("--no-accuracy", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -162,6 +236,7 @@ def main() -> None:
     sync_all()
     ev0 = md.events
     md.kernel_events = []
+    md.handoff_records, md.exchange_seconds, md.transport_iterations_total = 0, 0.0, 0
     histories = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -174,27 +249,64 @@ def main() -> None:
         wall = comm.allreduce_max_float(wall)
         histories, events = (int(v) for v in comm.allreduce_sum_int64(np.array([histories, events])))
 
+    # hand-off statistics of the timed steps (all ranks): records are 104 bytes
+    handoff_records = int(getattr(md, "handoff_records", 0))
+    exchange_s = float(getattr(md, "exchange_seconds", 0.0))
+    iters = int(getattr(md, "transport_iterations_total", args.steps))
+    if comm is not None:
+        handoff_records = int(comm.allreduce_sum_int64(np.array([handoff_records]))[0])
+        exchange_s = comm.allreduce_max_float(exchange_s)
+
     if rank == 0:
         # dominant kernel: k_transport, timed with HIP events on its stream (rank 0's launches)
         kt = [(a.elapsed_time(b) * 1e-3, n) for a, b, n in md.kernel_events]
         k_time = sum(t for t, _ in kt)
-        k_hist = sum(n for _, n in kt)
+        k_hist = sum(n for t, n in kt)
         ev_per_hist = events / max(histories, 1)
-        per_event = BYTES_PER_EVENT_IMC if args.workload in ("c1", "c2", "c4") else 72.0
-        k_bytes = k_hist * (BYTES_PER_HISTORY + per_event * ev_per_hist)
-        achieved = k_bytes / k_time / 1e9 if k_time > 0 else 0.0
-        fp64 = k_hist * ev_per_hist * FLOPS_PER_EVENT / k_time / 1e12 if k_time > 0 else 0.0
-        # HBM bytes per launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
-        # passes of this very command; profiles/r01_g_hbm_traffic_<workload>.json) -- valid for
-        # the workload and particle count they were collected on
-        traffic = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", f"r01_g_hbm_traffic_{args.workload}.json")))
-            if (tr["workload"] == args.workload and tr["particles_per_gpu"] == args.particles_per_gpu
-                    and args.block_nx == 64 and args.gpus == 1):
-                traffic = tr["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        k_events = k_hist * ev_per_hist
+        ddmc_bound = args.workload in ("c3", "c3-1d")            # the two regimes
+        per_event = 72.0 if args.workload in ("c3", "c3-1d", "c5") else BYTES_PER_EVENT_IMC
+        k_bytes = k_hist * BYTES_PER_HISTORY + k_events * per_event
+        variant = md.lib.jb_last_transport_variant(md.handle).decode()
+        variant = ("TransportPhotons_DDMC: " if md.pkg.Param("use_ddmc") else "TransportPhotons: ") + variant
+        # counters of this very command under rocprofv3 (separate --pmc passes), if a committed
+        # summary matches workload and size: labelled as read from that file, not measured now
+        pmc, pmc_file = None, None
+        for rnd in ("r02", "r01_g"):
+            f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{args.workload}.json")
+            try:
+                tr = json.load(open(f))
+                if (tr["workload"] == args.workload and tr["particles_per_gpu"] == args.particles_per_gpu
+                        and args.block_nx == 64 and args.gpus == 1):
+                    pmc, pmc_file = tr, os.path.relpath(f, ROOT)
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
+        fp64 = k_events * FLOPS_PER_EVENT / k_time / 1e12 if k_time > 0 else 0.0
+        l2_gbs = k_bytes / k_time / 1e9 if k_time > 0 else 0.0
+        if ddmc_bound:
+            roof = {"bound": "hbm", "achieved": l2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": l2_gbs / HBM_PEAK_GBS,
+                    "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                    "definition": "algorithmic bytes (168 B per history + 72 B per DDMC event, SURVEY "
+                                  "8d) / k_transport time (HIP events, this run)"}
+        else:
+            roof = {"bound": "fp64_valu", "achieved": fp64, "peak": FP64_VALU_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": fp64 / FP64_VALU_PEAK_TF,
+                    "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                    "definition": "events x 200 FP64 flop-equivalents (SURVEY 8d) / k_transport time "
+                                  "(HIP events, this run), against the vector FP64 peak; the IMC "
+                                  "regime is bound by VALU instruction issue, not by HBM",
+                    "l2_served_GBps": l2_gbs,
+                    "l2_served_definition": "168 B per history + 24 B of cell gathers per event / "
+                                            "kernel time: almost all served by L2, NOT an HBM rate"}
+        roof.update({"kernel": variant, "kernel_ms_avg": 1e3 * k_time / max(len(kt), 1),
+                     "launches": len(kt), "events_per_launch": k_events / max(len(kt), 1),
+                     "algorithmic_bytes_per_history": BYTES_PER_HISTORY + per_event * ev_per_hist})
+        if pmc:
+            roof["counters"] = {"source": pmc_file + " (rocprofv3 --pmc passes of this command; "
+                                                     "not measured in this run)",
+                                **{k: pmc[k] for k in pmc if k not in ("workload", "particles_per_gpu")}}
         out = {
             "metric": "particle-histories/s (whole node) on stepdiff",
             "value": histories / wall,
@@ -223,40 +335,28 @@ def main() -> None:
                 "c5": "[c5] stepdiff_smr_hybrid + nested level-2 region (2-D, 3 levels, IMC/DDMC hybrid), "
                       f"{md.mesh.nblocks} meshblocks, {args.particles_per_gpu * args.gpus:.3g} particles "
                       "(BASELINE.json configs[4])"}[args.workload],
-                       "blocks_per_gpu": md.nowned, "halo_blocks_per_gpu": md.nblocks - md.nowned, "particles_per_gpu": args.particles_per_gpu,
-                       "parallelism": f"meshblocks over {args.gpus} rank(s), RCCL particle hand-off"},
+                       "blocks_per_gpu": md.nowned, "halo_blocks_per_gpu": md.nblocks - md.nowned,
+                       "particles_per_gpu": args.particles_per_gpu,
+                       "parallelism": f"meshblocks over {args.gpus} rank(s), "
+                                      f"{'RCCL' if backend == 'nccl' else backend} particle hand-off"},
             "events_per_s": events / wall,
-            "transport_iterations_per_step": getattr(md, "transport_iterations", 1),
-            "kernel_diagnostics": md.stats(),
             "events_per_history": ev_per_hist,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {"c1": "k_transport<1, false, true, 2>", "c2": "k_transport<3, false, true, 2>", "c3": "k_transport<3, true, true, 2>",
-                                    "c3-1d": "k_transport<1, true, true, 2>", "c4": "k_transport<2, false, true, 2>",
-                                    "c5": "k_transport<2, true, true, 2>"}[args.workload],
-                         "kernel_variant": "GRAY = 2: gray opacities with kappa_a = 0 (the deck's "
-                                           "opacity_model = none); the absorption draw is consumed, its "
-                                           "logarithm is not evaluated -- bit-identical to the general "
-                                           "kernels (DESIGN.md section 4, tests/test_gpu_parity.py)",
-                         "kernel_ms_avg": 1e3 * k_time / max(len(kt), 1),
-                         "launches": len(kt),
-                         "algorithmic_bytes_per_history": BYTES_PER_HISTORY + per_event * ev_per_hist,
-                         "fp64_valu": {"achieved_tflops": fp64, "peak_tflops": FP64_VALU_PEAK_TF,
-                                       "frac": fp64 / FP64_VALU_PEAK_TF,
-                                       "note": "IMC regime is VALU-issue bound, not HBM bound (SURVEY "
-                                               "8d): PMC shows the SIMDs 99 % busy issuing VALU at 292 "
-                                               "instructions per 64-lane event, L2 hit rate 99.4 %, "
-                                               "76 GB/s of HBM traffic (profiles/r01_g_pmc_c2_*.json)"
-                                       if args.workload == "c2" else
-                                               "DDMC regime (3-D, 1e8 particles): SIMDs 54 % busy issuing "
-                                               "VALU at 3 waves/SIMD, 366 instructions per 64-lane event at "
-                                               "64 % lane use, L2 hit rate 84 %, 930 GB/s of HBM traffic "
-                                               "(profiles/r01_g_pmc_c3_*.json)"}},
+            "transport_iterations_per_step": iters / max(args.steps, 1),
+            "handoff": {"records_per_step": handoff_records / max(args.steps, 1),
+                        "bytes_per_step": 104.0 * handoff_records / max(args.steps, 1),
+                        "exchange_ms_per_step_max_rank": 1e3 * exchange_s / max(args.steps, 1),
+                        "note": "particles handed to another rank (all ranks summed); exchange = "
+                                "count kernel + read-back + count all-gather + pack + all-to-all-v "
+                                "+ unpack, wall time on the slowest rank"},
+            "kernel_diagnostics": md.stats(),
+            "roofline": roof,
         }
         if md.phase_times is not None:
             out["phase_ms_per_step"] = {k: 1e3 * v / args.steps for k, v in md.phase_times.items()}
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.block_nx)
+            if not args.no_accuracy:
+                out["accuracy"] = accuracy(device, out["cpu_baseline"]["cores"])
         print(json.dumps(out), flush=True)
     if comm is not None:
         dist.destroy_process_group()

@@ -198,6 +198,13 @@ jb_status jb_transport_photons(jb_context *ctx, jb_mesh *mesh, const jb_swarm_vi
 jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
                                     double t_start, double dt, int64_t first, int64_t last,
                                     int fuse_census_tally);
+/* the k_transport instantiation the last transport call on this mesh launched, e.g.
+ * "k_transport<3, true, 2, true>" = <NDIM, TALLY (census tally fused), GRAY (0 per-event
+ * opacities, 1 gray, 2 gray without absorption), EXACT (exact cell-face arithmetic)>; "" before
+ * the first launch.  jb_mesh_exact_geometry: 1 if every resident block has power-of-two cell
+ * widths and a lower corner that is a whole number of them. */
+const char *jb_last_transport_variant(const jb_mesh *mesh);
+int jb_mesh_exact_geometry(const jb_mesh *mesh);
 /* counters accumulated by the transport tasks since the last reset (synchronises) */
 jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats *stats, int reset);
 
@@ -276,10 +283,12 @@ jb_status jb_debug_rocrand_philox(jb_context *ctx, uint64_t seed, uint64_t subse
                                   uint32_t out[8]);
 jb_status jb_debug_seed_state(jb_context *ctx, uint32_t seed, uint32_t domain, uint64_t id,
                               uint64_t *state);
+/* first state of the random stream of the particle with creation index id (csrc/jb_rng.hpp) */
+jb_status jb_debug_stream_start(jb_context *ctx, uint32_t seed, uint64_t id, uint64_t *state);
 jb_status jb_debug_draw_stream(jb_context *ctx, uint64_t state, int n, double *out_host,
                                uint64_t *final_state);
 /* which: 0 log, 1 sin, 2 cos, 3 acos, 4 sqrt, 5 reciprocal, 6 lean sqrt, 7 lean x[i] / x[i+1],
- * 8 lean x[i] / c */
+ * 8 lean x[i] / c, 9 sin(2 pi x), 10 cos(2 pi x) */
 jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n, double *out_host);
 /* step functions on a tape of uniforms.  st: jb_debug_step record (see below); which:
  * 0 ptcl_transport_step, 1 ptcl_ddmc_step, 2 ptcl_ddmc_albedo */

@@ -107,6 +107,8 @@ PROTOTYPES = {
     "jb_transport_photons": (_int, [_vp, _vp, C.POINTER(SwarmView), _f64, _f64, _i64, _i64, _int]),
     "jb_transport_photons_ddmc": (_int, [_vp, _vp, C.POINTER(SwarmView), _f64, _f64, _i64, _i64,
                                          _int]),
+    "jb_last_transport_variant": (C.c_char_p, [_vp]),
+    "jb_mesh_exact_geometry": (_int, [_vp]),
     "jb_get_transport_stats": (_int, [_vp, C.POINTER(TransportStats), _int]),
     "jb_sample_ddmc_block_face": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, _i64]),
     "jb_check_completion": (_int, [_vp, C.POINTER(SwarmView), _f64, C.POINTER(_i64)]),
@@ -126,6 +128,7 @@ PROTOTYPES = {
                                C.POINTER(C.c_uint32)]),
     "jb_debug_rocrand_philox": (_int, [_vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),
     "jb_debug_seed_state": (_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "jb_debug_stream_start": (_int, [_vp, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jb_debug_draw_stream": (_int, [_vp, C.c_uint64, _int, _vp, C.POINTER(C.c_uint64)]),
     "jb_debug_math": (_int, [_vp, _int, _vp, _int, _vp]),
     "jb_debug_step_call": (_int, [_vp, _int, C.POINTER(DebugStep), _vp, _int, C.POINTER(_int)]),

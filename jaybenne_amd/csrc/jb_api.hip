@@ -61,6 +61,10 @@ struct jb_mesh {
   DevMesh dm{};
   std::vector<void *> owned;  // device allocations
   int nranks_seen = 1;
+  // every resident block: power-of-two cell widths, lower corner a whole number of them (the
+  // cell-face arithmetic is then exact; k_transport<..., EXACT>)
+  bool exact_geom = false;
+  const char *last_variant = "";  // the k_transport instantiation launched last
 };
 
 __global__ void k_rcp_refined(double b, double *out) { *out = m_rcp_refined(b); }
@@ -124,17 +128,26 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   ctx->dp.kappa_a = opacity->kappa;
   ctx->dp.kappa_s = scattering->kappa_s;
   ctx->dp.apm = scattering->apm;
-  hipDeviceProp_t prop;
-  JB_HIP(hipGetDeviceProperties(&prop, device));
-  ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  JB_HIP(hipMalloc(&ctx->counters_d, kCounterWords * sizeof(unsigned long long)));
-  JB_HIP(hipMemset(ctx->counters_d, 0, kCounterWords * sizeof(unsigned long long)));
-  JB_HIP(hipHostMalloc(&ctx->counters_h, kCounterWords * sizeof(unsigned long long)));
-  // the refined reciprocal of c that the step functions divide with (jb_math.hpp, m_div_r): one
-  // device evaluation, so that it is the v_rcp_f64-seeded value the kernels would compute
-  hipLaunchKernelGGL(k_rcp_refined, dim3(1), dim3(1), 0, 0, ctx->dp.c, (double *)ctx->counters_d);
-  JB_HIP(hipMemcpy(&ctx->dp.rc, ctx->counters_d, sizeof(double), hipMemcpyDeviceToHost));
-  JB_HIP(hipMemset(ctx->counters_d, 0, sizeof(double)));
+  // (a failure below must not leak the context: jb_finalize releases whatever exists)
+  auto init_device_state = [&]() -> jb_status {
+    hipDeviceProp_t prop;
+    JB_HIP(hipGetDeviceProperties(&prop, device));
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    JB_HIP(hipMalloc(&ctx->counters_d, kCounterWords * sizeof(unsigned long long)));
+    JB_HIP(hipMemset(ctx->counters_d, 0, kCounterWords * sizeof(unsigned long long)));
+    JB_HIP(hipHostMalloc(&ctx->counters_h, kCounterWords * sizeof(unsigned long long)));
+    // the refined reciprocal of c that the step functions divide with (jb_math.hpp, m_div_r): one
+    // device evaluation, so that it is the v_rcp_f64-seeded value the kernels would compute
+    hipLaunchKernelGGL(k_rcp_refined, dim3(1), dim3(1), 0, 0, ctx->dp.c, (double *)ctx->counters_d);
+    JB_HIP(hipMemcpy(&ctx->dp.rc, ctx->counters_d, sizeof(double), hipMemcpyDeviceToHost));
+    JB_HIP(hipMemset(ctx->counters_d, 0, sizeof(double)));
+    return JB_COMPLETE;
+  };
+  const jb_status st = init_device_state();
+  if (st != JB_COMPLETE) {
+    jb_finalize(ctx);
+    return st;
+  }
   *out = ctx;
   return JB_COMPLETE;
 }
@@ -157,6 +170,7 @@ extern "C" jb_status jb_set_stream(jb_context *ctx, void *hip_stream) {
 
 extern "C" jb_status jb_synchronize(jb_context *ctx) {
   if (!ctx) return fail(JB_ERR_INVALID, "null context");
+  JB_HIP(hipSetDevice(ctx->device));
   JB_HIP(hipStreamSynchronize(ctx->stream));
   return JB_COMPLETE;
 }
@@ -233,6 +247,31 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   D.ncell = v->nx[0] * v->nx[1] * v->nx[2];
   D.ntot = (long long)D.ni * D.nj * D.nk;
   if (D.ntot * 8 >= (1ll << 31)) { delete m; return fail(JB_ERR_INVALID, "block too large: cell indices are 32-bit"); }
+  if (D.ni >= (1 << 23) || (long long)D.nj * D.nk >= (1ll << 23)) {
+    delete m;
+    return fail(JB_ERR_INVALID, "block too large: ni and nj * nk must stay below 2^23 (24-bit cell index arithmetic)");
+  }
+  if (v->nblocks_total >= (1 << 20)) {  // cell_stream_id packs the global block id in 20 bits
+    delete m;
+    return fail(JB_ERR_INVALID, "more than 2^20 blocks: the per-cell source streams would alias");
+  }
+  if (D.ncell >= (1 << 24)) {           // ... and the cell in 24
+    delete m;
+    return fail(JB_ERR_INVALID, "more than 2^24 cells per block: the per-cell source streams would alias");
+  }
+  {
+    const char *off = getenv("JB_NO_EXACT_GEOM");  // tests: run the general kernels on an exact mesh
+    bool exact = !(off && off[0] == '1');
+    for (int b = 0; exact && b < v->nblocks; ++b)
+      for (int d = 0; exact && d < v->ndim; ++d) {
+        const double dx = v->blk_dx[3 * b + d], x0 = v->blk_xmin[3 * b + d];
+        int e;
+        const double q = x0 / dx;  // exact when dx is a power of two
+        exact = dx > 0.0 && std::frexp(dx, &e) == 0.5 && q == std::nearbyint(q) &&
+                std::fabs(q) < 1099511627776.0;  // 2^40: (q + i + 0.5) dx is exact
+      }
+    m->exact_geom = exact;
+  }
   int maxrank = 0;
   for (int g = 0; g < v->nblocks_total; ++g) maxrank = v->owner[g] > maxrank ? v->owner[g] : maxrank;
   m->nranks_seen = maxrank + 1;
@@ -286,7 +325,59 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   UPF(rho) UPF(sie) UPF(u) UPF(fleck) UPF(tally) UPF(edelta) UPF(src_ew) UPF(src_num)
   UPF(P1) UPF(P2) UPF(P3)
 #undef UPF
+  // face-crossing table of the tracking kernels (DevMesh::nbr_ent / nbr_x0)
+  {
+    std::vector<int32_t> ent(6 * (size_t)v->nblocks, -1);
+    std::vector<double> x0(6 * (size_t)v->nblocks, 0.0);
+    const int first[3] = {D.is, D.js, D.ks};
+    for (int b = 0; b < v->nblocks; ++b) {
+      long long l0[3] = {0, 0, 0}, cnt[3] = {1, 1, 1};
+      bool ok = true;
+      for (int d = 0; d < v->ndim; ++d) {
+        const double leaf = (v->gmax[d] - v->gmin[d]) / (double)v->nleaf[d];
+        const double q0 = (v->blk_xmin[3 * b + d] - v->gmin[d]) / leaf;
+        const double qc = (v->blk_xmax[3 * b + d] - v->blk_xmin[3 * b + d]) / leaf;
+        l0[d] = (long long)std::llround(q0);
+        cnt[d] = (long long)std::llround(qc);
+        ok = ok && std::fabs(q0 - (double)l0[d]) < 1e-6 && std::fabs(qc - (double)cnt[d]) < 1e-6 &&
+             cnt[d] >= 1 && l0[d] >= 0 && l0[d] + cnt[d] <= v->nleaf[d];
+      }
+      if (!ok) continue;  // (a block that is not a union of leaves: general relocation only)
+      for (int d = 0; d < v->ndim; ++d)
+        for (int up = 0; up < 2; ++up) {
+          const int f = 2 * d + up;
+          long long l[3] = {l0[0], l0[1], l0[2]};
+          l[d] = up ? l0[d] + cnt[d] : l0[d] - 1;
+          int kind = 0;
+          if (l[d] < 0 || l[d] >= v->nleaf[d]) {  // the face lies on the domain boundary
+            const int bc = v->bc[f];
+            if (bc == JB_BC_REFLECT) {
+              ent[6 * (size_t)b + f] = (2 << 28) | b;
+              x0[6 * (size_t)b + f] = v->blk_xmin[3 * b + d] - (double)first[d] * v->blk_dx[3 * b + d];
+              continue;
+            }
+            if (bc != JB_BC_PERIODIC) continue;  // outflow: the particle escapes
+            kind = 1;
+            l[d] = up ? 0 : v->nleaf[d] - 1;
+          }
+          const int g = v->leaf_map[(l[2] * v->nleaf[1] + l[1]) * v->nleaf[0] + l[0]];
+          const int li = v->local_index[g];
+          if (li < 0) continue;  // destination not resident: hand-off
+          bool same = true;  // same size, aligned across the face
+          for (int e = 0; e < 3; ++e) {
+            same = same && v->blk_dx[3 * li + e] == v->blk_dx[3 * b + e];
+            if (e != d && e < v->ndim) same = same && v->blk_xmin[3 * li + e] == v->blk_xmin[3 * b + e];
+          }
+          if (!same || li >= (1 << 28)) continue;
+          ent[6 * (size_t)b + f] = (kind << 28) | li;
+          x0[6 * (size_t)b + f] = v->blk_xmin[3 * li + d] - (double)first[d] * v->blk_dx[3 * li + d];
+        }
+    }
+    if ((st = upload(m, ent.data(), ent.size(), &D.nbr_ent)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
+    if ((st = upload(m, x0.data(), x0.size(), &D.nbr_x0)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
+  }
   // gray (frequency-independent) opacities: library-owned per-cell mean-free-path arrays
+  D.lam_base = nullptr;
   D.lam_abs = nullptr;
   D.lam_sc = nullptr;
   D.ddmc_cell = nullptr;
@@ -306,6 +397,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
       pa[b] = base + (size_t)(2 * b) * per;
       ps[b] = base + (size_t)(2 * b + 1) * per;
     }
+    D.lam_base = base;
     const double *const *tmp = nullptr;
     if ((st = upload(m, (const double *const *)pa.data(), (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
     D.lam_abs = (double *const *)tmp;
@@ -356,6 +448,7 @@ static jb_status check_swarm(const jb_swarm_view *s, const char *who) {
 // ------------------------------------------------------------------------------------------------
 extern "C" jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh *mesh, double dt) {
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   const DevMesh &M = mesh->dm;
   const long long cells = (long long)M.nblocks * M.ncell;
   hipLaunchKernelGGL(k_fleck, dim3(grid_for(ctx, cells)), dim3(kBlock), 0, ctx->stream, M, ctx->dp, dt);
@@ -379,6 +472,7 @@ extern "C" jb_status jb_source_photons_count(jb_context *ctx, jb_mesh *mesh, int
                                              double dt, int blocks_in_call, uint32_t epoch,
                                              int32_t *nper_block_host, int32_t *prefix_dev) {
   if (!ctx || !mesh || !nper_block_host || !prefix_dev) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   if (ctx->params.source_strategy == JB_STRATEGY_ENERGY)
     return fail(JB_ERR_INVALID, "Energy source strategy not implemented!");  // sourcing.cpp:38
   const DevMesh &M = mesh->dm;
@@ -411,6 +505,7 @@ extern "C" jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh,
                                             const uint64_t *id_base_host) {
   if (!ctx || !mesh || !nper_block_host || !prefix_dev || !slot_base_host || !id_base_host)
     return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_source_photons_fill");
   if (st != JB_COMPLETE) return st;
   const DevMesh &M = mesh->dm;
@@ -448,8 +543,9 @@ extern "C" jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh,
 
 // ------------------------------------------------------------------------------------------------
 template <int NDIM, bool DDMC>
-static void launch_transport(jb_context *ctx, const DevMesh &M, const DevSwarm &S, double t_start,
+static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, double t_start,
                              double dt, long long first, long long last, bool tally) {
+  const DevMesh &M = mesh->dm;
   // The kernel is persistent (waves draw particles from queues until they are empty), so the grid
   // is exactly what the chip holds at once: more workgroups would only start when the queues
   // are already drained.  JB_TRANSPORT_BLOCKS_PER_CU overrides the occupancy query (tuning aid).
@@ -457,15 +553,28 @@ static void launch_transport(jb_context *ctx, const DevMesh &M, const DevSwarm &
   if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) per_cu_env = atoi(e);
   const bool gray = M.lam_abs != nullptr;
   (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream);
-#define JB_LAUNCH(T, G)                                                                            \
+#define JB_LAUNCH_X(T, G, X)                                                                       \
   do {                                                                                             \
     int occ = 0;                                                                                   \
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_transport<NDIM, DDMC, T, G>, kBlock,  \
-                                                     0) != hipSuccess || occ < 1)                  \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_transport<NDIM, DDMC, T, G, X>,       \
+                                                     kBlock, 0) != hipSuccess || occ < 1)          \
       occ = 3;                                                                                     \
     const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
-    hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G>), dim3(g), dim3(kBlock), 0, ctx->stream, M,  \
-                       ctx->dp, S, t_start, dt, first, last, ctx->counters_d);                     \
+    hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G, X>), dim3(g), dim3(kBlock), 0, ctx->stream,  \
+                       M, ctx->dp, S, t_start, dt, first, last, ctx->counters_d);                  \
+    mesh->last_variant = NDIM == 1 ? "k_transport<1, " #T ", " #G ", " #X ">"                      \
+                         : NDIM == 2 ? "k_transport<2, " #T ", " #G ", " #X ">"                    \
+                                     : "k_transport<3, " #T ", " #G ", " #X ">";                   \
+  } while (0)
+  // (variant string: NDIM, TALLY, GRAY, EXACT; the DDMC flag is the entry point that was called)
+#define JB_LAUNCH(T, G)                                                                            \
+  do {                                                                                             \
+    if constexpr (!DDMC && G != 0) {                                                               \
+      if (mesh->exact_geom) JB_LAUNCH_X(T, G, true);                                               \
+      else JB_LAUNCH_X(T, G, false);                                                               \
+    } else {                                                                                       \
+      JB_LAUNCH_X(T, G, false);                                                                    \
+    }                                                                                              \
   } while (0)
   // gray opacity with kappa = 0 (opacity_model = none): sigma_a = rho * 0 in every cell
   const bool noabs = gray && ctx->dp.kappa_a == 0.0;
@@ -479,12 +588,14 @@ static void launch_transport(jb_context *ctx, const DevMesh &M, const DevSwarm &
   else if (gray) JB_LAUNCH(false, 1);
   else JB_LAUNCH(false, 0);
 #undef JB_LAUNCH
+#undef JB_LAUNCH_X
 }
 
 static jb_status transport_impl(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
                                 double t_start, double dt, int64_t first, int64_t last, int tally,
                                 bool ddmc) {
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_transport_photons");
   if (st != JB_COMPLETE) return st;
   if (first < 0 || last > swarm->n || first > last)
@@ -497,12 +608,12 @@ static jb_status transport_impl(jb_context *ctx, jb_mesh *mesh, const jb_swarm_v
   const DevSwarm S = dev_swarm(swarm);
   const bool tl = tally != 0;
   switch (M.ndim * 2 + (ddmc ? 1 : 0)) {
-  case 2: launch_transport<1, false>(ctx, M, S, t_start, dt, first, last, tl); break;
-  case 3: launch_transport<1, true>(ctx, M, S, t_start, dt, first, last, tl); break;
-  case 4: launch_transport<2, false>(ctx, M, S, t_start, dt, first, last, tl); break;
-  case 5: launch_transport<2, true>(ctx, M, S, t_start, dt, first, last, tl); break;
-  case 6: launch_transport<3, false>(ctx, M, S, t_start, dt, first, last, tl); break;
-  default: launch_transport<3, true>(ctx, M, S, t_start, dt, first, last, tl); break;
+  case 2: launch_transport<1, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  case 3: launch_transport<1, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  case 4: launch_transport<2, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  case 5: launch_transport<2, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  case 6: launch_transport<3, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  default: launch_transport<3, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
   }
   JB_HIP(hipGetLastError());
   return JB_COMPLETE;
@@ -519,6 +630,11 @@ extern "C" jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh,
   return transport_impl(ctx, mesh, swarm, t_start, dt, first, last, fuse_census_tally, true);
 }
 
+extern "C" const char *jb_last_transport_variant(const jb_mesh *mesh) {
+  return mesh ? mesh->last_variant : "";
+}
+extern "C" int jb_mesh_exact_geometry(const jb_mesh *mesh) { return mesh && mesh->exact_geom; }
+
 static jb_status fetch_counters(jb_context *ctx) {
   JB_HIP(hipMemcpyAsync(ctx->counters_h, ctx->counters_d, sizeof(unsigned long long) * kRankBase,
                         hipMemcpyDeviceToHost, ctx->stream));
@@ -528,6 +644,7 @@ static jb_status fetch_counters(jb_context *ctx) {
 
 extern "C" jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats *stats, int reset) {
   if (!ctx || !stats) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   jb_status st = fetch_counters(ctx);
   if (st != JB_COMPLETE) return st;
   stats->n_census = (int64_t)ctx->counters_h[CNT_CENSUS];
@@ -545,6 +662,7 @@ extern "C" jb_status jb_sample_ddmc_block_face(jb_context *ctx, jb_mesh *mesh,
                                                const jb_swarm_view *swarm, int64_t first,
                                                int64_t last) {
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_sample_ddmc_block_face");
   if (st != JB_COMPLETE) return st;
   const DevMesh &M = mesh->dm;
@@ -564,6 +682,7 @@ extern "C" jb_status jb_sample_ddmc_block_face(jb_context *ctx, jb_mesh *mesh,
 extern "C" jb_status jb_check_completion(jb_context *ctx, const jb_swarm_view *swarm, double t_end,
                                          int64_t *unfinished) {
   if (!ctx || !unfinished) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_check_completion");
   if (st != JB_COMPLETE) return st;
   JB_HIP(hipMemsetAsync(&ctx->counters_d[CNT_UNFINISHED], 0, sizeof(unsigned long long), ctx->stream));
@@ -579,6 +698,7 @@ extern "C" jb_status jb_check_completion(jb_context *ctx, const jb_swarm_view *s
 
 extern "C" jb_status jb_zero_energy_tally(jb_context *ctx, jb_mesh *mesh) {
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   const DevMesh &M = mesh->dm;
   hipLaunchKernelGGL(k_zero_tally, dim3(grid_for(ctx, (long long)M.nblocks * M.ncell)), dim3(kBlock), 0,
                      ctx->stream, M);
@@ -601,6 +721,7 @@ extern "C" jb_status jb_evaluate_radiation_energy(jb_context *ctx, jb_mesh *mesh
 
 extern "C" jb_status jb_update_fluid(jb_context *ctx, jb_mesh *mesh) {
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   if (!ctx->params.do_feedback) return JB_COMPLETE;  // jaybenne.cpp:590
   const DevMesh &M = mesh->dm;
   hipLaunchKernelGGL(k_update_fluid, dim3(grid_for(ctx, (long long)M.nblocks * M.ncell)), dim3(kBlock), 0,
@@ -612,6 +733,7 @@ extern "C" jb_status jb_update_fluid(jb_context *ctx, jb_mesh *mesh) {
 extern "C" jb_status jb_photon_reflect_bc(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
                                           int face) {
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   if (face < 0 || face > 5) return fail(JB_ERR_INVALID, "face must be 0..5");
   jb_status st = check_swarm(swarm, "jb_photon_reflect_bc");
   if (st != JB_COMPLETE) return st;
@@ -624,6 +746,7 @@ extern "C" jb_status jb_photon_reflect_bc(jb_context *ctx, jb_mesh *mesh, const 
 
 extern "C" jb_status jb_remove_marked_particles(jb_context *ctx, jb_swarm_view *swarm) {
   if (!ctx) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_remove_marked_particles");
   if (st != JB_COMPLETE) return st;
   const long long n = swarm->n;
@@ -662,6 +785,7 @@ extern "C" jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_s
                                       int64_t first, int64_t last, int nranks, int64_t *records_dev,
                                       int64_t record_capacity, int64_t *counts_host) {
   if (!ctx || !mesh || !counts_host) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_pack_outgoing");
   if (st != JB_COMPLETE) return st;
   if (first < 0 || last > swarm->n || first > last) return fail(JB_ERR_INVALID, "bad particle range");
@@ -704,6 +828,7 @@ extern "C" jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_s
 extern "C" jb_status jb_unpack_incoming(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm,
                                         const int64_t *records_dev, int64_t nrecords) {
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_unpack_incoming");
   if (st != JB_COMPLETE) return st;
   if (nrecords < 0) return fail(JB_ERR_INVALID, "negative record count");
@@ -737,6 +862,7 @@ extern "C" jb_status jb_gather_cells(jb_context *ctx, jb_mesh *mesh, int field, 
                                      const int32_t *blk_dev, const int32_t *cell_dev,
                                      double *out_dev) {
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   double *const *F = field_table(mesh->dm, field);
   if (!F) return fail(JB_ERR_INVALID, "jb_gather_cells: unknown field %d", field);
   if (n < 0) return fail(JB_ERR_INVALID, "negative cell count");
@@ -753,6 +879,7 @@ extern "C" jb_status jb_fill_cells(jb_context *ctx, jb_mesh *mesh, int field, in
                                    const int32_t *dst_cell_dev, const int32_t *src_blk_dev,
                                    const int32_t *src_cell_dev, const double *remote_dev) {
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
   double *const *F = field_table(mesh->dm, field);
   if (!F) return fail(JB_ERR_INVALID, "jb_fill_cells: unknown field %d", field);
   if (n < 0) return fail(JB_ERR_INVALID, "negative cell count");
@@ -853,6 +980,9 @@ __global__ void k_dbg_seed(uint32_t seed, uint32_t domain, unsigned long long id
                            unsigned long long *out) {
   *out = rng_seed_state(seed, domain, id);
 }
+__global__ void k_dbg_stream_start(uint32_t seed, unsigned long long id, unsigned long long *out) {
+  *out = rng_stream_start(seed, id);
+}
 __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
   load_math_tables();
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -866,7 +996,9 @@ __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
     case 5: out[i] = 1.0 / x[i]; break;
     case 6: out[i] = m_sqrt(x[i]); break;
     case 7: out[i] = m_div(x[i], x[(i + 1) % n]); break;
-    default: out[i] = m_div_r(x[i], 2.99792458e10, m_rcp_refined(2.99792458e10)); break;
+    case 8: out[i] = m_div_r(x[i], 2.99792458e10, m_rcp_refined(2.99792458e10)); break;
+    case 9: m_sincos2pi(x[i], s, c); out[i] = s; break;
+    default: m_sincos2pi(x[i], s, c); out[i] = c; break;
     }
   }
 }
@@ -940,6 +1072,7 @@ struct DbgBuf {
 extern "C" jb_status jb_debug_philox(jb_context *ctx, const uint32_t ctr[4], const uint32_t key[2],
                                      uint32_t out[4]) {
   if (!ctx) return fail(JB_ERR_INVALID, "null context");
+  JB_HIP(hipSetDevice(ctx->device));
   DbgBuf o;
   JB_HIP(o.put(nullptr, 16));
   hipLaunchKernelGGL(k_dbg_philox, dim3(1), dim3(1), 0, ctx->stream, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], (uint32_t *)o.d);
@@ -950,6 +1083,7 @@ extern "C" jb_status jb_debug_philox(jb_context *ctx, const uint32_t ctr[4], con
 extern "C" jb_status jb_debug_rocrand_philox(jb_context *ctx, uint64_t seed, uint64_t subsequence,
                                              uint32_t out[8]) {
   if (!ctx) return fail(JB_ERR_INVALID, "null context");
+  JB_HIP(hipSetDevice(ctx->device));
   DbgBuf o;
   JB_HIP(o.put(nullptr, 32));
   hipLaunchKernelGGL(k_dbg_rocrand, dim3(1), dim3(1), 0, ctx->stream, (unsigned long long)seed,
@@ -961,6 +1095,7 @@ extern "C" jb_status jb_debug_rocrand_philox(jb_context *ctx, uint64_t seed, uin
 extern "C" jb_status jb_debug_seed_state(jb_context *ctx, uint32_t seed, uint32_t domain,
                                          uint64_t id, uint64_t *state) {
   if (!ctx || !state) return fail(JB_ERR_INVALID, "bad argument");
+  JB_HIP(hipSetDevice(ctx->device));
   DbgBuf o;
   JB_HIP(o.put(nullptr, 8));
   hipLaunchKernelGGL(k_dbg_seed, dim3(1), dim3(1), 0, ctx->stream, seed, domain, (unsigned long long)id, (unsigned long long *)o.d);
@@ -968,9 +1103,21 @@ extern "C" jb_status jb_debug_seed_state(jb_context *ctx, uint32_t seed, uint32_
   JB_HIP(o.get(state, 8));
   return JB_COMPLETE;
 }
+extern "C" jb_status jb_debug_stream_start(jb_context *ctx, uint32_t seed, uint64_t id,
+                                           uint64_t *state) {
+  if (!ctx || !state) return fail(JB_ERR_INVALID, "bad argument");
+  JB_HIP(hipSetDevice(ctx->device));
+  DbgBuf o;
+  JB_HIP(o.put(nullptr, 8));
+  hipLaunchKernelGGL(k_dbg_stream_start, dim3(1), dim3(1), 0, ctx->stream, seed, (unsigned long long)id, (unsigned long long *)o.d);
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  JB_HIP(o.get(state, 8));
+  return JB_COMPLETE;
+}
 extern "C" jb_status jb_debug_draw_stream(jb_context *ctx, uint64_t state, int n, double *out_host,
                                           uint64_t *final_state) {
   if (!ctx || n < 0 || !final_state) return fail(JB_ERR_INVALID, "bad argument");
+  JB_HIP(hipSetDevice(ctx->device));
   DbgBuf o, f;
   JB_HIP(o.put(nullptr, sizeof(double) * n));
   JB_HIP(f.put(nullptr, 8));
@@ -983,6 +1130,7 @@ extern "C" jb_status jb_debug_draw_stream(jb_context *ctx, uint64_t state, int n
 extern "C" jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n,
                                    double *out_host) {
   if (!ctx || n < 0) return fail(JB_ERR_INVALID, "bad argument");
+  JB_HIP(hipSetDevice(ctx->device));
   DbgBuf x, o;
   JB_HIP(x.put(x_host, sizeof(double) * n));
   JB_HIP(o.put(nullptr, sizeof(double) * n));
@@ -994,6 +1142,7 @@ extern "C" jb_status jb_debug_math(jb_context *ctx, int which, const double *x_h
 extern "C" jb_status jb_debug_step_call(jb_context *ctx, int which, jb_debug_step *st,
                                         const double *tape, int ntape, int *ndraws) {
   if (!ctx || !st || !tape || ntape < 1 || !ndraws) return fail(JB_ERR_INVALID, "bad argument");
+  JB_HIP(hipSetDevice(ctx->device));
   DbgBuf s, t, n;
   JB_HIP(s.put(st, sizeof(*st)));
   JB_HIP(t.put(tape, sizeof(double) * ntape));
@@ -1008,6 +1157,7 @@ extern "C" jb_status jb_debug_sample_call(jb_context *ctx, int which, const doub
                                           const int32_t *i, const double *tape, int ntape,
                                           double out[4], int32_t iout[2], int *ndraws) {
   if (!ctx || !a || !i || !tape || ntape < 1 || !ndraws) return fail(JB_ERR_INVALID, "bad argument");
+  JB_HIP(hipSetDevice(ctx->device));
   DbgBuf da, di, t, o, io, n;
   JB_HIP(da.put(a, sizeof(double) * 8));
   JB_HIP(di.put(i, sizeof(int) * 4));

@@ -29,6 +29,15 @@ struct DevMesh {
   // library-owned per-cell mean free paths 1/(f sigma_a), 1/(sigma_s + (1-f) sigma_a), filled by
   // UpdateDerivedTransportFields for frequency-independent (gray) opacities
   double *const *lam_abs, *const *lam_sc;
+  const double *lam_base;  // lam_abs[b] = lam_base + 2 b ntot, lam_sc[b] = lam_base + (2 b + 1) ntot
+  // Crossing one face of a resident block b (face f = 2 axis + upper): nbr_ent[6 b + f] is -1 when
+  // the general relocation has to run (level change, destination not resident, outflow, inactive
+  // axis), else kind << 28 | destination block (local index) with kind 0 = the same-level
+  // neighbour, 1 = the same-level block on the other side of a periodic boundary, 2 = reflecting
+  // boundary (the block itself); nbr_x0[6 b + f] = coordinate of index 0 of the destination
+  // along the face's axis (Blk::x0).  Built by jb_mesh_create.
+  const int *nbr_ent;
+  const double *nbr_x0;
   // library-owned, gray opacities with DDMC: 8 doubles per cell {f sigma_a, sigma_a + sigma_s,
   // leak opacities P/dx of the faces x-, x+, y-, y+, z-, z+} -- everything a DDMC step gathers,
   // in one 64-byte record
@@ -122,10 +131,11 @@ __device__ __forceinline__ bool on_block(const DevMesh &M, int i, int j, int k) 
   return i >= M.is && i <= M.ie && j >= M.js && j <= M.je && k >= M.ks && k <= M.ke;
 }
 
-// cell index inside one block's [nk][nj][ni] array (a block has < 2^31 cells: checked at
-// jb_mesh_create)
+// cell index inside one block's [nk][nj][ni] array.  jb_mesh_create checks ni < 2^23 and
+// nj nk < 2^23, so both products are 24-bit multiplications (v_mad_i32_i24, full rate; a
+// general 32-bit multiply-add is a quarter-rate 64-bit one on gfx950).
 __device__ __forceinline__ int cidx(const DevMesh &M, int k, int j, int i) {
-  return (k * M.nj + j) * M.ni + i;
+  return __mul24(__mul24(k, M.nj) + j, M.ni) + i;
 }
 
 // ---- comm phase applied to one particle in flight ----------------------------------------------

@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(kBlock)
     load_block(M, b, B);
     const long long n = slot_base[b] + np;
     const uint64_t id = id_base[b] + (uint64_t)np;
-    LcgRng rng(rng_seed_state(P.key0, kRngDomainParticle, id));
+    LcgRng rng(rng_stream_start(P.key0, id));
     S.ip[n] = i; S.jp[n] = j; S.kp[n] = k;
     S.blk[n] = b;
     S.status[n] = ST_ACTIVE;
@@ -268,10 +268,10 @@ __global__ void __launch_bounds__(kBlock)
     S.y[n] = xc(B, 1, j) + B.dx[1] * (rng.drand() - 0.5);
     S.z[n] = xc(B, 2, k) + B.dx[2] * (rng.drand() - 0.5);
     const double theta = m_acos(2.0 * rng.drand() - 1.0);
-    const double phi = kTwoPi * rng.drand();
+    const double xi_phi = rng.drand();  // phi = 2 pi xi
     double sth, cth, sph, cph;
     m_sincos(theta, sth, cth);
-    m_sincos(phi, sph, cph);
+    m_sincos2pi(xi_phi, sph, cph);
     S.vx[n] = P.c * sth * cph;
     S.vy[n] = P.c * sth * sph;
     S.vz[n] = P.c * cth;
@@ -346,11 +346,17 @@ enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
 // 1 = gray: per-cell mean free paths / DDMC records precomputed by UpdateDerivedTransportFields;
 // 2 = gray and no absorption opacity at all (see imc_step_core; in a DDMC kernel it applies to
 //     the IMC steps of a hybrid deck).
-template <int NDIM, bool DDMC, bool TALLY, int GRAY>
+// EXACT (gray IMC kernels only): every resident block has power-of-two cell widths and a lower
+// corner that is a whole number of them (checked by jb_mesh_create; true of all the stepdiff
+// decks).  Then x0 + (i + 0.5) dx -+ 0.5 dx and upper - lower are exact, so the cell faces are
+// formed as fma(i, dx, x0) and + dx, and the nudge width as eps dx: the same doubles as the
+// general formulas (transport.cpp:114-119), in 3 instead of 8 operations per axis.
+template <int NDIM, bool DDMC, bool TALLY, int GRAY, bool EXACT = false>
 __global__ void
 __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER_SIMD)
     k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
                 long long last, unsigned long long *counters) {
+  static_assert(!EXACT || (GRAY != 0 && !DDMC), "EXACT is a variant of the gray IMC kernels");
   // Small meshes (the reference's 1-D decks: ~1e2 cells under 1e5..1e8 particles): the census
   // tally of every workgroup goes to LDS and is flushed once at the end, instead of 1e8 global
   // atomics contending for a handful of cache lines.
@@ -390,8 +396,10 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   constexpr long long kChunk = JB_DDMC_CHUNK;
   long long chunk_pos = 0, chunk_end = 0;
 
-  unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0, c_ev = 0;
-  unsigned int c_pass = 0, c_service = 0;  // wave-level: event-loop passes, service phases
+  unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0;
+  // wave-level (scalar): events = running lanes summed over the passes, passes, service phases
+  unsigned long long c_ev = 0;
+  unsigned int c_pass = 0, c_service = 0;
 
   // lane state
   int ls = LS_IDLE;
@@ -408,9 +416,9 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
 
   auto bind_block = [&](int blk) {
     load_block(M, blk, B);
-    if constexpr (kFastGray) {
-      f0 = (gcptr)M.lam_abs[blk];
-      f1 = (gcptr)M.lam_sc[blk];
+    if constexpr (kFastGray) {  // (library-owned, contiguous: no pointer-table load)
+      f0 = (gcptr)(M.lam_base + (long long)(2 * blk) * M.ntot);
+      f1 = (gcptr)(M.lam_base + (long long)(2 * blk + 1) * M.ntot);
     } else if constexpr (kPackedDdmc) {
       f0 = (gcptr)M.ddmc_cell[blk];
       f1 = (gcptr)M.lam_abs[blk];
@@ -430,6 +438,30 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
     s.zu = xc(Bq, 2, kp) + 0.5 * Bq.dx[2];
   };
 
+  // the comm phase of the reference, for one particle in flight: boundary conditions
+  // (boundaries.hpp:46-82, periodic, outflow), destination block, SampleDDMCBlockFace
+  auto relocate = [&]() {
+    if (!apply_swarm_bcs<NDIM>(M, x, y, z, vx, vy, vz)) {
+      status = ST_ESCAPED;
+      ls = LS_DONE;
+    } else {
+      const int g = find_block<NDIM>(M, x, y, z);
+      const int li = M.local_index[g];
+      if (li < 0) {  // not resident here: hand the particle to the block's owner
+        status = ST_OUTGOING;
+        b = g;  // global id travels in blk
+        ls = LS_DONE;
+      } else {
+        b = li;
+        bind_block(b);
+        if constexpr (DDMC && multi_d)
+          sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
+        xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // next launch's transport.cpp:96
+        ls = (t < t_end) ? LS_RUN : LS_DONE;
+      }
+    }
+  };
+
 #ifdef JB_TIMING  // scratch diagnostics: CNT_PASSES / CNT_SERVICE carry cycles / 1024 instead
   unsigned long long cyc_ev = 0, cyc_sv = 0, cyc_mark = __builtin_readcyclecounter();
 #endif
@@ -439,31 +471,15 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
 #ifdef JB_TIMING
     { const unsigned long long now = __builtin_readcyclecounter(); cyc_ev += now - cyc_mark; cyc_mark = now; }
 #endif
-    if (ls == LS_RELOC) {
-      // the comm phase of the reference, for one particle in flight: boundary conditions
-      // (boundaries.hpp:46-82, periodic, outflow), destination block, SampleDDMCBlockFace
-      if (!apply_swarm_bcs<NDIM>(M, x, y, z, vx, vy, vz)) {
-        status = ST_ESCAPED;
-        ls = LS_DONE;
-      } else {
-        const int g = find_block<NDIM>(M, x, y, z);
-        const int li = M.local_index[g];
-        if (li < 0) {  // not resident here: hand the particle to the block's owner
-          status = ST_OUTGOING;
-          b = g;  // global id travels in blk
-          ls = LS_DONE;
-        } else {
-          b = li;
-          bind_block(b);
-          if constexpr (DDMC && multi_d)
-            sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
-          xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // next launch's transport.cpp:96
-          ls = (t < t_end) ? LS_RUN : LS_DONE;
-        }
-      }
+    if constexpr (!kFastGray) {  // (the gray IMC kernels relocate inside their event loop)
+      if (ls == LS_RELOC) relocate();
     }
     if (ls == LS_DONE) {
-      if constexpr (kReloadBlock) load_block(M, b, B);
+      // (a particle relocated to a block that is not resident carries the GLOBAL id in b: the
+      // geometry tables only cover resident blocks, and nothing below reads B for it)
+      if constexpr (kReloadBlock) {
+        if (status != ST_OUTGOING) load_block(M, b, B);
+      }
       if constexpr (kPackedDdmc) {
         if (pend >= 0 && !resample) {  // (absorbed right after a leak: the record still gets it)
           Step s;
@@ -617,10 +633,95 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
     { const unsigned long long now = __builtin_readcyclecounter(); cyc_sv += now - cyc_mark; cyc_mark = now; }
 #endif
     int thresh = 1;
-    while (__popcll(__ballot(ls == LS_RUN)) >= thresh) {
+    int nrun = running;
+    while (nrun >= thresh) {
       ++c_pass;
-      if (ls == LS_RUN) {
-        ++c_ev;
+      c_ev += (unsigned int)nrun;
+      if constexpr (kFastGray) {
+        if (ls == LS_RUN) {
+          ImcCell c;
+          if constexpr (EXACT) {
+            c.xl = m_fma((double)ip, B.dx[0], B.x0[0]); c.xu = c.xl + B.dx[0];
+            c.yl = m_fma((double)jp, B.dx[1], B.x0[1]); c.yu = c.yl + B.dx[1];
+            c.zl = m_fma((double)kp, B.dx[2], B.x0[2]); c.zu = c.zl + B.dx[2];
+            c.fdx = kEpsImc * B.dx[0]; c.fdy = kEpsImc * B.dx[1]; c.fdz = kEpsImc * B.dx[2];
+          } else {  // transport.cpp:114-119, transport_utils.hpp:151-153
+            c.xl = xc(B, 0, ip) - 0.5 * B.dx[0]; c.xu = xc(B, 0, ip) + 0.5 * B.dx[0];
+            c.yl = xc(B, 1, jp) - 0.5 * B.dx[1]; c.yu = xc(B, 1, jp) + 0.5 * B.dx[1];
+            c.zl = xc(B, 2, kp) - 0.5 * B.dx[2]; c.zu = xc(B, 2, kp) + 0.5 * B.dx[2];
+            c.fdx = kEpsImc * (c.xu - c.xl); c.fdy = kEpsImc * (c.yu - c.yl);
+            c.fdz = kEpsImc * (c.zu - c.zl);
+          }
+          // per-cell mean free paths precomputed by k_fleck: two gathers instead of three, and
+          // no division (same values: same operations on the same operands)
+          const int q = cidx(M, kp, jp, ip);
+          bool is_absorbed, is_scattered;
+          imc_step_fast<NDIM, kNoAbs>(c, vv, P.rc, t_end, B.dx_push, kNoAbs ? 0.0 : f0[q], f1[q],
+                                      rng, t, x, y, z, vx, vy, vz, ip, jp, kp, is_absorbed,
+                                      is_scattered);
+          if (!on_block(M, ip, jp, kp)) {
+            ls = LS_RELOC;  // comm phase: below, for the lanes that need it
+          } else if (is_absorbed) {  // transport.cpp:157-163
+            if (M.owned[b]) {
+              atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
+              status = ST_ABSORBED;
+            } else {
+              status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
+            }
+            ls = LS_DONE;
+          } else {
+            if (is_scattered) scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
+            if (!(t < t_end)) ls = LS_DONE;                  // census
+          }
+        }
+        // A particle that left its block is relocated at once (in the reference: end of the
+        // launch, swarm send / receive, a new launch).  On the headline workload that is 0.36 %
+        // of the events, i.e. one wave pass in five has a lane here, so the common cases -- one
+        // face crossed into a resident block of the same size, a periodic wrap, a reflection --
+        // are served from a per-(block, face) table: destination, and the one geometry value
+        // that changes.  Same arithmetic on the position as apply_swarm_bcs; the new cell index
+        // is what Xtoijk gives for a particle eps_imc dx inside the face it came through (first
+        // or last cell along the axis, the others unchanged).  Everything else takes relocate().
+        if (__ballot(ls == LS_RELOC) != 0ull) {
+          if (ls == LS_RELOC) {
+            const int ox = (ip < M.is) ? 0 : ((ip > M.ie) ? 1 : -1);
+            const int oy = (jp < M.js) ? 2 : ((jp > M.je) ? 3 : -1);
+            const int oz = (kp < M.ks) ? 4 : ((kp > M.ke) ? 5 : -1);
+            const int nout = (int)(ox >= 0) + (int)(oy >= 0) + (int)(oz >= 0);
+            const int face = ox >= 0 ? ox : (oy >= 0 ? oy : oz);
+            int ent = -1;
+            double nx0 = 0.0;
+            if (nout == 1) {
+              ent = M.nbr_ent[6 * b + face];
+              nx0 = ((gcptr)M.nbr_x0)[6 * b + face];
+            }
+            if (ent >= 0) {
+              const int kind = ent >> 28, axis = face >> 1;
+              const bool up = (face & 1) != 0;
+              b = ent & 0x0fffffff;
+              double pos = axis == 0 ? x : (axis == 1 ? y : z);
+              const double lo = axis == 0 ? M.gmin[0] : (axis == 1 ? M.gmin[1] : M.gmin[2]);
+              const double hi = axis == 0 ? M.gmax[0] : (axis == 1 ? M.gmax[1] : M.gmax[2]);
+              if (kind == 1) pos = up ? lo + (pos - hi) : hi - (lo - pos);       // periodic
+              else if (kind == 2) pos = up ? hi - (pos - hi) : lo + (lo - pos);  // boundaries.hpp:46-82
+              const double vsgn = kind == 2 ? -1.0 : 1.0;
+              const bool at_first = (kind == 2) != up;  // entered through the lower face
+              if (axis == 0) {
+                x = pos; vx *= vsgn; B.x0[0] = nx0; ip = at_first ? M.is : M.ie;
+              } else if (axis == 1) {
+                y = pos; vy *= vsgn; B.x0[1] = nx0; jp = at_first ? M.js : M.je;
+              } else {
+                z = pos; vz *= vsgn; B.x0[2] = nx0; kp = at_first ? M.ks : M.ke;
+              }
+              f0 = (gcptr)(M.lam_base + (long long)(2 * b) * M.ntot);
+              f1 = (gcptr)(M.lam_base + (long long)(2 * b + 1) * M.ntot);
+              ls = (t < t_end) ? LS_RUN : LS_DONE;
+            } else {
+              relocate();
+            }
+          }
+        }
+      } else if (ls == LS_RUN) {
         Step s;
         Blk Bl;
         if constexpr (kReloadBlock) load_block(M, b, Bl);
@@ -633,12 +734,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         s.is_absorbed = false; s.is_scattered = false; s.is_rejected = false;
         s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
         bool is_ddmc_step = false;
-        if constexpr (kFastGray) {
-          // per-cell mean free paths precomputed by k_fleck: two gathers instead of three, and
-          // no division (same values: same operations on the same operands)
-          if constexpr (kNoAbs) imc_step_core<NDIM, true>(s, 0.0, f1[q], rng);
-          else imc_step_core<NDIM, false>(s, f0[q], f1[q], rng);
-        } else if constexpr (kPackedDdmc) {
+        if constexpr (kPackedDdmc) {
           typedef double v4d __attribute__((ext_vector_type(4)));
           typedef const v4d __attribute__((address_space(1))) *grec;
           const grec rec = (grec)(f0 + 8 * q);
@@ -683,18 +779,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
         if constexpr (kPackedDdmc) { pend = s.pend; pz1 = s.pz1; pz2 = s.pz2; }
 
-        // Xtoijk (transport.cpp:146)
-        if constexpr (kFastGray) {
-          // After an IMC step a particle is either >= eps_imc dx inside its cell or has been put
-          // eps_imc dx beyond the face it reached (transport_utils.hpp:151-159), so
-          // floor((x - xmin) / dx) moves by exactly one in that direction: two compares per axis
-          // instead of subtract / multiply / floor / convert.
-          ip += (int)(x > s.xu) - (int)(x < s.xl);
-          if constexpr (multi_d) jp += (int)(y > s.yu) - (int)(y < s.yl);
-          if constexpr (three_d) kp += (int)(z > s.zu) - (int)(z < s.zl);
-        } else {
-          xtoijk<NDIM>(M, Bp, x, y, z, ip, jp, kp);
-        }
+        xtoijk<NDIM>(M, Bp, x, y, z, ip, jp, kp);  // transport.cpp:146
 
         if (!on_block(M, ip, jp, kp)) {
           if constexpr (DDMC) {  // transport_ddmc.cpp:203-211: zero velocity flags a DDMC leak
@@ -723,7 +808,8 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           if (!(t < t_end)) ls = LS_DONE;                    // census
         }
       }
-      waste += running - __popcll(__ballot(ls == LS_RUN));
+      nrun = __popcll(__ballot(ls == LS_RUN));
+      waste += running - nrun;
       if (waste >= kServiceBudget) thresh = 65;  // wave-uniform: ends the loop
     }
   }
@@ -739,7 +825,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   }
 
   unsigned long long r_census = wave_sum(c_census), r_abs = wave_sum(c_abs), r_esc = wave_sum(c_esc),
-                     r_out = wave_sum(c_out), r_ev = wave_sum(c_ev);
+                     r_out = wave_sum(c_out), r_ev = c_ev;
   if (lane == 0) {
     if (r_census) atomicAdd(&counters[CNT_CENSUS], r_census);
     if (r_abs) atomicAdd(&counters[CNT_ABSORBED], r_abs);

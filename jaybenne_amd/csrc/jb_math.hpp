@@ -29,15 +29,41 @@
 
 namespace jb {
 
+
+// fma through the 3-address VOP3 form.  Left to itself the compiler turns a Horner step
+// p = fma(r, p, C) with a loop-invariant constant C into "v_mov_b64 acc, C; v_fmac_f64 acc, r, p"
+// (two instructions; the kernels are VALU-issue bound).  Same operation, same rounding.
+__device__ __forceinline__ double m_fma(double a, double b, double c) {
+#ifdef JB_NO_ASM_FMA
+  return fma(a, b, c);
+#else
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+#endif
+}
+
+// min of two non-NaN numbers / minNum when one is NaN: one v_min_f64 (std::min written as
+// `(b < a) ? b : a` costs a compare and two selects).  Inputs are results of arithmetic, i.e.
+// already canonical, which is all the IEEE-mode v_min_f64 asks for.
+__device__ __forceinline__ double m_min(double a, double b) {
+  double d;
+  asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 __shared__ double lds_log_tab[JB_LOG_N][3];
 __shared__ double lds_sc_tab[JB_SC_N + 1][2];
+__shared__ double lds_sc2_tab[JB_SC2_N + 1][2];
 
-// Copies the two tables into this workgroup's LDS (4.1 KB); ends with a barrier.
+// Copies the three tables into this workgroup's LDS (8.2 KB); ends with a barrier.
 __device__ __forceinline__ void load_math_tables() {
   for (int q = threadIdx.x; q < JB_LOG_N * 3; q += blockDim.x)
     (&lds_log_tab[0][0])[q] = (&jb_log_tab[0][0])[q];
   for (int q = threadIdx.x; q < (JB_SC_N + 1) * 2; q += blockDim.x)
     (&lds_sc_tab[0][0])[q] = (&jb_sc_tab[0][0])[q];
+  for (int q = threadIdx.x; q < (JB_SC2_N + 1) * 2; q += blockDim.x)
+    (&lds_sc2_tab[0][0])[q] = (&jb_sc2_tab[0][0])[q];
   __syncthreads();
 }
 
@@ -82,12 +108,15 @@ __device__ __forceinline__ double m_div(double a, double b) { return m_div_r(a, 
 
 __device__ __forceinline__ double m_log(double x) {  // x positive, finite, normal
   constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-  const uint64_t ix = (uint64_t)__double_as_longlong(x);
-  const uint64_t tmp = ix - JB_LOG_OFF;
-  const int i = (int)((tmp >> 45) & (JB_LOG_N - 1));
-  const int k = (int)(uint32_t)(tmp >> 32) >> 20;  // = (int64)tmp >> 52, from the high word
-  const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
-  const double z = __longlong_as_double((long long)iz);
+  // tmp = bits(x) - JB_LOG_OFF; i = (tmp >> 45) & 127; k = (int64)tmp >> 52;
+  // z = bits(x) - (tmp & 0xfff0000000000000): the low word of JB_LOG_OFF is zero, so all of it
+  // happens in the high word
+  static_assert((JB_LOG_OFF & 0xffffffffull) == 0ull, "m_log works on the high word only");
+  const uint32_t hx = (uint32_t)__double2hiint(x);
+  const uint32_t th = hx - (uint32_t)(JB_LOG_OFF >> 32);
+  const int i = (int)((th >> 13) & (JB_LOG_N - 1));
+  const int k = (int)th >> 20;
+  const double z = __hiloint2double((int)(hx - (th & 0xfff00000u)), __double2loint(x));
   const double invc = lds_log_tab[i][0], lc_hi = lds_log_tab[i][1], lc_lo = lds_log_tab[i][2];
   const double r = fma(z, invc, -1.0);
   const double kd = (double)k;
@@ -95,12 +124,12 @@ __device__ __forceinline__ double m_log(double x) {  // x positive, finite, norm
   const double hi = w + r;
   const double lo = ((w - hi) + r) + fma(kd, ln2_lo, lc_lo);
   const double r2 = r * r;
-  double p = fma(r, -0.125, 1.0 / 7.0);
-  p = fma(r, p, -1.0 / 6.0);
-  p = fma(r, p, 0.2);
-  p = fma(r, p, -0.25);
-  p = fma(r, p, 1.0 / 3.0);
-  p = fma(r, p, -0.5);
+  double p = m_fma(r, -0.125, 1.0 / 7.0);
+  p = m_fma(r, p, -1.0 / 6.0);
+  p = m_fma(r, p, 0.2);
+  p = m_fma(r, p, -0.25);
+  p = m_fma(r, p, 1.0 / 3.0);
+  p = m_fma(r, p, -0.5);
   return fma(r2, p, lo) + hi;
 }
 
@@ -111,13 +140,31 @@ __device__ __forceinline__ void m_sincos(double x, double &sn, double &cs) {  //
   const double si = lds_sc_tab[i][0], ci = lds_sc_tab[i][1];
   const double r2 = r * r;
   const double sr = fma(r * r2,
-                        fma(r2, fma(r2, fma(r2, 1.0 / 362880.0, -1.0 / 5040.0), 1.0 / 120.0),
-                            -1.0 / 6.0),
+                        m_fma(r2, m_fma(r2, m_fma(r2, 1.0 / 362880.0, -1.0 / 5040.0), 1.0 / 120.0),
+                              -1.0 / 6.0),
                         r);
   const double cm1 =
-      r2 * fma(r2, fma(r2, fma(r2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5);
+      r2 * m_fma(r2, m_fma(r2, m_fma(r2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5);
   sn = si + fma(si, cm1, ci * sr);
   cs = ci + fma(ci, cm1, -(si * sr));
+}
+
+// sin and cos of 2 pi u for a uniform u in (0,1) (the azimuth of every direction sample:
+// scattering.hpp:24-27, transport_utils.hpp:33-38,271-275, sourcing.cpp:181): the grid point
+// (256 per turn) is found on u itself -- i = (int)(256 u + 0.5), u - i/256 is exact -- so the
+// reduction costs one multiplication by 2 pi of a remainder |u - i/256| <= 1/512 instead of an
+// extended-precision subtraction, and |r| <= pi/256 needs only r - r^3/6 + r^5/120 and
+// -r^2/2 + r^4/24 - r^6/720 (next terms < 1e-17).  Absolute error <= 1.7e-16.
+constexpr double kTwoPiM = 6.283185307179586476925286766559;
+__device__ __forceinline__ void m_sincos2pi(double u, double &sn, double &cs) {
+  const int i = (int)fma(u, 256.0, 0.5);
+  const double r = fma((double)i, -0.00390625, u) * kTwoPiM;
+  const double si = lds_sc2_tab[i][0], ci = lds_sc2_tab[i][1];
+  const double r2 = r * r;
+  const double sr = m_fma(r * r2, m_fma(r2, 1.0 / 120.0, -1.0 / 6.0), r);
+  const double cm1 = r2 * m_fma(r2, m_fma(r2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
+  sn = m_fma(si, cm1, m_fma(ci, sr, si));
+  cs = m_fma(ci, cm1, m_fma(-si, sr, ci));
 }
 
 __device__ __forceinline__ double m_acos_R(double z) {

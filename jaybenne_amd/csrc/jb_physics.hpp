@@ -36,9 +36,8 @@ __device__ __forceinline__ void face_iso_dir(double vv, double xi1, double xi2, 
   const double mu = m_sqrt(xi1);
   const double om = 1.0 - mu * mu;  // exactly 0 when mu rounds to 1, else >= 2^-53
   const double nu = (om > 0.0) ? m_sqrt(om > 0.0 ? om : 1.0) : 0.0;
-  const double phi = kTwoPi * xi2;
   double sn, cs;
-  m_sincos(phi, sn, cs);
+  m_sincos2pi(xi2, sn, cs);
   v1 = vv * mu;
   v2 = vv * nu * cs;
   v3 = vv * nu * sn;
@@ -56,11 +55,11 @@ __device__ __forceinline__ void sample_face_iso_dir(double vv, Rng &rng, double 
 // reference scattering.hpp:21-29 -- 2 draws
 template <class Rng>
 __device__ __forceinline__ void scatter(Rng &rng, double vv, double &vx, double &vy, double &vz) {
-  const double mu = 2.0 * rng.drand() - 1.0;
-  const double phi = kTwoPi * rng.drand();
+  const double mu = fma(2.0, rng.drand(), -1.0);  // (2 xi is exact: same value as 2 xi - 1)
+  const double xi2 = rng.drand();
   const double st = m_sqrt(1.0 - mu * mu);  // |mu| <= 1 - 2^-52, so 1 - mu^2 >= 2^-52
   double sn, cs;
-  m_sincos(phi, sn, cs);
+  m_sincos2pi(xi2, sn, cs);
   vx = vv * st * cs;
   vy = vv * st * sn;
   vz = vv * mu;
@@ -169,6 +168,69 @@ __device__ __forceinline__ void imc_step_core(Step &s, double lam_abs, double la
   if (multi_d && fabs(s.y - s.yu) < fdy) s.y = s.yu + fdy;
   if (three_d && fabs(s.z - s.zl) < fdz) s.z = s.zl - fdz;
   if (three_d && fabs(s.z - s.zu) < fdz) s.z = s.zu + fdz;
+}
+
+// The same step as imc_step_core for the gray-opacity tracking kernels, fused with what the
+// kernel does around it (transport.cpp:114-119,146): the caller hands in the cell's faces and the
+// three nudge widths eps_imc (upper - lower), and gets the cell index of the new position back.
+//  * The two face tests of an axis are made on the position before either nudge: the cell is
+//    ~4e8 nudge widths across, so they cannot both hold, and a particle put eps below the lower
+//    face is not within eps of the upper one -- the same result as the reference's sequence.
+//  * Xtoijk after the step (transport.cpp:146): a particle is either >= eps inside its cell or
+//    has just been put eps beyond a face, so floor((x - xmin) / dx) changes exactly when a nudge
+//    fired, by one, in that direction.
+__device__ __forceinline__ void idx_step(int &i, bool hi, bool lo) {
+  i += (int)hi;
+  i -= (int)lo;
+}
+
+struct ImcCell {
+  double xl, xu, yl, yu, zl, zu;  // faces
+  double fdx, fdy, fdz;           // eps_imc_offset * (upper - lower)
+};
+template <int NDIM, bool NOABS, class Rng>
+__device__ __forceinline__ void imc_step_fast(const ImcCell &c, double vv, double rvv, double t_end,
+                                              double dx_push0, double lam_abs, double lam_sc,
+                                              Rng &rng, double &t, double &x, double &y, double &z,
+                                              double vx, double vy, double vz, int &ip, int &jp,
+                                              int &kp, bool &is_absorbed, bool &is_scattered) {
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  double dx_abs = 0.0;
+  if constexpr (NOABS) rng.skip();
+  else dx_abs = -lam_abs * m_log(rng.drand());
+  const double dx_sc = -lam_sc * m_log(rng.drand());
+  const double dx_end = vv * (t_end - t);
+  // std::min of two numbers is one v_min_f64.  A velocity component that is exactly zero makes
+  // m_div return NaN (0 x inf in its first step), and minNum(x, NaN) = x: the distance stays as
+  // it is, which is what the reference's `(v > 0) ? ... : (v < 0) ? ... : dx_push` says.
+  double dx_push = m_min(dx_push0, dx_end);
+  dx_push = m_min(dx_push, m_div(vv * ((vx > 0.0 ? c.xu : c.xl) - x), vx));
+  if (multi_d) dx_push = m_min(dx_push, m_div(vv * ((vy > 0.0 ? c.yu : c.yl) - y), vy));
+  if (three_d) dx_push = m_min(dx_push, m_div(vv * ((vz > 0.0 ? c.zu : c.zl) - z), vz));
+  is_absorbed = NOABS ? false : (dx_abs < dx_push) && (dx_abs < dx_sc);
+  is_scattered = !is_absorbed && (dx_sc < dx_push);
+  const double dt_push =
+      m_div_r(NOABS ? m_min(dx_push, dx_sc)
+                    : (is_absorbed ? dx_abs : (is_scattered ? dx_sc : dx_push)), vv, rvv);
+  t += dt_push;
+  x += vx * dt_push;
+  y += (multi_d ? 1.0 : 0.0) * vy * dt_push;
+  z += (three_d ? 1.0 : 0.0) * vz * dt_push;
+  {
+    const bool lo = fabs(x - c.xl) < c.fdx, hi = fabs(x - c.xu) < c.fdx;
+    x = lo ? c.xl - c.fdx : (hi ? c.xu + c.fdx : x);
+    idx_step(ip, hi, lo);
+  }
+  if (multi_d) {
+    const bool lo = fabs(y - c.yl) < c.fdy, hi = fabs(y - c.yu) < c.fdy;
+    y = lo ? c.yl - c.fdy : (hi ? c.yu + c.fdy : y);
+    idx_step(jp, hi, lo);
+  }
+  if (three_d) {
+    const bool lo = fabs(z - c.zl) < c.fdz, hi = fabs(z - c.zu) < c.fdz;
+    z = lo ? c.zl - c.fdz : (hi ? c.zu + c.fdz : z);
+    idx_step(kp, hi, lo);
+  }
 }
 
 // reference transport_utils.hpp:111-160 -- one IMC tracking step, 2 draws
@@ -290,9 +352,9 @@ __device__ __forceinline__ void ddmc_census_resample(Step &s, Rng &rng) {
   s.y = s.yl + rng.drand() * dy;
   const double mu = 1.0 - 2.0 * rng.drand();
   const double nu = sqrt(1.0 - mu * mu);
-  const double phi = kTwoPi * rng.drand();
+  const double xi2 = rng.drand();
   double sn, cs;
-  m_sincos(phi, sn, cs);
+  m_sincos2pi(xi2, sn, cs);
   s.vz = s.vv * mu;
   s.vx = s.vv * nu * cs;
   s.vy = s.vv * nu * sn;

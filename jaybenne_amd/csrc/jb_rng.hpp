@@ -6,10 +6,10 @@
 // 64-bit state travels with the particle (8 bytes in the swarm) -- one linear congruential
 // stream per history, as in MCNP and OpenMC:
 //
-//   seeding  state = words (0,1) of Philox4x32-10(counter = {0, 0, id_lo, id_hi},
-//            key = {seed, domain}); Philox laid out like rocRAND's
-//            rocrand_init(seed, subsequence = id, offset = 0).  Done once, when the particle is
-//            sourced.
+//   seeding  the streams are disjoint segments of the generator's single cycle, a fixed stride
+//            S = 2^34 - 3 apart (rng_stream_start below); the base point comes from
+//            Philox4x32-10 laid out like rocRAND's rocrand_init(seed, subsequence, offset = 0).
+//            Done once, when the particle is sourced.
 //   draw     s = s * 6364136223846793005 + 1442695040888963407 (mod 2^64, Knuth's MMIX LCG);
 //            xi = ((s >> 12) + 0.5) * 2^-52   in the open interval (0,1)
 //
@@ -54,23 +54,47 @@ __device__ __forceinline__ uint64_t rng_seed_state(uint32_t seed, uint32_t domai
   return ((uint64_t)b.w1 << 32) | b.w0;
 }
 
-// (k52 + 0.5) * 2^-52, formed without an integer -> double conversion: 1.k52 (exponent bits of
-// 1.0 over the 52-bit mantissa k52) minus 1 is k52 * 2^-52 exactly, and adding 2^-53 is exact in
-// 53 bits.  Same value as ((double)k52 + 0.5) * 2^-52.
+// Start of the stream of the particle with creation index `id`.  All particle streams are
+// DISJOINT segments of the one 2^64-cycle of the generator, a fixed stride apart (the
+// arrangement of MCNP / OpenMC; Brown, "Random number generation with arbitrary strides", 1994):
+//   start(id) = T_S^(id mod 2^30) ( base(id >> 30) ),   T_S = S steps of the recurrence,
+//   S = 2^34 - 3 (odd, so a skip changes every bit of the state; 2^30 S < 2^64: no wrap),
+//   base(g) = words (0,1) of Philox4x32-10(counter = {0, 0, g_lo, g_hi}, key = {seed, 0}).
+// Two particles whose ids lie in the same block of 2^30 consecutive ids cannot see a common
+// draw unless one of them draws more than S = 1.7e10 uniforms in its life (an IMC history of
+// the stepdiff decks draws ~5e3 per cycle); blocks of ids start at unrelated (Philox) points.
+constexpr uint64_t kLcgMul = 6364136223846793005ull, kLcgInc = 1442695040888963407ull;
+constexpr uint64_t kStrideMul = 0xb0c24fccf6a8435dull;  // a^S mod 2^64
+constexpr uint64_t kStrideInc = 0x574abb626a358eebull;  // c (a^S - 1) / (a - 1) mod 2^64
+__device__ __forceinline__ uint64_t rng_stream_start(uint32_t seed, uint64_t id) {
+  uint64_t s = rng_seed_state(seed, kRngDomainParticle, id >> 30);
+  uint64_t A = kStrideMul, C = kStrideInc;
+  for (uint32_t n = (uint32_t)id & 0x3fffffffu; n != 0u; n >>= 1) {  // T_S^n by squaring
+    if (n & 1u) s = A * s + C;
+    C = (A + 1ull) * C;
+    A = A * A;
+  }
+  return s;
+}
+
+// (k52 + 0.5) * 2^-52, formed without an integer -> double conversion from 1.k52 (exponent bits
+// of 1.0 over the 52-bit mantissa k52).  Same value as ((double)k52 + 0.5) * 2^-52.
 __device__ __forceinline__ double u52_to_double(uint64_t k52) {
   const double one_to_two = __longlong_as_double((long long)(0x3ff0000000000000ull | k52));
-  return (one_to_two - 1.0) + 1.1102230246251565404236316680908203125e-16;  // 2^-53
+  // 1.k52 - (1 - 2^-53) = (2 k52 + 1) 2^-53: an odd 53-bit integer times 2^-53, so the single
+  // subtraction is exact
+  return one_to_two - 0.99999999999999988897769753748434595763683319091796875;  // 1 - 2^-53
 }
 
 struct LcgRng {
   uint64_t s;
   __device__ __forceinline__ explicit LcgRng(uint64_t state) : s(state) {}
   __device__ __forceinline__ double drand() {
-    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    s = s * kLcgMul + kLcgInc;
     return u52_to_double(s >> 12);
   }
   // consume one draw whose value cannot influence the result
-  __device__ __forceinline__ void skip() { s = s * 6364136223846793005ull + 1442695040888963407ull; }
+  __device__ __forceinline__ void skip() { s = s * kLcgMul + kLcgInc; }
 };
 
 // Replays a caller-supplied list of uniforms (debug entry points / golden-vector tests only).

@@ -192,6 +192,11 @@ class MeshData:
         self.kernel_events = None   # set to [] to time every transport launch with HIP events
         self._exchange = None       # halo.FieldExchange, built on first use
         self.phase_times = None     # set to {} to account wall time per phase of RadiationStep
+        # hand-off accounting (bench.py): records this rank handed to others, wall time spent in
+        # the exchange phase, transport iterations, since the caller last zeroed them
+        self.handoff_records = 0
+        self.exchange_seconds = 0.0
+        self.transport_iterations_total = 0
         self._make_mesh_handle(owner)
 
     def reserve(self, nslots: int) -> None:
@@ -468,6 +473,7 @@ def _exchange(md: MeshData, first: int, last: int):
     if total == 0:
         return 0, 0
     nsend = int(counts.sum())
+    md.handoff_records += nsend
     recv = md.comm.exchange_records(md.records[:nsend] if nsend else None, counts, md.device,
                                     recv_counts=matrix[:, md.rank].copy())
     nrecv = 0 if recv is None else int(recv.shape[0])
@@ -528,10 +534,13 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
         with _Phase(md, f"transport[{min(it, 2)}]"):
             transport(md, t_start, dt, first, last, fuse_census_tally=True)
         md.transport_iterations += 1
+        md.transport_iterations_total += 1
         if md.nranks == 1:
             break
         with _Phase(md, "exchange"):
+            t_x = time.perf_counter()
             nrecv, moved = _exchange(md, first, last)
+            md.exchange_seconds += time.perf_counter() - t_x
         if moved == 0:
             break
         first = md.n - nrecv        # the arrivals, appended at the end of the swarm

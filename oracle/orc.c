@@ -35,6 +35,7 @@ void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
 uint64_t orc_seed_state(uint32_t seed, uint32_t domain, uint64_t id) {
   return orc_rng_seed_state(seed, domain, id);
 }
+uint64_t orc_stream_start(uint32_t seed, uint64_t id) { return orc_rng_stream_start(seed, id); }
 uint64_t orc_draw_stream(uint64_t state, int n, double *out) {
   orc_rng r = orc_rng_from_state(state);
   for (int i = 0; i < n; ++i) out[i] = orc_drand(&r);
@@ -45,6 +46,9 @@ void orc_math_log(const double *x, int n, double *out) {
 }
 void orc_math_sincos(const double *x, int n, double *sn, double *cs) {
   for (int i = 0; i < n; ++i) orc_sincos(x[i], &sn[i], &cs[i]);
+}
+void orc_math_sincos2pi(const double *u, int n, double *sn, double *cs) {
+  for (int i = 0; i < n; ++i) orc_sincos2pi(u[i], &sn[i], &cs[i]);
 }
 void orc_math_acos(const double *x, int n, double *out) {
   for (int i = 0; i < n; ++i) out[i] = orc_acos(x[i]);
@@ -289,8 +293,8 @@ void orc_source_fill(const orc_mesh *M, const orc_params *P, orc_swarm *S, int s
           double dej = 0.0;
           for (int np = pstart; np < pstart + npart; ++np) {
             const int64_t n = slot_base[b] + np;
-            orc_rng rng = orc_rng_from_state(orc_rng_seed_state(
-                (uint32_t)P->seed, ORC_RNG_DOMAIN_PARTICLE, id_base[b] + (uint64_t)np));
+            orc_rng rng = orc_rng_from_state(
+                orc_rng_stream_start((uint32_t)P->seed, id_base[b] + (uint64_t)np));
             S->ip[n] = i; S->jp[n] = j; S->kp[n] = k;
             S->blk[n] = b;
             S->status[n] = ORC_ST_ACTIVE;
@@ -298,10 +302,10 @@ void orc_source_fill(const orc_mesh *M, const orc_params *P, orc_swarm *S, int s
             S->y[n] = yi + dx_j * (orc_drand(&rng) - 0.5);
             S->z[n] = zi + dx_k * (orc_drand(&rng) - 0.5);
             const double theta = orc_acos(2.0 * orc_drand(&rng) - 1.0);
-            const double phi = ORC_TWO_PI * orc_drand(&rng);
+            const double xi_phi = orc_drand(&rng);
             double sth, cth, sph, cph;
             orc_sincos(theta, &sth, &cth);
-            orc_sincos(phi, &sph, &cph);
+            orc_sincos2pi(xi_phi, &sph, &cph);
             S->vx[n] = P->c * sth * cph;
             S->vy[n] = P->c * sth * sph;
             S->vz[n] = P->c * cth;

@@ -77,9 +77,11 @@ int orc_get_threads(void);
 /* generator + math, vectorised for tests */
 void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint64_t orc_seed_state(uint32_t seed, uint32_t domain, uint64_t id);
+uint64_t orc_stream_start(uint32_t seed, uint64_t id); /* first state of particle id's stream */
 uint64_t orc_draw_stream(uint64_t state, int n, double *out); /* returns the final state */
 void orc_math_log(const double *x, int n, double *out);
 void orc_math_sincos(const double *x, int n, double *sn, double *cs);
+void orc_math_sincos2pi(const double *u, int n, double *sn, double *cs); /* of 2 pi u */
 void orc_math_acos(const double *x, int n, double *out);
 
 /* step functions driven by a tape of uniforms; `st` is an orc_step (orc_steps.h) laid out as

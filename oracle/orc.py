@@ -95,6 +95,8 @@ def lib():
                                       C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
         L.orc_seed_state.restype = C.c_uint64
         L.orc_seed_state.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+        L.orc_stream_start.restype = C.c_uint64
+        L.orc_stream_start.argtypes = [C.c_uint32, C.c_uint64]
         L.orc_draw_stream.restype = C.c_uint64
         L.orc_draw_stream.argtypes = [C.c_uint64, C.c_int, _dp]
         L.orc_call_scatter.argtypes = [C.c_double, _dp, C.c_int, _dp]
@@ -140,6 +142,11 @@ def seed_state(seed: int, domain: int, sid: int) -> int:
     return int(lib().orc_seed_state(seed, domain, sid))
 
 
+def stream_start(seed: int, pid: int) -> int:
+    """First state of the random stream of the particle with creation index ``pid``."""
+    return int(lib().orc_stream_start(seed, pid))
+
+
 def draw_stream(state: int, n: int):
     """n uniforms from a stream that starts in `state`; returns (uniforms, final state)."""
     out = np.empty(n)
@@ -158,6 +165,14 @@ def math_sincos(x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     s, c = np.empty_like(x), np.empty_like(x)
     lib().orc_math_sincos(_d(x), x.size, _d(s), _d(c))
+    return s, c
+
+
+def math_sincos2pi(u):
+    """sin, cos of 2 pi u (the azimuth form the step functions use)."""
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    s, c = np.empty_like(u), np.empty_like(u)
+    lib().orc_math_sincos2pi(_d(u), u.size, _d(s), _d(c))
     return s, c
 
 

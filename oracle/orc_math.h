@@ -75,6 +75,20 @@ static inline void orc_pm_sincos(double x, double *sn, double *cs) {
   *cs = ci + fma(ci, cm1, -(si * sr));
 }
 
+/* ---- portable sin / cos of 2 pi u, u a uniform in (0,1): the grid point (256 per turn) is
+ * found on u itself (i = (int)(256 u + 0.5), u - i/256 exact), the remainder is multiplied by
+ * 2 pi once; angle addition with degree-5 / degree-6 polynomials ------------------------------ */
+static inline void orc_pm_sincos2pi(double u, double *sn, double *cs) {
+  const int i = (int)fma(u, 256.0, 0.5);
+  const double r = fma((double)i, -0.00390625, u) * 6.283185307179586476925286766559;
+  const double si = jb_sc2_tab[i][0], ci = jb_sc2_tab[i][1];
+  const double r2 = r * r; /* |r| <= pi / 256: r^7 / 5040 < 1e-17, r^8 / 40320 < 2e-20 */
+  const double sr = fma(r * r2, fma(r2, 1.0 / 120.0, -1.0 / 6.0), r);
+  const double cm1 = r2 * fma(r2, fma(r2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
+  *sn = fma(si, cm1, fma(ci, sr, si));
+  *cs = fma(ci, cm1, fma(-si, sr, ci));
+}
+
 /* ---- portable acos: |x| <= 1 ------------------------------------------------------------ */
 static inline double orc_pm_acos_R(double z) {
   static const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
@@ -119,6 +133,17 @@ static inline void orc_sincos(double x, double *sn, double *cs) {
     *cs = cos(x);
   } else {
     orc_pm_sincos(x, sn, cs);
+  }
+}
+/* sin, cos of phi = 2 pi u (reference: `phi = 2.0 * M_PI * drand(); cos(phi), sin(phi)`,
+ * scattering.hpp:24-27, transport_utils.hpp:33-38,271-275, sourcing.cpp:181-185) */
+static inline void orc_sincos2pi(double u, double *sn, double *cs) {
+  if (orc_math_mode == ORC_MATH_LIBM) {
+    const double phi = (2.0 * M_PI) * u;
+    *sn = sin(phi);
+    *cs = cos(phi);
+  } else {
+    orc_pm_sincos2pi(u, sn, cs);
   }
 }
 static inline double orc_acos(double x) {

@@ -11,10 +11,10 @@
  * with the particle -- the arrangement of the production Monte Carlo transport codes (MCNP,
  * OpenMC: one linear congruential stream per history):
  *
- *     seeding   state = words (0,1) of Philox4x32-10( counter = {0, 0, id_lo, id_hi},
- *                                                     key = {seed, domain} )
- *               Philox4x32-10 is the published Random123 algorithm (Salmon et al., SC'11), laid
- *               out like rocRAND's rocrand_init(seed, subsequence = id, offset = 0).
+ *     seeding   the particle streams are disjoint segments of the generator's single cycle,
+ *               a fixed stride apart (orc_rng_stream_start below); base points come from
+ *               Philox4x32-10, the published Random123 algorithm (Salmon et al., SC'11), laid
+ *               out like rocRAND's rocrand_init(seed, subsequence, offset = 0).
  *     draw      s = s * 6364136223846793005 + 1442695040888963407  (mod 2^64; Knuth's MMIX LCG)
  *               xi = ((s >> 12) + 0.5) * 2^-52      in the OPEN interval (0,1)
  *
@@ -70,6 +70,27 @@ static inline uint64_t orc_rng_seed_state(uint32_t seed, uint32_t domain, uint64
   return ((uint64_t)o[1] << 32) | o[0];
 }
 
+/* Start of the stream of the particle with creation index `id`: disjoint segments of the
+ * generator's single cycle, a fixed odd stride S = 2^34 - 3 apart within each block of 2^30
+ * consecutive ids (MCNP / OpenMC arrangement; Brown 1994, "Random number generation with
+ * arbitrary strides"); the block's base point is Philox-derived.  T_S^n by squaring of the
+ * affine map x -> A x + C. */
+#define ORC_LCG_MUL 6364136223846793005ull
+#define ORC_LCG_INC 1442695040888963407ull
+#define ORC_STRIDE ((1ull << 34) - 3ull)
+#define ORC_STRIDE_MUL 0xb0c24fccf6a8435dull /* a^S mod 2^64 */
+#define ORC_STRIDE_INC 0x574abb626a358eebull /* c (a^S - 1) / (a - 1) mod 2^64 */
+static inline uint64_t orc_rng_stream_start(uint32_t seed, uint64_t id) {
+  uint64_t s = orc_rng_seed_state(seed, ORC_RNG_DOMAIN_PARTICLE, id >> 30);
+  uint64_t A = ORC_STRIDE_MUL, C = ORC_STRIDE_INC;
+  for (uint32_t n = (uint32_t)id & 0x3fffffffu; n != 0u; n >>= 1) {
+    if (n & 1u) s = A * s + C;
+    C = (A + 1ull) * C;
+    A = A * A;
+  }
+  return s;
+}
+
 static inline orc_rng orc_rng_from_state(uint64_t state) {
   orc_rng r = {state, 0u, NULL, 0};
   return r;
@@ -85,7 +106,7 @@ static inline double orc_drand(orc_rng *r) {
     r->ctr++;
     return v;
   }
-  const uint64_t s = r->s * 6364136223846793005ull + 1442695040888963407ull;
+  const uint64_t s = r->s * ORC_LCG_MUL + ORC_LCG_INC;
   r->s = s;
   r->ctr++;
   return orc_u52_to_double(s >> 12);

@@ -32,9 +32,9 @@ static inline void orc_sample_face_iso_dir(double vv, orc_rng *rng, double *v1, 
                                            double *v3) {
   const double mu = sqrt(orc_drand(rng));
   const double nu = sqrt(1.0 - mu * mu);
-  const double phi = ORC_TWO_PI * orc_drand(rng);
+  const double xi2 = orc_drand(rng);
   double sn, cs;
-  orc_sincos(phi, &sn, &cs);
+  orc_sincos2pi(xi2, &sn, &cs);
   *v1 = vv * mu;
   *v2 = vv * nu * cs;
   *v3 = vv * nu * sn;
@@ -43,10 +43,10 @@ static inline void orc_sample_face_iso_dir(double vv, orc_rng *rng, double *v1, 
 /* reference src/jaybenne/scattering.hpp:21-29: isotropic scatter. 2 draws. */
 static inline void orc_scatter(orc_rng *rng, double vv, double *vx, double *vy, double *vz) {
   const double mu = 2.0 * orc_drand(rng) - 1.0;
-  const double phi = ORC_TWO_PI * orc_drand(rng);
+  const double xi2 = orc_drand(rng);
   const double st = sqrt(1.0 - mu * mu);
   double sn, cs;
-  orc_sincos(phi, &sn, &cs);
+  orc_sincos2pi(xi2, &sn, &cs);
   *vx = vv * st * cs;
   *vy = vv * st * sn;
   *vz = vv * mu;
@@ -221,9 +221,9 @@ static inline void orc_ptcl_ddmc_step(orc_step *s, orc_rng *rng) {
     s->y = s->yl + orc_drand(rng) * dy;
     const double mu = 1.0 - 2.0 * orc_drand(rng);
     const double nu = sqrt(1.0 - mu * mu);
-    const double phi = ORC_TWO_PI * orc_drand(rng);
+    const double xi2 = orc_drand(rng);
     double sn, cs;
-    orc_sincos(phi, &sn, &cs);
+    orc_sincos2pi(xi2, &sn, &cs);
     s->vz = s->vv * mu;
     s->vx = s->vv * nu * cs;
     s->vy = s->vv * nu * sn;

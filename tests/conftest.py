@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # a GPU test that stops making progress (a kernel that never drains) must end the run, not
+    # sit on the box until the pool's own watchdog fires
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(300, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def gpu_device():
     import torch

@@ -181,3 +181,77 @@ def test_two_rank_field_halo_exchange():
         assert p.exitcode == 0
     res = dict(out.get(timeout=5) for _ in range(2))
     assert res == {0: "ok", 1: "ok"}
+
+
+# ------------------------------------------------------------------------------------------------
+def _eight_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import load_deck
+        from jaybenne_amd.comm import RECORD_WORDS, Comm
+        from jaybenne_amd.halo import FieldExchange
+        from jaybenne_amd.mesh import Mesh
+        comm = Comm()
+        # hand-off: rank s sends (s * world + d) % 5 records to every other rank d; each record's
+        # first word names (source, destination, ordinal)
+        counts = np.array([(rank * world + d) % 5 if d != rank else 0 for d in range(world)], dtype=np.int64)
+        rows = []
+        for d in range(world):
+            for q in range(counts[d]):
+                rows.append([rank * 10000 + d * 100 + q] + [0] * (RECORD_WORDS - 1))
+        send = torch.tensor(rows, dtype=torch.int64).reshape(-1, RECORD_WORDS) if rows else None
+        mat = comm.gather_count_matrix(counts)
+        want_mat = np.array([[(s_ * world + d) % 5 if d != s_ else 0 for d in range(world)]
+                             for s_ in range(world)])
+        assert np.array_equal(mat, want_mat)
+        recv = comm.exchange_records(send, counts, torch.device("cpu"), recv_counts=mat[:, rank].copy())
+        want = [s_ * 10000 + rank * 100 + q for s_ in range(world) for q in range(want_mat[s_, rank])]
+        got = [] if recv is None else recv[:, 0].tolist()
+        assert got == want                               # grouped by source rank, in send order
+        # termination: nothing moves -> the matrix is all zero on every rank
+        assert comm.gather_count_matrix(np.zeros(world, dtype=np.int64)).sum() == 0
+        # field halo refresh on the two-level SMR deck (20 blocks over 8 ranks: 2 or 3 each)
+        mesh = Mesh.from_deck(load_deck("stepdiff_smr"))
+        mesh.partition(world)
+        md = _StubMeshData(mesh, rank, world, comm)
+        ex = FieldExchange(md)
+        rng = np.random.default_rng(11)
+        glob = rng.random(mesh.field_shape)
+        want_f = glob.copy()
+        mesh.fill_ghosts(want_f)
+        mine = np.full((len(md.resident_gids),) + mesh.field_shape[1:], np.nan)
+        sl = mesh.interior()
+        nown = len(md.gids)
+        mine[:nown][sl] = glob[md.gids][sl]
+        flat = mine.reshape(mine.shape[0], -1)
+        sendv = torch.from_numpy(flat[ex.serve_blk.numpy(), ex.serve_cell.numpy()].copy())
+        remote = torch.empty(ex.nremote, dtype=torch.float64)
+        comm.exchange_values(sendv, ex.send_counts, remote, ex.recv_counts)
+        ex.refresh_numpy(mine, remote.numpy())
+        assert np.array_equal(mine, want_f[md.resident_gids])
+        out.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        out.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_handoff_and_halo():
+    """The rank count of the north-star node (and of the reference's CI, ci.yml:129-140): 8 x 8
+    count matrix, every rank pair exchanging records, arrival order, the all-zero termination
+    matrix, and the ghost / halo refresh plan of the SMR deck split eight ways."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eight_worker, args=(r, 8, port, out)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = dict(out.get(timeout=5) for _ in range(8))
+    assert res == {r: "ok" for r in range(8)}

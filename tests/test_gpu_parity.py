@@ -76,6 +76,11 @@ def test_uniform_stream_bit_exact(ctx):
         want, want_fin = orc.draw_stream(st.value, out.size)
         assert np.array_equal(out, want) and fin.value == want_fin
         assert out.min() > 0.0 and out.max() < 1.0
+    # particle streams: disjoint strided segments (csrc/jb_rng.hpp), device vs oracle
+    for pid in (0, 1, 2, 12345, 2 ** 30 - 1, 2 ** 30, (3 << 30) | 777, 2 ** 40 + 99):
+        st = C.c_uint64(0)
+        _lib.check(ctx.lib.jb_debug_stream_start(ctx.ctx, 349857, pid, C.byref(st)))
+        assert st.value == orc.stream_start(349857, pid), pid
 
 
 def _dev_math(ctx, which, x):
@@ -100,6 +105,9 @@ def test_device_math_bit_exact(ctx):
     s, c = orc.math_sincos(phi)
     assert np.array_equal(_dev_math(ctx, 1, phi), s)
     assert np.array_equal(_dev_math(ctx, 2, phi), c)
+    s2, c2 = orc.math_sincos2pi(u)
+    assert np.array_equal(_dev_math(ctx, 9, u), s2)
+    assert np.array_equal(_dev_math(ctx, 10, u), c2)
     mu = 2.0 * u - 1.0
     assert np.array_equal(_dev_math(ctx, 3, mu), orc.math_acos(mu))
     # IEEE sqrt and divide on the device are correctly rounded (the host's are)

@@ -47,13 +47,16 @@ def test_three_level_hybrid_extension(gpu_device, tmp_path, capsys):
     assert "levels [0, 1, 2]" in out and rc == 0, out
 
 
-@pytest.mark.parametrize("deck,tol", [("inf", 0.03), ("inf_stiff", 0.08)])
+@pytest.mark.parametrize("deck,tol", [("inf", 0.03), ("inf_stiff", 0.04)])
 def test_infinite_medium_decks(gpu_device, deck, tol):
-    """inputs/inf.in and inputs/inf_stiff.in run as shipped (100 and 10 cycles; the swarm pool grows
-    as emission particles accumulate): the domain-mean radiation energy density stays at a T0^4."""
+    """inputs/inf.in and inputs/inf_stiff.in (100 and 10 cycles; the swarm pool grows as emission
+    particles accumulate): the domain-mean radiation energy density stays at a T0^4.  inf runs as
+    shipped; inf_stiff as shipped leaves ~35 census particles per cycle (5 % noise on the mean),
+    so it runs with 16 x its particle count (~1 %)."""
     from helpers import load_deck
     from jaybenne_amd import constants, mcblock
-    drv = mcblock.McblockDriver(load_deck(deck), device=gpu_device)
+    ov = {"jaybenne/num_particles": 160000} if deck == "inf_stiff" else None
+    drv = mcblock.McblockDriver(load_deck(deck, ov), device=gpu_device)
     ur = 4.0 * constants.STEFAN_BOLTZMANN / constants.SPEED_OF_LIGHT * drv.mcb.initial_temperature ** 4
     sl = drv.mesh.interior()
     cap0, ratio = drv.md.capacity, []

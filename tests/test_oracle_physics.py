@@ -95,14 +95,16 @@ def test_absorption_and_feedback_conserve_energy():
 
 
 @pytest.mark.parametrize("deck,cycles,capacity_factor,tol", [("inf", 25, 40.0, 0.03),
-                                                            ("inf_stiff", 10, 12.0, 0.08)])
+                                                            ("inf_stiff", 10, 12.0, 0.04)])
 def test_infinite_medium_equilibrium(deck, cycles, capacity_factor, tol):
     """The reference's equilibrium decks (inputs/inf.in: 3-D IMC with sigma_s = 1e5;
     inputs/inf_stiff.in: 1-D DDMC with sigma_a = 1e3): material held at T0 emits f j dV dt per
     cycle and absorbs at f sigma_a c, so the radiation energy density must stay at a T0^4.
-    Checked on the domain mean, averaged over the cycles (Monte Carlo noise: ~1 % and ~5 %)."""
+    Checked on the domain mean, averaged over the cycles.  inf_stiff as shipped leaves ~35
+    census particles per cycle (5 % noise on the 10-cycle mean, seed to seed 0.92 .. 1.12); it is
+    run with 16 x its particle count, which brings the noise to ~1 %."""
     from jaybenne_amd import constants
-    pin = load_deck(deck)
+    pin = load_deck(deck, {"jaybenne/num_particles": 160000} if deck == "inf_stiff" else None)
     O, mesh, pkg = make_oracle(pin, orc.MATH_LIBM, threads=8, capacity_factor=capacity_factor)
     ur = 4.0 * constants.STEFAN_BOLTZMANN / constants.SPEED_OF_LIGHT * pkg.initial_temperature ** 4
     sl = mesh.interior()

@@ -36,11 +36,53 @@ def test_stream_seeding_layout():
         assert orc.seed_state(seed, domain, sid) == (w[1] << 32) | w[0]
 
 
+A, C_, MASK = 6364136223846793005, 1442695040888963407, (1 << 64) - 1
+STRIDE = (1 << 34) - 3
+
+
+def _jump(s, n):
+    """s after n steps of the recurrence (big-integer restatement of Brown's algorithm)."""
+    a, c, h, f = 1, 0, A, C_
+    while n:
+        if n & 1:
+            a, c = (a * h) & MASK, (c * h + f) & MASK
+        f, h = (f * (h + 1)) & MASK, (h * h) & MASK
+        n >>= 1
+    return (a * s + c) & MASK
+
+
+def test_jump_matches_stepping():
+    s0 = 0x0123456789abcdef
+    s = s0
+    for n in range(1, 300):
+        s = (s * A + C_) & MASK
+        assert _jump(s0, n) == s
+    assert _jump(_jump(s0, 12345), STRIDE) == _jump(s0, 12345 + STRIDE)
+
+
+def test_particle_streams_are_disjoint_strided_segments():
+    """start(id) = base(id >> 30) advanced by (id mod 2^30) * S steps, S = 2^34 - 3: the streams
+    of one block of 2^30 ids are segments of the one cycle that cannot meet before S draws."""
+    seed = 349857
+    for g in (0, 1, 5):
+        base = orc.seed_state(seed, 0, g)
+        assert orc.stream_start(seed, g << 30) == base
+        for lo in (1, 2, 3, 1000, 99999, 2 ** 29 + 12345, 2 ** 30 - 1):
+            assert orc.stream_start(seed, (g << 30) | lo) == _jump(base, lo * STRIDE), (g, lo)
+    # neighbours are exactly S steps apart: stream id + 1 starts where stream id would be after
+    # S draws
+    s5 = orc.stream_start(seed, 5)
+    assert _jump(s5, STRIDE) == orc.stream_start(seed, 6)
+    # the last stream of a block ends before the cycle closes: no wrap onto the first
+    assert (2 ** 30 - 1) * STRIDE + STRIDE <= 1 << 64
+    assert STRIDE % 2 == 1          # an odd skip changes every bit of the state
+
+
 def test_streams_are_distinct_and_uniform():
-    firsts = np.array([orc.draw_stream(orc.seed_state(349857, 0, i), 4)[0] for i in range(4000)])
+    firsts = np.array([orc.draw_stream(orc.stream_start(349857, i), 4)[0] for i in range(4000)])
     assert len(np.unique(firsts[:, 0])) == 4000
     # crude uniformity of the first draw over neighbouring ids, and no lag-1 correlation
     assert abs(firsts[:, 0].mean() - 0.5) < 0.02
     assert abs(np.corrcoef(firsts[:-1, 0], firsts[1:, 0])[0, 1]) < 0.05
-    long_run, _ = orc.draw_stream(orc.seed_state(349857, 0, 42), 200000)
+    long_run, _ = orc.draw_stream(orc.stream_start(349857, 42), 200000)
     assert abs(long_run.mean() - 0.5) < 0.003 and abs(long_run.var() - 1 / 12) < 0.002
