@@ -18,6 +18,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "jb_device.hpp"
 
 namespace jb {
@@ -410,12 +412,16 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   double t = 0, x = 0, y = 0, z = 0, vx = 0, vy = 0, vz = 0, ee = 0;
   Blk B;
   gcptr f0 = nullptr, f1 = nullptr, f2 = nullptr;  // this block's cell arrays
+  double fd[3] = {0.0, 0.0, 0.0};                  // EXACT: the block's nudge widths
   // deferred direction of the last DDMC leak (packed-record DDMC kernels; see ddmc_step_event)
   int pend = -1;
   double pz1 = 0.0, pz2 = 0.0;
 
   auto bind_block = [&](int blk) {
     load_block(M, blk, B);
+    if constexpr (EXACT) {  // nudge widths eps_imc (upper - lower) = eps_imc dx, exactly
+      fd[0] = kEpsImc * B.dx[0]; fd[1] = kEpsImc * B.dx[1]; fd[2] = kEpsImc * B.dx[2];
+    }
     if constexpr (kFastGray) {  // (library-owned, contiguous: no pointer-table load)
       f0 = (gcptr)(M.lam_base + (long long)(2 * blk) * M.ntot);
       f1 = (gcptr)(M.lam_base + (long long)(2 * blk + 1) * M.ntot);
@@ -460,6 +466,37 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         ls = (t < t_end) ? LS_RUN : LS_DONE;
       }
     }
+  };
+
+  // One face of the lane's block crossed (kFastGray kernels): destination and the one geometry
+  // value that changes come from the per-(block, face) table; returns false when the general
+  // relocation has to run.
+  auto cross_face = [&](auto axis_c, bool up, double &pos, double &vel, int &idx, int first_i,
+                        int last_i) -> bool {
+    constexpr int AXIS = decltype(axis_c)::value;
+    const int slot = 6 * b + 2 * AXIS + (int)up;
+    const int ent = M.nbr_ent[slot];
+    const double nx0 = ((gcptr)M.nbr_x0)[slot];
+    if (ent < 0) return false;
+    const int kind = ent >> 28;
+    bool at_first = up;  // entered through the destination's lower face
+    if (kind != 0) {
+      const double lo = M.gmin[AXIS], hi = M.gmax[AXIS];
+      if (kind == 1) {  // periodic
+        pos = up ? lo + (pos - hi) : hi - (lo - pos);
+      } else {  // reflecting (boundaries.hpp:46-82): back into the same block
+        pos = up ? hi - (pos - hi) : lo + (lo - pos);
+        vel = -vel;
+        at_first = !up;
+      }
+    }
+    b = ent & 0x0fffffff;
+    B.x0[AXIS] = nx0;
+    idx = at_first ? first_i : last_i;
+    f0 = (gcptr)(M.lam_base + (long long)(2 * b) * M.ntot);
+    f1 = (gcptr)(M.lam_base + (long long)(2 * b + 1) * M.ntot);
+    ls = (t < t_end) ? LS_RUN : LS_DONE;
+    return true;
   };
 
 #ifdef JB_TIMING  // scratch diagnostics: CNT_PASSES / CNT_SERVICE carry cycles / 1024 instead
@@ -644,7 +681,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
             c.xl = m_fma((double)ip, B.dx[0], B.x0[0]); c.xu = c.xl + B.dx[0];
             c.yl = m_fma((double)jp, B.dx[1], B.x0[1]); c.yu = c.yl + B.dx[1];
             c.zl = m_fma((double)kp, B.dx[2], B.x0[2]); c.zu = c.zl + B.dx[2];
-            c.fdx = kEpsImc * B.dx[0]; c.fdy = kEpsImc * B.dx[1]; c.fdz = kEpsImc * B.dx[2];
+            c.fdx = fd[0]; c.fdy = fd[1]; c.fdz = fd[2];
           } else {  // transport.cpp:114-119, transport_utils.hpp:151-153
             c.xl = xc(B, 0, ip) - 0.5 * B.dx[0]; c.xu = xc(B, 0, ip) + 0.5 * B.dx[0];
             c.yl = xc(B, 1, jp) - 0.5 * B.dx[1]; c.yu = xc(B, 1, jp) + 0.5 * B.dx[1];
@@ -684,41 +721,16 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         // or last cell along the axis, the others unchanged).  Everything else takes relocate().
         if (__ballot(ls == LS_RELOC) != 0ull) {
           if (ls == LS_RELOC) {
-            const int ox = (ip < M.is) ? 0 : ((ip > M.ie) ? 1 : -1);
-            const int oy = (jp < M.js) ? 2 : ((jp > M.je) ? 3 : -1);
-            const int oz = (kp < M.ks) ? 4 : ((kp > M.ke) ? 5 : -1);
-            const int nout = (int)(ox >= 0) + (int)(oy >= 0) + (int)(oz >= 0);
-            const int face = ox >= 0 ? ox : (oy >= 0 ? oy : oz);
-            int ent = -1;
-            double nx0 = 0.0;
-            if (nout == 1) {
-              ent = M.nbr_ent[6 * b + face];
-              nx0 = ((gcptr)M.nbr_x0)[6 * b + face];
-            }
-            if (ent >= 0) {
-              const int kind = ent >> 28, axis = face >> 1;
-              const bool up = (face & 1) != 0;
-              b = ent & 0x0fffffff;
-              double pos = axis == 0 ? x : (axis == 1 ? y : z);
-              const double lo = axis == 0 ? M.gmin[0] : (axis == 1 ? M.gmin[1] : M.gmin[2]);
-              const double hi = axis == 0 ? M.gmax[0] : (axis == 1 ? M.gmax[1] : M.gmax[2]);
-              if (kind == 1) pos = up ? lo + (pos - hi) : hi - (lo - pos);       // periodic
-              else if (kind == 2) pos = up ? hi - (pos - hi) : lo + (lo - pos);  // boundaries.hpp:46-82
-              const double vsgn = kind == 2 ? -1.0 : 1.0;
-              const bool at_first = (kind == 2) != up;  // entered through the lower face
-              if (axis == 0) {
-                x = pos; vx *= vsgn; B.x0[0] = nx0; ip = at_first ? M.is : M.ie;
-              } else if (axis == 1) {
-                y = pos; vy *= vsgn; B.x0[1] = nx0; jp = at_first ? M.js : M.je;
-              } else {
-                z = pos; vz *= vsgn; B.x0[2] = nx0; kp = at_first ? M.ks : M.ke;
-              }
-              f0 = (gcptr)(M.lam_base + (long long)(2 * b) * M.ntot);
-              f1 = (gcptr)(M.lam_base + (long long)(2 * b + 1) * M.ntot);
-              ls = (t < t_end) ? LS_RUN : LS_DONE;
-            } else {
-              relocate();
-            }
+            const bool xo = ip < M.is || ip > M.ie;
+            const bool yo = multi_d && (jp < M.js || jp > M.je);
+            const bool zo = three_d && (kp < M.ks || kp > M.ke);
+            // (one lane, rarely two, gets here in a pass: each axis has its own copy of the few
+            // instructions instead of selecting position / index / geometry by axis number)
+            bool done = false;
+            if (xo && !yo && !zo) done = cross_face(std::integral_constant<int, 0>{}, ip > M.ie, x, vx, ip, M.is, M.ie);
+            else if (yo && !xo && !zo) done = cross_face(std::integral_constant<int, 1>{}, jp > M.je, y, vy, jp, M.js, M.je);
+            else if (zo && !xo && !yo) done = cross_face(std::integral_constant<int, 2>{}, kp > M.ke, z, vz, kp, M.ks, M.ke);
+            if (!done) relocate();
           }
         }
       } else if (ls == LS_RUN) {

@@ -52,14 +52,14 @@ __device__ __forceinline__ double m_min(double a, double b) {
   return d;
 }
 
-__shared__ double lds_log_tab[JB_LOG_N][3];
+__shared__ double lds_log_tab[JB_LOG_N][4];  // 32-byte rows: one address serves both reads
 __shared__ double lds_sc_tab[JB_SC_N + 1][2];
 __shared__ double lds_sc2_tab[JB_SC2_N + 1][2];
 
 // Copies the three tables into this workgroup's LDS (8.2 KB); ends with a barrier.
 __device__ __forceinline__ void load_math_tables() {
   for (int q = threadIdx.x; q < JB_LOG_N * 3; q += blockDim.x)
-    (&lds_log_tab[0][0])[q] = (&jb_log_tab[0][0])[q];
+    lds_log_tab[q / 3][q % 3] = (&jb_log_tab[0][0])[q];
   for (int q = threadIdx.x; q < (JB_SC_N + 1) * 2; q += blockDim.x)
     (&lds_sc_tab[0][0])[q] = (&jb_sc_tab[0][0])[q];
   for (int q = threadIdx.x; q < (JB_SC2_N + 1) * 2; q += blockDim.x)
