@@ -65,6 +65,7 @@ struct jb_mesh {
   // cell-face arithmetic is then exact; k_transport<..., EXACT>)
   bool exact_geom = false;
   const char *last_variant = "";  // the k_transport instantiation launched last
+  const char *last_pair = "";     // ... and the k_ddmc_all launched beside it (gray DDMC), or ""
 };
 
 __global__ void k_rcp_refined(double b, double *out) { *out = m_rcp_refined(b); }
@@ -376,6 +377,13 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
     if ((st = upload(m, ent.data(), ent.size(), &D.nbr_ent)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
     if ((st = upload(m, x0.data(), x0.size(), &D.nbr_x0)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
   }
+  {
+    const int one = 1;   // until UpdateDerivedTransportFields has looked at the cells
+    const int *flag = nullptr;
+    if ((st = upload(m, &one, 1, &flag)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
+    D.not_all_ddmc = (int *)flag;
+  }
+  D.ddmc_base = nullptr;
   // gray (frequency-independent) opacities: library-owned per-cell mean-free-path arrays
   D.lam_base = nullptr;
   D.lam_abs = nullptr;
@@ -413,6 +421,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
       for (int b = 0; b < v->nblocks; ++b) pp[b] = pack + (size_t)b * per * 8;
       if ((st = upload(m, (const double *const *)pp.data(), (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
       D.ddmc_cell = (double *const *)tmp;
+      D.ddmc_base = pack;
     }
   }
   *out = m;
@@ -458,6 +467,9 @@ extern "C" jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh
     if (M.ndim > 1) hipLaunchKernelGGL(k_face_prob<1>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
     if (M.ndim > 2) hipLaunchKernelGGL(k_face_prob<2>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
     if (M.ddmc_cell) {
+      // JB_NO_DDMC_ALL=1 keeps the general kernel also on all-DDMC meshes (tests, A/B)
+      const char *off = getenv("JB_NO_DDMC_ALL");
+      JB_HIP(hipMemsetAsync(M.not_all_ddmc, (off && off[0] == '1') ? 1 : 0, sizeof(int), ctx->stream));
       const int gp = grid_for(ctx, cells);
       if (M.ndim == 1) hipLaunchKernelGGL(k_ddmc_pack<1>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
       else if (M.ndim == 2) hipLaunchKernelGGL(k_ddmc_pack<2>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
@@ -560,8 +572,9 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
                                                      kBlock, 0) != hipSuccess || occ < 1)          \
       occ = 3;                                                                                     \
     const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
+    const int *pair_flag = (DDMC && G != 0) ? M.not_all_ddmc : nullptr;                            \
     hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G, X>), dim3(g), dim3(kBlock), 0, ctx->stream,  \
-                       M, ctx->dp, S, t_start, dt, first, last, ctx->counters_d);                  \
+                       M, ctx->dp, S, t_start, dt, first, last, ctx->counters_d, pair_flag);       \
     mesh->last_variant = NDIM == 1 ? "k_transport<1, " #T ", " #G ", " #X ">"                      \
                          : NDIM == 2 ? "k_transport<2, " #T ", " #G ", " #X ">"                    \
                                      : "k_transport<3, " #T ", " #G ", " #X ">";                   \
@@ -576,6 +589,26 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
       JB_LAUNCH_X(T, G, false);                                                                    \
     }                                                                                              \
   } while (0)
+  mesh->last_pair = "";
+  if constexpr (DDMC) {
+    if (gray && M.ddmc_cell) {  // every cell a DDMC cell: the lean kernel (else it returns at once)
+      mesh->last_pair = NDIM == 1 ? (tally ? "k_ddmc_all<1, true>" : "k_ddmc_all<1, false>")
+                        : NDIM == 2 ? (tally ? "k_ddmc_all<2, true>" : "k_ddmc_all<2, false>")
+                                    : (tally ? "k_ddmc_all<3, true>" : "k_ddmc_all<3, false>");
+      int occ = 0;
+      if (tally) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, true>, kBlock, 0) != hipSuccess || occ < 1) occ = 4;
+        const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
+        hipLaunchKernelGGL((k_ddmc_all<NDIM, true>), dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, S,
+                           t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
+      } else {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, false>, kBlock, 0) != hipSuccess || occ < 1) occ = 4;
+        const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
+        hipLaunchKernelGGL((k_ddmc_all<NDIM, false>), dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, S,
+                           t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
+      }
+    }
+  }
   // gray opacity with kappa = 0 (opacity_model = none): sigma_a = rho * 0 in every cell
   const bool noabs = gray && ctx->dp.kappa_a == 0.0;
   if (noabs) {
@@ -631,7 +664,16 @@ extern "C" jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh,
 }
 
 extern "C" const char *jb_last_transport_variant(const jb_mesh *mesh) {
-  return mesh ? mesh->last_variant : "";
+  if (!mesh) return "";
+  if (mesh->last_pair[0]) {  // a gray DDMC launch is a pair: the device-side flag says which one ran
+    int flag = 1;
+    if (hipSetDevice(mesh->ctx->device) != hipSuccess ||
+        hipStreamSynchronize(mesh->ctx->stream) != hipSuccess ||
+        hipMemcpy(&flag, mesh->dm.not_all_ddmc, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+      return "";
+    return flag == 0 ? mesh->last_pair : mesh->last_variant;
+  }
+  return mesh->last_variant;
 }
 extern "C" int jb_mesh_exact_geometry(const jb_mesh *mesh) { return mesh && mesh->exact_geom; }
 

@@ -42,6 +42,11 @@ struct DevMesh {
   // leak opacities P/dx of the faces x-, x+, y-, y+, z-, z+} -- everything a DDMC step gathers,
   // in one 64-byte record
   double *const *ddmc_cell;
+  const double *ddmc_base;  // ddmc_cell[b] = ddmc_base + 8 b ntot
+  // set to 1 by UpdateDerivedTransportFields when some interior cell of a resident block takes
+  // IMC steps (dx_push (sigma_a + sigma_s) <= tau_ddmc, transport_ddmc.cpp:135); 0 = every step
+  // of every particle is a DDMC step (k_ddmc_all)
+  int *not_all_ddmc;
 };
 
 struct DevParams {

@@ -1,0 +1,386 @@
+// jb_kernel_ddmc.hpp -- TransportPhotons_DDMC for meshes whose every cell takes the DDMC branch
+// (transport_ddmc.cpp:135: dx_push (sigma_s + sigma_a) > tau_ddmc everywhere; gray opacities):
+// the reference's stepdiff_ddmc / stepdiff_smr_ddmc / inf_stiff decks and BASELINE configs[2].
+//
+// Why a kernel of its own.  A DDMC history is short (~34 steps in 3-D) and each step waits for
+// one random 64-byte cell record: the loop is bound by memory latency, so what counts is how many
+// waves a SIMD can keep in flight, i.e. how few registers a lane needs inside the loop.  In an
+// all-DDMC mesh almost nothing of a particle is live between two steps:
+//   * after a leak the position is "eps_ddmc dx beyond the face it left through, cell centre
+//     across" (transport_utils.hpp:209-263) -- a function of the new cell and the leak channel;
+//     the albedo test of the next step (transport_utils.hpp:288-389) compares 1e8 eps against
+//     2.5e6 eps and cannot fire, and then moves the particle to the cell centre (:392-396);
+//   * the direction drawn at the leak is read by nobody until the particle leaves DDMC cells, is
+//     absorbed or crosses a block (deferred: channel + its two uniforms, as in k_transport).
+// So a lane in the event loop carries cell, time, random-stream state and the pending leak
+// ("virtual" state: 17 registers); position and direction exist only in the service phase, which
+// loads a particle, takes its first step with the general step functions (real position: the
+// albedo test can fire there), and rebuilds position / direction from the virtual state where a
+// consumer appears (block crossing, census resampling, absorption, write-back).  Same draws, same
+// arithmetic, same bits as k_transport<NDIM, true, TALLY, 1 or 2> -- tests/test_gpu_parity.py
+// holds both to the oracle.
+#pragma once
+
+#include "jb_device.hpp"
+
+namespace jb {
+
+#ifndef JB_DDMC_ALL_WAVES_PER_SIMD
+#define JB_DDMC_ALL_WAVES_PER_SIMD 4
+#endif
+#ifndef JB_DDMC_ALL_BUDGET   // idle lane-passes that buy a service phase
+#define JB_DDMC_ALL_BUDGET 128
+#endif
+#ifndef JB_DDMC_ALL_CHUNK
+#define JB_DDMC_ALL_CHUNK 128
+#endif
+
+enum { DS_IDLE = 0, DS_VIRT = 1, DS_REAL = 2, DS_DONE = 3, DS_RELOC = 4 };
+
+template <int NDIM, bool TALLY>
+__global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
+    k_ddmc_all(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
+               long long last, unsigned long long *counters, const int *not_all_ddmc) {
+  if (*not_all_ddmc != 0) return;  // (uniform) some cell takes IMC steps: k_transport runs instead
+  __shared__ double lds_tally[TALLY ? kLdsTally : 1];
+  const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
+  if constexpr (TALLY) {
+    if (tally_in_lds)
+      for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) lds_tally[q] = 0.0;
+  }
+  load_math_tables();  // (ends with a barrier)
+  constexpr bool multi_d = NDIM >= 2;
+  constexpr int kBudget = JB_DDMC_ALL_BUDGET;
+  constexpr long long kChunk = JB_DDMC_ALL_CHUNK;
+  const double vv = P.c;
+  const double t_end = t_start + dt;
+  const int lane = threadIdx.x & 63;
+  unsigned long long *queue = counters + CNT_QUEUE;
+  const long long per_q = (last - first + kQueues - 1) / kQueues;
+  int cur = blockIdx.x % kQueues, tried = 0;
+  bool more = true;
+  long long chunk_pos = 0, chunk_end = 0;
+
+  unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0;
+  unsigned long long c_ev = 0;   // wave-level: running lanes summed over the event-loop passes
+  unsigned int c_ev_real = 0;    // per lane: steps taken in the service phase
+  unsigned int c_pass = 0, c_service = 0;
+
+  // ---- lane state that lives across the event loop ("virtual" particle)
+  int ls = DS_IDLE;
+  long long n = 0;
+  LcgRng rng(0);
+  int b = 0, ip = 0, jp = 0, kp = 0;
+  double t = 0.0;
+  int pend = -1;  // channel of the last leak (0..5) while its direction is deferred, else -1
+  double pz1 = 0.0, pz2 = 0.0;
+  bool resample = false;  // reached census in a DDMC step: position / direction to be resampled
+  // ---- state that exists only between two points of one service phase
+  int status = ST_ACTIVE;
+  double x = 0.0, y = 0.0, z = 0.0, vx = 0.0, vy = 0.0, vz = 0.0;
+  bool real_pos = false;  // x, y, z, v hold the particle's position / direction (DS_RELOC lanes)
+
+  auto faces_of = [&](Step &s, const Blk &Bq, int i, int j, int k) {  // transport.cpp:114-119
+    s.xl = xc(Bq, 0, i) - 0.5 * Bq.dx[0]; s.xu = xc(Bq, 0, i) + 0.5 * Bq.dx[0];
+    s.yl = xc(Bq, 1, j) - 0.5 * Bq.dx[1]; s.yu = xc(Bq, 1, j) + 0.5 * Bq.dx[1];
+    s.zl = xc(Bq, 2, k) - 0.5 * Bq.dx[2]; s.zu = xc(Bq, 2, k) + 0.5 * Bq.dx[2];
+  };
+  auto load_record = [&](Step &s, int blk, int q) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    typedef const v4d __attribute__((address_space(1))) *grec;
+    // (library-owned, contiguous: no pointer-table load in front of the gather)
+    const grec rec = (grec)((gcptr)M.ddmc_base + 8 * ((long long)blk * M.ntot + q));
+    const v4d r0 = rec[0];
+    const v4d r1 = rec[1];
+    s.ffaa = r0.x; s.sig = r0.y;
+    s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
+  };
+
+#ifdef JB_TIMING
+  unsigned long long cyc_ev = 0, cyc_sv = 0, cyc_mark = __builtin_readcyclecounter();
+#endif
+  for (;;) {
+    // ================================ SERVICE ================================
+    ++c_service;
+#ifdef JB_TIMING
+    { const unsigned long long now = __builtin_readcyclecounter(); cyc_ev += now - cyc_mark; cyc_mark = now; }
+#endif
+    // -- 1. block crossings: the comm phase of the reference for one particle in flight
+    if (ls == DS_RELOC) {
+      Blk Bo;
+      load_block(M, b, Bo);
+      Step s;
+      s.vv = vv; s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
+      if (!real_pos) {
+        // leak out of the block from the virtual state: the position the step function gave the
+        // particle (transport_utils.hpp:209-263), from the cell it left and the channel
+        const int axis = pend >> 1;
+        const bool up = (pend & 1) != 0;
+        const int step = up ? 1 : -1;
+        faces_of(s, Bo, ip - (axis == 0 ? step : 0), jp - (axis == 1 ? step : 0),
+                 kp - (axis == 2 ? step : 0));
+        const double dx = s.xu - s.xl, dy = s.yu - s.yl, dz = s.zu - s.zl;
+        const double eps = kEpsDdmc;
+        x = (axis == 0) ? (up ? s.xu + eps * dx : s.xl - eps * dx) : s.xl + 0.5 * dx;
+        y = (axis == 1) ? (up ? s.yu + eps * dy : s.yl - eps * dy) : s.yl + 0.5 * dy;
+        z = (axis == 2) ? (up ? s.zu + eps * dz : s.zl - eps * dz) : s.zl + 0.5 * dz;
+        vx = 0.0; vy = 0.0; vz = 0.0;  // (overwritten below or flagged as a DDMC leak)
+      }
+      // transport_ddmc.cpp:203-211: zero velocity flags a DDMC leak for SampleDDMCBlockFace
+      // (multi-D); in 1-D the direction travels with the particle
+      if (pend >= 0) {
+        if constexpr (multi_d) {
+          vx = 0.0; vy = 0.0; vz = 0.0;
+        } else {
+          s.vx = vx; s.vy = vy; s.vz = vz;
+          materialise_dir(s);
+          vx = s.vx; vy = s.vy; vz = s.vz;
+        }
+        pend = -1;
+      }
+      if (!apply_swarm_bcs<NDIM>(M, x, y, z, vx, vy, vz)) {
+        status = ST_ESCAPED;
+        ls = DS_DONE;
+      } else {
+        const int g = find_block<NDIM>(M, x, y, z);
+        const int li = M.local_index[g];
+        if (li < 0) {  // not resident here: hand the particle to the block's owner
+          status = ST_OUTGOING;
+          b = g;  // global id travels in blk
+          ls = DS_DONE;
+        } else {
+          b = li;
+          Blk Bn;
+          load_block(M, b, Bn);
+          if constexpr (multi_d)
+            sample_block_face<NDIM>(M, P, Bn, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
+          xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);
+          ls = (t < t_end) ? DS_REAL : DS_DONE;
+        }
+      }
+      real_pos = true;
+    }
+    // -- 2. finished particles: census resampling, write-back, tally
+    if (ls == DS_DONE) {
+      if (status != ST_OUTGOING && status != ST_ESCAPED) {
+        Blk Bd;
+        load_block(M, b, Bd);
+        Step s;
+        s.vv = vv;
+        faces_of(s, Bd, ip, jp, kp);
+        if (resample) {  // transport_utils.hpp:265-276, once per history
+          ddmc_census_resample(s, rng);
+          x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
+          pend = -1;
+        } else if (!real_pos) {
+          // absorbed (or already at census when it was loaded) in the virtual state: the albedo
+          // step left it at the cell centre (transport_utils.hpp:392-396), with the direction of
+          // its last leak
+          x = 0.5 * (s.xl + s.xu); y = 0.5 * (s.yl + s.yu); z = 0.5 * (s.zl + s.zu);
+        }
+        if (pend >= 0) {
+          s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
+          s.vx = vx; s.vy = vy; s.vz = vz;
+          materialise_dir(s);
+          vx = s.vx; vy = s.vy; vz = s.vz;
+          pend = -1;
+        }
+        if ((status == ST_ACTIVE || status == ST_OUTGOING_ABSORBED) && !M.owned[b]) {
+          if (status == ST_ACTIVE) status = ST_OUTGOING;  // the owner of the block tallies it
+          b = M.gid[b];
+        } else if (status == ST_ACTIVE) {
+          if constexpr (TALLY) {  // jaybenne.cpp:547-561
+            const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
+            if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], S.w[n] / dv);
+            else atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
+          }
+        }
+      }
+      S.blk[n] = b;
+      S.t[n] = t;
+      S.x[n] = x; S.y[n] = y; S.z[n] = z;
+      S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+      S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
+      S.status[n] = status;
+      S.rng[n] = rng.s;
+      if (status == ST_ACTIVE) ++c_census;
+      else if (status == ST_ABSORBED) ++c_abs;
+      else if (status == ST_ESCAPED) ++c_esc;
+      else ++c_out;
+      resample = false;
+      ls = DS_IDLE;
+    }
+    // -- 3. hand new particles to idle lanes (chunks of consecutive slots, one atomic per chunk)
+    {
+      unsigned long long idle = __ballot(ls == DS_IDLE);
+      while (idle != 0ull && more) {
+        if (chunk_pos >= chunk_end) {
+          const long long q_first = first + (long long)cur * per_q;
+          long long q_last = q_first + per_q;
+          if (q_last > last) q_last = last;
+          unsigned long long base = 0;
+          if (lane == 0) base = atomicAdd(&queue[cur], (unsigned long long)kChunk);
+          chunk_pos = q_first + (long long)uniform_u64(base);
+          chunk_end = chunk_pos + kChunk < q_last ? chunk_pos + kChunk : q_last;
+          if (chunk_pos >= q_last) {  // this queue is drained: move on
+            chunk_pos = chunk_end = 0;
+            cur = (cur + 1) % kQueues;
+            if (++tried == kQueues) more = false;
+            continue;
+          }
+        }
+        const int want = __popcll(idle);
+        const long long avail = chunk_end - chunk_pos;
+        const int give = (long long)want < avail ? want : (int)avail;
+        const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+        if (ls == DS_IDLE && rank < give) {
+          const long long cand = chunk_pos + rank;
+          const int st_in = S.status[cand];
+          const unsigned long long rng_in = S.rng[cand];
+          const int b_in = S.blk[cand];
+          const double t_in = S.t[cand], x_in = S.x[cand], y_in = S.y[cand], z_in = S.z[cand];
+          const double vx_in = S.vx[cand], vy_in = S.vy[cand], vz_in = S.vz[cand];
+          if (st_in == ST_ACTIVE) {
+            n = cand;
+            rng.s = rng_in;
+            b = b_in;
+            t = t_in;
+            x = x_in; y = y_in; z = z_in; vx = vx_in; vy = vy_in; vz = vz_in;
+            status = ST_ACTIVE;
+            resample = false;
+            pend = -1;
+            real_pos = true;
+            Blk Bn;
+            load_block(M, b, Bn);
+            xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);  // transport.cpp:96
+            ls = (t < t_end) ? DS_REAL : DS_DONE;      // already at census: nothing to track
+          }
+        }
+        chunk_pos += give;
+        idle = __ballot(ls == DS_IDLE);
+      }
+    }
+    // -- 4. one step with the real position (first step after a load or a block crossing, and
+    //       the steps after an albedo rejection): the general step functions
+    if (ls == DS_REAL) {
+      ++c_ev_real;
+      Blk Br;
+      load_block(M, b, Br);
+      Step s;
+      s.t_start = t_start; s.dt = dt; s.vv = vv; s.rvv = P.rc; s.dx_push = Br.dx_push;
+      faces_of(s, Br, ip, jp, kp);
+      s.t = t; s.x = x; s.y = y; s.z = z; s.vx = vx; s.vy = vy; s.vz = vz;
+      s.ip = ip; s.jp = jp; s.kp = kp;
+      s.is_absorbed = false; s.is_scattered = false; s.is_rejected = false;
+      s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
+      load_record(s, b, cidx(M, kp, jp, ip));
+      ptcl_ddmc_albedo<NDIM, true>(s, rng);
+      bool census = false;
+      if (!s.is_rejected) census = ddmc_step_event<NDIM, true, true>(s, rng);
+      t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
+      pend = s.pend; pz1 = s.pz1; pz2 = s.pz2;
+      xtoijk<NDIM>(M, Br, x, y, z, ip, jp, kp);  // transport.cpp:146
+      if (!s.is_rejected) resample = census;  // (as k_transport: the flag of the last step)
+      real_pos = true;
+      if (!on_block(M, ip, jp, kp)) {
+        // (a rejected particle keeps its direction: pend < 0; a leak is flagged in step 1)
+        ls = DS_RELOC;
+      } else if (s.is_absorbed) {  // transport.cpp:157-163
+        if (M.owned[b]) {
+          atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
+          status = ST_ABSORBED;
+        } else {
+          status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
+        }
+        ls = DS_DONE;
+      } else if (!(t < t_end)) {  // census
+        ls = DS_DONE;
+      } else if (!s.is_rejected) {
+        real_pos = false;  // leaked into a neighbouring cell of this block: virtual from here on
+        ls = DS_VIRT;
+      }  // (else: rejected at a face, still a real position next to it: another step here)
+    }
+    const int running = __popcll(__ballot(ls == DS_VIRT));
+    const unsigned long long pending = __ballot(ls == DS_REAL || ls == DS_DONE || ls == DS_RELOC);
+    if (running == 0) {
+      if (pending != 0ull || more) continue;
+      if (__ballot(ls != DS_IDLE) != 0ull) continue;
+      break;
+    }
+    // lanes that wait for the next service phase count against the budget from the start
+    int waste = 8 * __popcll(pending);
+
+    // ================================ EVENTS =================================
+#ifdef JB_TIMING
+    { const unsigned long long now = __builtin_readcyclecounter(); cyc_sv += now - cyc_mark; cyc_mark = now; }
+#endif
+    int thresh = 1;
+    int nrun = running;
+    while (nrun >= thresh) {
+      ++c_pass;
+      c_ev += (unsigned int)nrun;
+      if (ls == DS_VIRT) {
+        Step s;
+        s.t_start = t_start; s.dt = dt; s.vv = vv;
+        s.t = t;
+        s.ip = ip; s.jp = jp; s.kp = kp;
+        s.is_absorbed = false;
+        s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
+        // (faces and position feed nothing that is read below: the cell record holds the leak
+        // opacities P / dx, the step's position output is never formed)
+        s.xl = s.yl = s.zl = 0.0; s.xu = s.yu = s.zu = 1.0;
+        load_record(s, b, cidx(M, kp, jp, ip));
+        const bool census = ddmc_step_event<NDIM, true, true>(s, rng);
+        t = s.t;
+        ip = s.ip; jp = s.jp; kp = s.kp;  // = Xtoijk of the position the step gives (see header)
+        pend = s.pend; pz1 = s.pz1; pz2 = s.pz2;
+        resample = census;
+        if (!on_block(M, ip, jp, kp)) {
+          ls = DS_RELOC;
+        } else if (s.is_absorbed) {  // transport.cpp:157-163
+          if (M.owned[b]) {
+            atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
+            status = ST_ABSORBED;
+          } else {
+            status = ST_OUTGOING_ABSORBED;
+          }
+          ls = DS_DONE;
+        } else if (!(t < t_end)) {  // census
+          ls = DS_DONE;
+        }
+      }
+      nrun = __popcll(__ballot(ls == DS_VIRT));
+      waste += running - nrun;
+      if (waste >= kBudget) thresh = 65;
+    }
+  }
+
+  if constexpr (TALLY) {
+    if (tally_in_lds) {
+      __syncthreads();
+      for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) {
+        const double v = lds_tally[q];
+        if (v != 0.0) atomicAdd(&M.tally[q / (int)M.ntot][q % (int)M.ntot], v);
+      }
+    }
+  }
+  unsigned long long r_census = wave_sum(c_census), r_abs = wave_sum(c_abs), r_esc = wave_sum(c_esc),
+                     r_out = wave_sum(c_out);
+  const unsigned long long r_ev = c_ev + wave_sum(c_ev_real);
+  if (lane == 0) {
+    if (r_census) atomicAdd(&counters[CNT_CENSUS], r_census);
+    if (r_abs) atomicAdd(&counters[CNT_ABSORBED], r_abs);
+    if (r_esc) atomicAdd(&counters[CNT_ESCAPED], r_esc);
+    if (r_out) atomicAdd(&counters[CNT_OUTGOING], r_out);
+    if (r_ev) atomicAdd(&counters[CNT_EVENTS], r_ev);
+#ifdef JB_TIMING
+    atomicAdd(&counters[CNT_PASSES], cyc_ev >> 10);
+    atomicAdd(&counters[CNT_SERVICE], cyc_sv >> 10);
+#else
+    atomicAdd(&counters[CNT_PASSES], (unsigned long long)c_pass);
+    atomicAdd(&counters[CNT_SERVICE], (unsigned long long)c_service);
+#endif
+  }
+}
+
+}  // namespace jb

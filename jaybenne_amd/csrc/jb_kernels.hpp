@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P) {
     double *o = M.ddmc_cell[b] + 8 * q;
     o[0] = ff * aa;
     o[1] = aa + ss;
+    if (!(B.dx_push * o[1] > P.tau_ddmc)) atomicOr(M.not_all_ddmc, 1);  // an IMC cell
     o[2] = M.P1[b][q] / dx;
     o[3] = M.P1[b][cidx(M, k, j, i + 1)] / dx;
     o[4] = multi_d ? M.P2[b][q] / dy : 0.0;
@@ -357,8 +358,11 @@ template <int NDIM, bool DDMC, bool TALLY, int GRAY, bool EXACT = false>
 __global__ void
 __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER_SIMD)
     k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
-                long long last, unsigned long long *counters) {
+                long long last, unsigned long long *counters, const int *skip_unless) {
   static_assert(!EXACT || (GRAY != 0 && !DDMC), "EXACT is a variant of the gray IMC kernels");
+  // (gray DDMC launches come in pairs: k_ddmc_all runs when every cell is a DDMC cell, this
+  // kernel when *skip_unless says otherwise)
+  if (skip_unless != nullptr && *skip_unless == 0) return;
   // Small meshes (the reference's 1-D decks: ~1e2 cells under 1e5..1e8 particles): the census
   // tally of every workgroup goes to LDS and is flushed once at the end, instead of 1e8 global
   // atomics contending for a handful of cache lines.
@@ -1125,3 +1129,5 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 }  // namespace jb
+
+#include "jb_kernel_ddmc.hpp"

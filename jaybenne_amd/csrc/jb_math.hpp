@@ -43,6 +43,17 @@ __device__ __forceinline__ double m_fma(double a, double b, double c) {
 #endif
 }
 
+// fma(-a, b, c) with the negation as a source modifier (an asm operand `-a` would cost a v_xor)
+__device__ __forceinline__ double m_fnma(double a, double b, double c) {
+#ifdef JB_NO_ASM_FMA
+  return fma(-a, b, c);
+#else
+  double d;
+  asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+#endif
+}
+
 // min of two non-NaN numbers / minNum when one is NaN: one v_min_f64 (std::min written as
 // `(b < a) ? b : a` costs a compare and two selects).  Inputs are results of arithmetic, i.e.
 // already canonical, which is all the IEEE-mode v_min_f64 asks for.
@@ -164,7 +175,7 @@ __device__ __forceinline__ void m_sincos2pi(double u, double &sn, double &cs) {
   const double sr = m_fma(r * r2, m_fma(r2, 1.0 / 120.0, -1.0 / 6.0), r);
   const double cm1 = r2 * m_fma(r2, m_fma(r2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
   sn = m_fma(si, cm1, m_fma(ci, sr, si));
-  cs = m_fma(ci, cm1, m_fma(-si, sr, ci));
+  cs = m_fma(ci, cm1, m_fnma(si, sr, ci));
 }
 
 __device__ __forceinline__ double m_acos_R(double z) {

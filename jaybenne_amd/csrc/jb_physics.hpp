@@ -55,8 +55,9 @@ __device__ __forceinline__ void sample_face_iso_dir(double vv, Rng &rng, double 
 // reference scattering.hpp:21-29 -- 2 draws
 template <class Rng>
 __device__ __forceinline__ void scatter(Rng &rng, double vv, double &vx, double &vy, double &vz) {
-  const double mu = fma(2.0, rng.drand(), -1.0);  // (2 xi is exact: same value as 2 xi - 1)
-  const double xi2 = rng.drand();
+  double xi1, xi2;
+  rng.drand2(xi1, xi2);
+  const double mu = fma(2.0, xi1, -1.0);  // (2 xi is exact: same value as 2 xi - 1)
   const double st = m_sqrt(1.0 - mu * mu);  // |mu| <= 1 - 2^-52, so 1 - mu^2 >= 2^-52
   double sn, cs;
   m_sincos2pi(xi2, sn, cs);

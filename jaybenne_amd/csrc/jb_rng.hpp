@@ -93,6 +93,15 @@ struct LcgRng {
     s = s * kLcgMul + kLcgInc;
     return u52_to_double(s >> 12);
   }
+  // the next two draws at once: both states are formed from the current one (two independent
+  // multiply-adds instead of a chain of two); same states, same uniforms as drand(); drand()
+  __device__ __forceinline__ void drand2(double &u1, double &u2) {
+    constexpr uint64_t kMul2 = kLcgMul * kLcgMul, kInc2 = (kLcgMul + 1ull) * kLcgInc;
+    const uint64_t s1 = s * kLcgMul + kLcgInc;
+    s = s * kMul2 + kInc2;
+    u1 = u52_to_double(s1 >> 12);
+    u2 = u52_to_double(s >> 12);
+  }
   // consume one draw whose value cannot influence the result
   __device__ __forceinline__ void skip() { s = s * kLcgMul + kLcgInc; }
 };
@@ -109,6 +118,10 @@ struct TapeRng {
     return v;
   }
   __device__ __forceinline__ void skip() { ++ctr; }
+  __device__ __forceinline__ void drand2(double &u1, double &u2) {
+    u1 = drand();
+    u2 = drand();
+  }
 };
 
 }  // namespace jb
