@@ -696,6 +696,11 @@ extern "C" jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats 
   stats->n_events = (int64_t)ctx->counters_h[CNT_EVENTS];
   stats->n_wave_passes = (int64_t)ctx->counters_h[CNT_PASSES];
   stats->n_wave_services = (int64_t)ctx->counters_h[CNT_SERVICE];
+#ifdef JB_TIMING  // (diagnostic build: wave-cycles / 1024 per sub-phase of k_ddmc_all's service phase)
+  fprintf(stderr, "JB_TIMING phases reloc %llu claim %llu done %llu take %llu real %llu\n",
+          ctx->counters_h[24], ctx->counters_h[25], ctx->counters_h[26], ctx->counters_h[27],
+          ctx->counters_h[28]);
+#endif
   if (reset) JB_HIP(hipMemsetAsync(ctx->counters_d, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
   return JB_COMPLETE;
 }

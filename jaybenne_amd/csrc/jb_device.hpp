@@ -70,6 +70,7 @@ struct DevSwarm {
 // read-only field data reached through a pointer that was itself loaded from memory: telling
 // the compiler it is global memory makes the gathers global_load instead of flat_load
 typedef const double __attribute__((address_space(1))) *gcptr;
+typedef const int __attribute__((address_space(1))) *gcptr_i;
 
 enum { ST_ACTIVE = 0, ST_ABSORBED = 1, ST_ESCAPED = 2, ST_OUTGOING = 3, ST_OUTGOING_ABSORBED = 4 };
 enum { BC_PERIODIC = 0, BC_REFLECT = 1, BC_OUTFLOW = 2 };
@@ -111,6 +112,54 @@ __device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
     B.dx[d] = ((gcptr)M.blk_dx)[3 * b + d];
     B.x0[d] = B.xmin[d] - (double)first[d] * B.dx[d];
     B.inv_dx[d] = ((gcptr)M.blk_inv_dx)[3 * b + d];
+  }
+  B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));
+}
+
+// The same from a copy of the per-block tables in LDS (kernels whose service phase would wait
+// for these small dependent loads behind its own stores: vector-memory operations complete in
+// issue order, LDS reads have their own counter).  Up to kLdsBlocks resident blocks.
+constexpr int kLdsBlocks = 128;
+struct LdsBlockTable {
+  double xmin[kLdsBlocks][3], dx[kLdsBlocks][3], inv_dx[kLdsBlocks][3];
+  double *tally[kLdsBlocks];
+  int owned[kLdsBlocks];
+  int nbr_ent[kLdsBlocks][6];
+};
+__device__ __forceinline__ void fill_block_table(const DevMesh &M, LdsBlockTable &T) {
+  if (M.nblocks > kLdsBlocks) return;
+  for (int q = threadIdx.x; q < 3 * M.nblocks; q += blockDim.x) {
+    (&T.xmin[0][0])[q] = M.blk_xmin[q];
+    (&T.dx[0][0])[q] = M.blk_dx[q];
+    (&T.inv_dx[0][0])[q] = M.blk_inv_dx[q];
+  }
+  for (int q = threadIdx.x; q < M.nblocks; q += blockDim.x) {
+    T.tally[q] = M.tally[q];
+    T.owned[q] = M.owned[q];
+  }
+  for (int q = threadIdx.x; q < 6 * M.nblocks; q += blockDim.x) (&T.nbr_ent[0][0])[q] = M.nbr_ent[q];
+}
+__device__ __forceinline__ int block_nbr_ent(const DevMesh &M, const LdsBlockTable &T, int b, int face) {
+  return M.nblocks > kLdsBlocks ? ((gcptr_i)M.nbr_ent)[6 * b + face] : T.nbr_ent[b][face];
+}
+__device__ __forceinline__ bool block_owned(const DevMesh &M, const LdsBlockTable &T, int b) {
+  return (M.nblocks > kLdsBlocks ? M.owned[b] : T.owned[b]) != 0;
+}
+__device__ __forceinline__ double *block_tally(const DevMesh &M, const LdsBlockTable &T, int b) {
+  return M.nblocks > kLdsBlocks ? M.tally[b] : T.tally[b];
+}
+__device__ __forceinline__ void load_block(const DevMesh &M, const LdsBlockTable &T, int b, Blk &B) {
+  if (M.nblocks > kLdsBlocks) {  // (uniform)
+    load_block(M, b, B);
+    return;
+  }
+  const int first[3] = {M.is, M.js, M.ks};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    B.xmin[d] = T.xmin[b][d];
+    B.dx[d] = T.dx[b][d];
+    B.x0[d] = B.xmin[d] - (double)first[d] * B.dx[d];
+    B.inv_dx[d] = T.inv_dx[b][d];
   }
   B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));
 }

@@ -12,11 +12,15 @@
 //     2.5e6 eps and cannot fire, and then moves the particle to the cell centre (:392-396);
 //   * the direction drawn at the leak is read by nobody until the particle leaves DDMC cells, is
 //     absorbed or crosses a block (deferred: channel + its two uniforms, as in k_transport).
-// So a lane in the event loop carries cell, time, random-stream state and the pending leak
-// ("virtual" state: 17 registers); position and direction exist only in the service phase, which
-// loads a particle, takes its first step with the general step functions (real position: the
-// albedo test can fire there), and rebuilds position / direction from the virtual state where a
-// consumer appears (block crossing, census resampling, absorption, write-back).  Same draws, same
+// So a lane in the event loop carries cell, time, weight, random-stream state and the pending
+// leak ("virtual" state: 19 registers); position and direction exist only in the service phase.
+// It loads a particle and evaluates the albedo step's six face tests on its real position: if
+// none holds (a particle lies within 5.5e-9 dx of a face of its cell once in ~1e8) the step
+// starts from the cell centre like every other and the lane goes straight to the loop; otherwise
+// that step is taken there and then with the general step functions.  A direction that no step
+// has changed is not carried either: it stays where it was loaded from (S.vx, vy, vz).  Position
+// and direction are rebuilt from the virtual state where a consumer appears (block crossing,
+// census resampling, absorption, write-back).  Same draws, same
 // arithmetic, same bits as k_transport<NDIM, true, TALLY, 1 or 2> -- tests/test_gpu_parity.py
 // holds both to the oracle.
 #pragma once
@@ -29,7 +33,7 @@ namespace jb {
 #define JB_DDMC_ALL_WAVES_PER_SIMD 4
 #endif
 #ifndef JB_DDMC_ALL_BUDGET   // idle lane-passes that buy a service phase
-#define JB_DDMC_ALL_BUDGET 128
+#define JB_DDMC_ALL_BUDGET 256
 #endif
 #ifndef JB_DDMC_ALL_CHUNK
 #define JB_DDMC_ALL_CHUNK 128
@@ -48,6 +52,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     if (tally_in_lds)
       for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) lds_tally[q] = 0.0;
   }
+  __shared__ LdsBlockTable lds_blocks;
+  fill_block_table(M, lds_blocks);
   load_math_tables();  // (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2;
   constexpr int kBudget = JB_DDMC_ALL_BUDGET;
@@ -71,8 +77,11 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
   long long n = 0;
   LcgRng rng(0);
   int b = 0, ip = 0, jp = 0, kp = 0;
-  double t = 0.0;
-  int pend = -1;  // channel of the last leak (0..5) while its direction is deferred, else -1
+  double t = 0.0, wgt = 0.0;
+  // channel of the last leak (0..5) while its direction is deferred; -1: the direction is the one
+  // in vx, vy, vz (real_pos) or, for a lane in the loop, the one in S.vx, vy, vz [n]; -2: zero,
+  // the flag a multi-D DDMC leak across a block face leaves behind (transport_ddmc.cpp:203-211)
+  int pend = -1;
   double pz1 = 0.0, pz2 = 0.0;
   bool resample = false;  // reached census in a DDMC step: position / direction to be resampled
   // ---- state that exists only between two points of one service phase
@@ -96,8 +105,26 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
   };
 
+  // a particle with a real position (just loaded / just relocated) enters the loop unless the
+  // albedo step would find it at a face of its cell
+  auto enter = [&](const Blk &Bq) {
+    Step s;
+    faces_of(s, Bq, ip, jp, kp);
+    s.x = x; s.y = y; s.z = z;
+    if (at_cell_face<NDIM>(s)) {
+      ls = DS_REAL;
+    } else {
+      real_pos = false;
+      ls = DS_VIRT;
+    }
+  };
+
 #ifdef JB_TIMING
   unsigned long long cyc_ev = 0, cyc_sv = 0, cyc_mark = __builtin_readcyclecounter();
+  unsigned long long cyc_ph[6] = {0, 0, 0, 0, 0, 0}, ph_mark = 0;  // reloc, claim, done, take, real, tail
+#define JB_PH(k) { const unsigned long long now_ = __builtin_readcyclecounter(); cyc_ph[k] += now_ - ph_mark; ph_mark = now_; }
+#else
+#define JB_PH(k)
 #endif
   for (;;) {
     // ================================ SERVICE ================================
@@ -105,10 +132,13 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
 #ifdef JB_TIMING
     { const unsigned long long now = __builtin_readcyclecounter(); cyc_ev += now - cyc_mark; cyc_mark = now; }
 #endif
+#ifdef JB_TIMING
+    ph_mark = __builtin_readcyclecounter();
+#endif
     // -- 1. block crossings: the comm phase of the reference for one particle in flight
     if (ls == DS_RELOC) {
       Blk Bo;
-      load_block(M, b, Bo);
+      load_block(M, lds_blocks, b, Bo);
       Step s;
       s.vv = vv; s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
       if (!real_pos) {
@@ -151,69 +181,37 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         } else {
           b = li;
           Blk Bn;
-          load_block(M, b, Bn);
+          load_block(M, lds_blocks, b, Bn);
           if constexpr (multi_d)
             sample_block_face<NDIM>(M, P, Bn, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
           xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);
-          ls = (t < t_end) ? DS_REAL : DS_DONE;
-        }
-      }
-      real_pos = true;
-    }
-    // -- 2. finished particles: census resampling, write-back, tally
-    if (ls == DS_DONE) {
-      if (status != ST_OUTGOING && status != ST_ESCAPED) {
-        Blk Bd;
-        load_block(M, b, Bd);
-        Step s;
-        s.vv = vv;
-        faces_of(s, Bd, ip, jp, kp);
-        if (resample) {  // transport_utils.hpp:265-276, once per history
-          ddmc_census_resample(s, rng);
-          x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
-          pend = -1;
-        } else if (!real_pos) {
-          // absorbed (or already at census when it was loaded) in the virtual state: the albedo
-          // step left it at the cell centre (transport_utils.hpp:392-396), with the direction of
-          // its last leak
-          x = 0.5 * (s.xl + s.xu); y = 0.5 * (s.yl + s.yu); z = 0.5 * (s.zl + s.zu);
-        }
-        if (pend >= 0) {
-          s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
-          s.vx = vx; s.vy = vy; s.vz = vz;
-          materialise_dir(s);
-          vx = s.vx; vy = s.vy; vz = s.vz;
-          pend = -1;
-        }
-        if ((status == ST_ACTIVE || status == ST_OUTGOING_ABSORBED) && !M.owned[b]) {
-          if (status == ST_ACTIVE) status = ST_OUTGOING;  // the owner of the block tallies it
-          b = M.gid[b];
-        } else if (status == ST_ACTIVE) {
-          if constexpr (TALLY) {  // jaybenne.cpp:547-561
-            const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
-            if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], S.w[n] / dv);
-            else atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
+          real_pos = true;
+          if (t < t_end) {
+            enter(Bn);
+            if (ls == DS_VIRT) {  // (the loop does not carry the direction: park it)
+              S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+            }
+          } else {
+            ls = DS_DONE;
           }
         }
       }
-      S.blk[n] = b;
-      S.t[n] = t;
-      S.x[n] = x; S.y[n] = y; S.z[n] = z;
-      S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
-      S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
-      S.status[n] = status;
-      S.rng[n] = rng.s;
-      if (status == ST_ACTIVE) ++c_census;
-      else if (status == ST_ABSORBED) ++c_abs;
-      else if (status == ST_ESCAPED) ++c_esc;
-      else ++c_out;
-      resample = false;
-      ls = DS_IDLE;
+      if (ls != DS_VIRT) real_pos = true;
     }
-    // -- 3. hand new particles to idle lanes (chunks of consecutive slots, one atomic per chunk)
+    JB_PH(0)
+    // -- 2a. every lane that is idle, or will be once its finished particle is written back,
+    //        claims the next slot of the wave's chunk (chunks of consecutive slots, one atomic
+    //        per chunk) and REQUESTS that particle now: vector-memory operations complete in
+    //        issue order, so loads issued after the write-back below would wait for its stores
+    //        and its tally atomic
+    long long cand = -1;
+    int st_in = ST_ABSORBED, b_in = 0;
+    unsigned long long rng_in = 0ull;
+    double t_in = 0.0, x_in = 0.0, y_in = 0.0, z_in = 0.0, vx_in = 0.0, vy_in = 0.0, vz_in = 0.0,
+           w_in = 0.0;
     {
-      unsigned long long idle = __ballot(ls == DS_IDLE);
-      while (idle != 0ull && more) {
+      unsigned long long need = __ballot(ls == DS_IDLE || ls == DS_DONE);
+      while (need != 0ull && more) {
         if (chunk_pos >= chunk_end) {
           const long long q_first = first + (long long)cur * per_q;
           long long q_last = q_first + per_q;
@@ -229,43 +227,110 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
             continue;
           }
         }
-        const int want = __popcll(idle);
+        const int want = __popcll(need);
         const long long avail = chunk_end - chunk_pos;
         const int give = (long long)want < avail ? want : (int)avail;
-        const int rank = __popcll(idle & ((1ull << lane) - 1ull));
-        if (ls == DS_IDLE && rank < give) {
-          const long long cand = chunk_pos + rank;
-          const int st_in = S.status[cand];
-          const unsigned long long rng_in = S.rng[cand];
-          const int b_in = S.blk[cand];
-          const double t_in = S.t[cand], x_in = S.x[cand], y_in = S.y[cand], z_in = S.z[cand];
-          const double vx_in = S.vx[cand], vy_in = S.vy[cand], vz_in = S.vz[cand];
-          if (st_in == ST_ACTIVE) {
-            n = cand;
-            rng.s = rng_in;
-            b = b_in;
-            t = t_in;
-            x = x_in; y = y_in; z = z_in; vx = vx_in; vy = vy_in; vz = vz_in;
-            status = ST_ACTIVE;
-            resample = false;
-            pend = -1;
-            real_pos = true;
-            Blk Bn;
-            load_block(M, b, Bn);
-            xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);  // transport.cpp:96
-            ls = (t < t_end) ? DS_REAL : DS_DONE;      // already at census: nothing to track
-          }
+        const int rank = __popcll(need & ((1ull << lane) - 1ull));
+        const bool mine = ((need >> lane) & 1ull) != 0ull && rank < give;
+        if (mine) {
+          cand = chunk_pos + rank;
+          st_in = S.status[cand];
+          rng_in = S.rng[cand];
+          b_in = S.blk[cand];
+          t_in = S.t[cand]; x_in = S.x[cand]; y_in = S.y[cand]; z_in = S.z[cand];
+          vx_in = S.vx[cand]; vy_in = S.vy[cand]; vz_in = S.vz[cand];
+          w_in = S.w[cand];
         }
         chunk_pos += give;
-        idle = __ballot(ls == DS_IDLE);
+        need &= ~__ballot(mine);
       }
     }
+    JB_PH(1)
+    // -- 2b. finished particles: census resampling, write-back, tally
+    if (ls == DS_DONE) {
+      bool write_v = real_pos;  // else: unchanged since it was loaded (or parked), or set below
+      if (status != ST_OUTGOING && status != ST_ESCAPED) {
+        Blk Bd;
+        load_block(M, lds_blocks, b, Bd);
+        Step s;
+        s.vv = vv;
+        faces_of(s, Bd, ip, jp, kp);
+        if (resample) {  // transport_utils.hpp:265-276, once per history
+          ddmc_census_resample(s, rng);
+          x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
+          pend = -1;
+          write_v = true;
+        } else if (!real_pos) {
+          // absorbed (or already at census when it was loaded) in the virtual state: the albedo
+          // step left it at the cell centre (transport_utils.hpp:392-396), with the direction of
+          // its last leak
+          x = 0.5 * (s.xl + s.xu); y = 0.5 * (s.yl + s.yu); z = 0.5 * (s.zl + s.zu);
+        }
+        if (pend >= 0) {
+          s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
+          s.vx = vx; s.vy = vy; s.vz = vz;
+          materialise_dir(s);
+          vx = s.vx; vy = s.vy; vz = s.vz;
+          pend = -1;
+          write_v = true;
+        } else if (pend == -2) {
+          vx = 0.0; vy = 0.0; vz = 0.0;
+          pend = -1;
+          write_v = true;
+        }
+        if ((status == ST_ACTIVE || status == ST_OUTGOING_ABSORBED) && !block_owned(M, lds_blocks, b)) {
+          if (status == ST_ACTIVE) status = ST_OUTGOING;  // the owner of the block tallies it
+          b = M.gid[b];
+        } else if (status == ST_ACTIVE) {
+          if constexpr (TALLY) {  // jaybenne.cpp:547-561
+            const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
+            if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
+            else atomicAdd(&block_tally(M, lds_blocks, b)[cidx(M, kp, jp, ip)], wgt / dv);
+          }
+        }
+      }
+      S.blk[n] = b;
+      S.t[n] = t;
+      S.x[n] = x; S.y[n] = y; S.z[n] = z;
+      if (write_v) {
+        S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+      }
+      S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
+      S.status[n] = status;
+      S.rng[n] = rng.s;
+      if (status == ST_ACTIVE) ++c_census;
+      else if (status == ST_ABSORBED) ++c_abs;
+      else if (status == ST_ESCAPED) ++c_esc;
+      else ++c_out;
+      resample = false;
+      ls = DS_IDLE;
+    }
+    JB_PH(2)
+    // -- 3b. the lanes that claimed a slot in 2a take their new particle
+    if (ls == DS_IDLE && cand >= 0 && st_in == ST_ACTIVE) {
+      n = cand;
+      rng.s = rng_in;
+      b = b_in;
+      t = t_in;
+      wgt = w_in;
+      x = x_in; y = y_in; z = z_in; vx = vx_in; vy = vy_in; vz = vz_in;
+      status = ST_ACTIVE;
+      resample = false;
+      pend = -1;
+      real_pos = true;
+      Blk Bn;
+      load_block(M, lds_blocks, b, Bn);
+      xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);  // transport.cpp:96
+      if (t < t_end) enter(Bn);
+      else ls = DS_DONE;  // already at census: nothing to track
+    }
+    JB_PH(3)
     // -- 4. one step with the real position (first step after a load or a block crossing, and
     //       the steps after an albedo rejection): the general step functions
     if (ls == DS_REAL) {
       ++c_ev_real;
       Blk Br;
-      load_block(M, b, Br);
+      load_block(M, lds_blocks, b, Br);
       Step s;
       s.t_start = t_start; s.dt = dt; s.vv = vv; s.rvv = P.rc; s.dx_push = Br.dx_push;
       faces_of(s, Br, ip, jp, kp);
@@ -286,8 +351,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         // (a rejected particle keeps its direction: pend < 0; a leak is flagged in step 1)
         ls = DS_RELOC;
       } else if (s.is_absorbed) {  // transport.cpp:157-163
-        if (M.owned[b]) {
-          atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
+        if (block_owned(M, lds_blocks, b)) {
+          atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], wgt);
           status = ST_ABSORBED;
         } else {
           status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
@@ -300,6 +365,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         ls = DS_VIRT;
       }  // (else: rejected at a face, still a real position next to it: another step here)
     }
+    JB_PH(4)
     const int running = __popcll(__ballot(ls == DS_VIRT));
     const unsigned long long pending = __ballot(ls == DS_REAL || ls == DS_DONE || ls == DS_RELOC);
     if (running == 0) {
@@ -336,10 +402,29 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         pend = s.pend; pz1 = s.pz1; pz2 = s.pz2;
         resample = census;
         if (!on_block(M, ip, jp, kp)) {
-          ls = DS_RELOC;
+          // A leak through a block face (0.4 per history on BASELINE configs[2]).  Into a resident
+          // block of the same size -- directly or through a periodic boundary -- nothing happens
+          // to the particle beyond the new block and cell: SampleDDMCBlockFace only acts on an
+          // arrival from a COARSER block (it looks for x_min + 2 eps_ddmc dx, a same-size leak
+          // lands at x_min + eps_ddmc dx: sample_ddmc_bface.cpp:158-165), Xtoijk gives the first
+          // or last cell along the axis, and in more than one dimension the direction is zeroed
+          // (transport_ddmc.cpp:203-211).  Everything else goes through the service phase.
+          const int axis = pend >> 1;
+          const bool up = (pend & 1) != 0;
+          const int ent = block_nbr_ent(M, lds_blocks, b, pend);
+          if (ent >= 0 && (ent >> 28) != 2) {
+            b = ent & 0x0fffffff;
+            if (axis == 0) ip = up ? M.is : M.ie;
+            else if (axis == 1) jp = up ? M.js : M.je;
+            else kp = up ? M.ks : M.ke;
+            if constexpr (multi_d) pend = -2;
+            if (!(t < t_end)) ls = DS_DONE;
+          } else {
+            ls = DS_RELOC;
+          }
         } else if (s.is_absorbed) {  // transport.cpp:157-163
-          if (M.owned[b]) {
-            atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
+          if (block_owned(M, lds_blocks, b)) {
+            atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], wgt);
             status = ST_ABSORBED;
           } else {
             status = ST_OUTGOING_ABSORBED;
@@ -376,6 +461,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
 #ifdef JB_TIMING
     atomicAdd(&counters[CNT_PASSES], cyc_ev >> 10);
     atomicAdd(&counters[CNT_SERVICE], cyc_sv >> 10);
+    for (int k = 0; k < 6; ++k) atomicAdd(&counters[24 + k], cyc_ph[k] >> 10);  // (scratch words)
 #else
     atomicAdd(&counters[CNT_PASSES], (unsigned long long)c_pass);
     atomicAdd(&counters[CNT_SERVICE], (unsigned long long)c_service);

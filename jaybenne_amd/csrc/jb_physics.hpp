@@ -422,6 +422,19 @@ __device__ __forceinline__ void ptcl_ddmc_albedo(Step &s, Rng &rng) {
   }
 }
 
+// Would ptcl_ddmc_albedo find the particle at a face of its cell (transport_utils.hpp:288-373)?
+// The same six tests in the same order; when none holds the albedo step draws nothing and only
+// moves the particle to the cell centre (:392-396).
+template <int NDIM>
+__device__ __forceinline__ bool at_cell_face(const Step &s) {
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  const double dx = s.xu - s.xl, dy = s.yu - s.yl, dz = s.zu - s.zl;
+  const double tol = 2.5 * kEpsImc;
+  return fuzzy_equal(s.x, s.xl, dx, tol) || fuzzy_equal(s.x, s.xu, dx, tol) ||
+         (multi_d && (fuzzy_equal(s.y, s.yl, dy, tol) || fuzzy_equal(s.y, s.yu, dy, tol))) ||
+         (three_d && (fuzzy_equal(s.z, s.zl, dz, tol) || fuzzy_equal(s.z, s.zu, dz, tol)));
+}
+
 // reference sample_ddmc_bface.cpp:24-41 -- 2 draws
 template <class Rng>
 __device__ __forceinline__ void sample_face_2d(int i_l, double dx, double P_l, double P_u, Rng &rng,

@@ -1,0 +1,16 @@
+set -e
+mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for c in "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_ATOMIC_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $c | cut -d' ' -f1)
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/tcc_c3_$tag -o runc -- \
+    python3 bench.py --workload c3 --particles-per-gpu 100000000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/tcc_c3_$tag.json 2> gpurun_out/tcc_err.txt
+  python3 - gpurun_out/tcc_c3_$tag <<'P'
+import csv, glob, os, sys
+tot = {}
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_ddmc_all" in r["Kernel_Name"] or "k_transport" in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+print(tot)
+P
+done

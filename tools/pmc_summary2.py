@@ -8,18 +8,19 @@ for p in "ABC":
     d = f"gpurun_out/pmc2_{w}_{name}_{p}"
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_transport" not in r["Kernel_Name"]:
+            if "k_transport" not in r["Kernel_Name"] and "k_ddmc_all" not in r["Kernel_Name"]:
                 continue
             tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             tot["_vgpr"] = r.get("VGPR_Count") or r.get("Arch_VGPR_Count")
             tot["_kernel"] = r["Kernel_Name"][:60]
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_transport" in r["Kernel_Name"]:
+            if "k_transport" in r["Kernel_Name"] or "k_ddmc_all" in r["Kernel_Name"]:
                 dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 b = json.load(open(f"gpurun_out/pmc2_{w}_{name}_A.json"))
 k = b["kernel_diagnostics"]
 ev, passes = k["n_events"], k["n_wave_passes"]
+dur = [d for d in dur if d > 0.05 * max(dur)] if dur else dur
 ms = sum(dur) / max(len(dur), 1)
 out = {"workload": w, "lib": name, "kernel": tot.get("_kernel"), "vgpr": tot.get("_vgpr"), "launch_ms": ms,
        "events": ev, "wave_passes": passes, "services": k["n_wave_services"],
