@@ -30,7 +30,7 @@
 namespace jb {
 
 #ifndef JB_DDMC_ALL_WAVES_PER_SIMD
-#define JB_DDMC_ALL_WAVES_PER_SIMD 4
+#define JB_DDMC_ALL_WAVES_PER_SIMD 3
 #endif
 #ifndef JB_DDMC_ALL_BUDGET   // idle lane-passes that buy a service phase
 #define JB_DDMC_ALL_BUDGET 256
@@ -285,10 +285,13 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           if constexpr (TALLY) {  // jaybenne.cpp:547-561
             const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
             if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
+#ifndef JB_EXPERIMENT_NOTALLY
             else atomicAdd(&block_tally(M, lds_blocks, b)[cidx(M, kp, jp, ip)], wgt / dv);
+#endif
           }
         }
       }
+#ifndef JB_EXPERIMENT_NOSTORE   // (timing experiment only: results are wrong without the stores)
       S.blk[n] = b;
       S.t[n] = t;
       S.x[n] = x; S.y[n] = y; S.z[n] = z;
@@ -298,6 +301,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
       S.status[n] = status;
       S.rng[n] = rng.s;
+#else
+      S.t[n] = t;
+#endif
       if (status == ST_ACTIVE) ++c_census;
       else if (status == ST_ABSORBED) ++c_abs;
       else if (status == ST_ESCAPED) ++c_esc;
@@ -366,15 +372,16 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       }  // (else: rejected at a face, still a real position next to it: another step here)
     }
     JB_PH(4)
+    // Lanes that still hold a real position (a step at a face, a general relocation, a particle
+    // to write back) are served before the loop is entered again: position and direction are
+    // then dead across the event loop and cost it no registers.
+    if (__ballot(ls == DS_REAL || ls == DS_DONE || ls == DS_RELOC) != 0ull) continue;
     const int running = __popcll(__ballot(ls == DS_VIRT));
-    const unsigned long long pending = __ballot(ls == DS_REAL || ls == DS_DONE || ls == DS_RELOC);
     if (running == 0) {
-      if (pending != 0ull || more) continue;
-      if (__ballot(ls != DS_IDLE) != 0ull) continue;
+      if (more) continue;
       break;
     }
-    // lanes that wait for the next service phase count against the budget from the start
-    int waste = 8 * __popcll(pending);
+    int waste = 0;
 
     // ================================ EVENTS =================================
 #ifdef JB_TIMING
@@ -412,11 +419,14 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           const int axis = pend >> 1;
           const bool up = (pend & 1) != 0;
           const int ent = block_nbr_ent(M, lds_blocks, b, pend);
-          if (ent >= 0 && (ent >> 28) != 2) {
+          // (a reflecting boundary puts the particle back into the cell it left, eps_ddmc dx
+          // inside the wall; in 1-D its direction would have to be mirrored: service phase)
+          if (ent >= 0 && (multi_d || (ent >> 28) != 2)) {
+            const bool at_first = ((ent >> 28) == 2) != up;
             b = ent & 0x0fffffff;
-            if (axis == 0) ip = up ? M.is : M.ie;
-            else if (axis == 1) jp = up ? M.js : M.je;
-            else kp = up ? M.ks : M.ke;
+            if (axis == 0) ip = at_first ? M.is : M.ie;
+            else if (axis == 1) jp = at_first ? M.js : M.je;
+            else kp = at_first ? M.ks : M.ke;
             if constexpr (multi_d) pend = -2;
             if (!(t < t_end)) ls = DS_DONE;
           } else {
