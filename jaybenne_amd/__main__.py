@@ -31,7 +31,11 @@ def main(argv=None) -> int:
     ap.add_argument("--match-total-energy", action="store_true",
                     help="with --transverse-average: scale the solution to the tally's total energy "
                          "(fewer than one source particle per cell under-samples the energy)")
-    ap.add_argument("--output", default=None, help="write tally / coordinates to this .npz")
+    ap.add_argument("--output", default=None,
+                    help="write the final state to this file: .phdf (Parthenon-style HDF5, needs "
+                         "libhdf5) or .npz.  Without it a deck with a <parthenon/output0> block of "
+                         "file_type = hdf5 writes <problem_id>.out0.final.phdf into --output-dir")
+    ap.add_argument("--output-dir", default=None, help="directory for deck-driven dumps (default: none written)")
     ap.add_argument("overrides", nargs="*", help="block/key=value")
     args = ap.parse_args(argv)
 
@@ -80,9 +84,35 @@ def main(argv=None) -> int:
     print(f"Mean weighted fractional error: {err['mean_frac_error_weighted']:.2e}")
     print(f"Max error:                      {err['max_error']:.2e}")
     print(f"Max fractional error:           {err['max_frac_error']:.2e}")
-    if args.output:
-        np.savez(args.output, tally=tally, time=drv.time, blk_xmin=drv.mesh.blk_xmin,
-                 blk_dx=drv.mesh.blk_dx, blk_level=drv.mesh.blk_level)
+    out_path = args.output
+    if out_path is None and args.output_dir is not None and \
+            pin.GetOrAddString("parthenon/output0", "file_type", "none") == "hdf5":
+        out_path = os.path.join(args.output_dir, f"{drv.mcb.problem_id}.out0.final.phdf")
+    if out_path:
+        from . import phdf
+        if out_path.endswith(".npz") or not phdf.available():
+            if not out_path.endswith(".npz"):
+                print("libhdf5 not found: writing .npz instead", file=sys.stderr)
+                out_path = os.path.splitext(out_path)[0] + ".npz"
+            np.savez(out_path, tally=tally, time=drv.time, blk_xmin=drv.mesh.blk_xmin,
+                     blk_dx=drv.mesh.blk_dx, blk_level=drv.mesh.blk_level)
+        else:
+            # <parthenon/output0> variables / swarm_variables of the deck (inputs/stepdiff_smr.in:86-94)
+            names = {"field.material.density": "rho", "field.material.sie": "sie",
+                     "field.material.internal_energy": "u", "field.jaybenne.energy_tally": "tally",
+                     "field.jaybenne.fleck_factor": "fleck"}
+            want = [v.strip() for v in pin.GetOrAddString(
+                "parthenon/output0", "variables", "field.jaybenne.energy_tally").replace("&", "").split(",") if v.strip()]
+            variables = {v: drv.md.get_field(names[v]) for v in want if v in names}
+            sw = drv.md.get_swarm()
+            svars = [v.strip() for v in pin.GetOrAddString(
+                "parthenon/output0", "swarm_variables", "swarm.x, swarm.y").replace("&", "").split(",") if v.strip()]
+            key = {"swarm.x": "x", "swarm.y": "y", "swarm.z": "z", "weight": "w", "time": "t", "energy": "e"}
+            swarm = {"blk": drv.md.gids[sw["blk"]], "id": sw["id"]}
+            swarm.update({v: sw[key[v]] for v in svars if v in key})
+            phdf.write_dump(out_path, drv.mesh, drv.time, drv.dt, drv.ncycle, variables,
+                            {"photons": swarm}, input_text=open(args.input).read())
+        print(f"wrote {out_path}")
     if args.tolerance is None:
         return 0
     crit = {"mean": err["mean_frac_error"], "pointwise": err["max_frac_error"],

@@ -23,6 +23,34 @@ def test_reference_regression_suite(gpu_device, deck, overrides, tol, capsys):
     assert rc == 0 and "TEST PASSED" in out, out
 
 
+def test_cli_writes_the_decks_hdf5_dump(gpu_device, tmp_path, capsys):
+    """inputs/stepdiff_smr.in:86-94 asks for an hdf5 dump of four fields and the swarm's x, y: the
+    command line writes <problem_id>.out0.final.phdf, and the reference's acceptance loop run on
+    the dump (cell centres from block bounds + Get, tst/regression_test.py:361-406) reproduces
+    the number the command line printed."""
+    from jaybenne_amd import analysis, phdf
+    from jaybenne_amd.__main__ import main
+    if not phdf.available():
+        pytest.skip("libhdf5 not found")
+    rc = main(["-i", os.path.join(DECKS, "stepdiff_smr.in"), "--tolerance", "0.3",
+               "--output-dir", str(tmp_path)] + SMR)
+    out = capsys.readouterr().out
+    assert rc == 0, out
+    d = phdf.read_dump(str(tmp_path / "stepdiff.out0.final.phdf"))
+    assert d.NumDims == 2 and d.NumBlocks == 20 and sorted(set(d.Levels.tolist())) == [0, 1]
+    assert d.Variables == ["field.material.density", "field.material.sie",
+                           "field.material.internal_energy", "field.jaybenne.energy_tally"]
+    var = d.Get("field.jaybenne.energy_tally")
+    sol = analysis.ur_solution(d.Time, d.X1c)
+    frac = np.abs(sol - var) / np.abs((sol + var) / 2.0)
+    weighted = float((frac * sol).sum() / sol.sum())
+    printed = float([ln for ln in out.splitlines() if ln.startswith("Mean weighted")][0].split()[-1])
+    assert weighted == pytest.approx(printed, rel=2e-2)       # (printed with 3 digits)
+    ph = d.GetSwarm("photons")
+    assert ph.x is not None and ph.y is not None and ph.z is None and len(ph.x) == int(ph.counts.sum())
+    assert np.all(d.Get("field.material.density") == 1.0)
+
+
 def test_smr_noise_floor_with_more_particles(gpu_device, capsys):
     """The 0.3 gate of the SMR decks is Monte Carlo noise (20 particles per cell); with 20x the
     particles the same problem must come down by ~sqrt(20): a systematic error would not."""
