@@ -1,0 +1,282 @@
+// handoff_mpi.cpp -- the inter-rank particle hand-off of the history loop driven from C++ over
+// MPI, with nothing but the C ABI (include/jaybenne_amd.h), the HIP runtime and MPI in the process:
+// the iterate-sublist of reference jaybenne.cpp:113-131 (transport -> MeshSend / MeshReceive ->
+// CheckCompletion with its global_sync) as a host would write it around
+// jb_transport_photons / jb_pack_outgoing / jb_unpack_incoming.
+//
+//   mpiexec -n R ./handoff_mpi [cells_per_block] [blocks] [particles] [cycles]
+//
+// Problem: inputs/stepdiff.in in 1-D (x in [-0.5, 0.5], sigma_s = 1e3, no absorption, T = 1e5 K
+// for x < 0 and 1 K for x >= 0, reflecting walls), `blocks` meshblocks dealt to the R ranks in
+// contiguous runs.  A rank keeps ONLY the blocks it owns (no halo copies): every photon that
+// leaves a rank's blocks comes back from the transport kernel marked JB_ST_OUTGOING with the
+// global id of its destination block, is packed into 104-byte records per destination rank,
+// travels through MPI_Alltoallv (staged through host memory: the MPI of this image is not
+// GPU-aware; with a GPU-aware MPI or RCCL the device buffers go in directly) and is appended to
+// the receiver's swarm.  The loop ends when no rank moved a particle (MPI_Allreduce).
+//
+// Checks (exit code 0 iff all hold): the photon count and the total weight are conserved over the
+// cycles (sigma_a = 0), every photon ends each cycle exactly at census, and the energy tally
+// integrates to the radiation energy.  All ranks may share one GPU (rank % device_count).
+#include <hip/hip_runtime.h>
+#include <mpi.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "jaybenne_amd.h"
+
+#define HIP_OK(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      std::fprintf(stderr, "%s failed: %s\n", #call, hipGetErrorString(e_));                 \
+      MPI_Abort(MPI_COMM_WORLD, 3);                                                          \
+    }                                                                                        \
+  } while (0)
+#define JB_OK(call)                                                                          \
+  do {                                                                                       \
+    jb_status s_ = (call);                                                                   \
+    if (s_ < 0) {                                                                            \
+      std::fprintf(stderr, "%s failed (%d): %s\n", #call, (int)s_, jb_last_error());         \
+      MPI_Abort(MPI_COMM_WORLD, 4);                                                          \
+    }                                                                                        \
+  } while (0)
+
+template <class T>
+static T *dev_alloc(size_t n) {
+  T *p = nullptr;
+  HIP_OK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+  HIP_OK(hipMemset(p, 0, (n ? n : 1) * sizeof(T)));
+  return p;
+}
+
+int main(int argc, char **argv) {
+  MPI_Init(&argc, &argv);
+  int rank = 0, nranks = 1;
+  MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+  MPI_Comm_size(MPI_COMM_WORLD, &nranks);
+  const int nx = argc > 1 ? std::atoi(argv[1]) : 16;
+  const int nblocks_total = argc > 2 ? std::atoi(argv[2]) : 8;
+  const long long nparticles = argc > 3 ? std::atoll(argv[3]) : 200000;
+  const int cycles = argc > 4 ? std::atoi(argv[4]) : 3;
+  if (nblocks_total < nranks) {
+    if (rank == 0) std::fprintf(stderr, "need at least one block per rank\n");
+    MPI_Finalize();
+    return 2;
+  }
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  const int device = rank % ndev;
+  HIP_OK(hipSetDevice(device));
+
+  // ---- package (jaybenne::Initialize; deck values of inputs/stepdiff.in)
+  const double c = 2.99792458e10, sb = 5.670374419e-5;
+  jb_params p{};
+  p.num_particles = nparticles;
+  p.dt = 3.335641e-11;
+  p.min_swarm_occupancy = 0.0;
+  p.numin = 0.0; p.numax = 1.0e300;
+  p.tau_ddmc = 5.0;
+  p.unique_rank_seeds = 1;
+  p.seed = 349857;
+  p.max_transport_iterations = 10000;
+  p.use_ddmc = 0;
+  p.source_strategy = JB_STRATEGY_UNIFORM;
+  p.do_emission = 0;
+  p.do_feedback = 0;
+  p.rank = rank;
+  jb_eos eos{JB_EOS_IDEAL_GAS, 0, 1.66666666667 - 1.0, 1.0 / (1.66666666667 - 1.0)};
+  jb_opacity opac{JB_OPAC_GRAY, 0, 0.0, c, sb};
+  jb_scattering scat{JB_SCAT_GRAY, 0, 1.0e3, 1.0};
+  jb_context *ctx = nullptr;
+  JB_OK(jb_initialize(&p, &eos, &opac, &scat, device, &ctx));
+
+  // ---- mesh: blocks [b0, b1) belong to this rank; nothing else is resident
+  const int ng = 2;
+  const int b0 = (int)((long long)nblocks_total * rank / nranks);
+  const int b1 = (int)((long long)nblocks_total * (rank + 1) / nranks);
+  const int nb = b1 - b0;
+  const int ni = nx + 2 * ng;
+  const double blen = 1.0 / nblocks_total, dx = blen / nx;
+  std::vector<int32_t> leaf_map(nblocks_total), owner(nblocks_total), local_index(nblocks_total, -1),
+      gid(nb), level(nb, 0), nbr_lev(6 * nb, 0);
+  std::vector<double> xmin(3 * nb), xmax(3 * nb), dxs(3 * nb);
+  for (int g = 0; g < nblocks_total; ++g) {
+    leaf_map[g] = g;
+    int r = 0;
+    while ((int)((long long)nblocks_total * (r + 1) / nranks) <= g) ++r;
+    owner[g] = r;
+  }
+  for (int l = 0; l < nb; ++l) {
+    const int g = b0 + l;
+    gid[l] = g;
+    local_index[g] = l;
+    xmin[3 * l] = -0.5 + g * blen; xmax[3 * l] = -0.5 + (g + 1) * blen; dxs[3 * l] = dx;
+    for (int d = 1; d < 3; ++d) { xmin[3 * l + d] = -0.5; xmax[3 * l + d] = 0.5; dxs[3 * l + d] = 1.0; }
+  }
+  // fields: one [ni] array per block and field, filled with the initial condition of mcblock.cpp:187-199
+  const char *fields[] = {"rho", "sie", "u", "fleck", "tally", "edelta", "src_ew", "src_num"};
+  std::vector<std::vector<double *>> fptr(8, std::vector<double *>(nb));
+  const double cv = eos.cv, t_hot = 1.0e5, t_cold = 1.0;
+  for (int l = 0; l < nb; ++l) {
+    std::vector<double> rho(ni, 1.0), sie(ni), u(ni);
+    for (int i = 0; i < ni; ++i) {
+      double xcen = xmin[3 * l] + (i - ng + 0.5) * dx;
+      xcen = std::fmin(std::fmax(xcen, -0.5 + 0.5 * dx), 0.5 - 0.5 * dx);  // outflow ghost = edge cell
+      sie[i] = cv * (xcen < 0.0 ? t_hot : t_cold);
+      u[i] = rho[i] * sie[i];
+    }
+    for (int f = 0; f < 8; ++f) fptr[f][l] = dev_alloc<double>(ni);
+    HIP_OK(hipMemcpy(fptr[0][l], rho.data(), ni * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(fptr[1][l], sie.data(), ni * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(fptr[2][l], u.data(), ni * sizeof(double), hipMemcpyHostToDevice));
+  }
+  (void)fields;
+  jb_mesh_view v{};
+  v.ndim = 1; v.ng = ng; v.nblocks = nb; v.nblocks_total = nblocks_total;
+  v.nx[0] = nx; v.nx[1] = 1; v.nx[2] = 1;
+  v.nleaf[0] = nblocks_total; v.nleaf[1] = 1; v.nleaf[2] = 1;
+  v.bc[0] = v.bc[1] = JB_BC_REFLECT;
+  v.bc[2] = v.bc[3] = v.bc[4] = v.bc[5] = JB_BC_PERIODIC;
+  v.rank = rank;
+  for (int d = 0; d < 3; ++d) { v.gmin[d] = -0.5; v.gmax[d] = 0.5; }
+  v.leaf_map = leaf_map.data(); v.owner = owner.data(); v.local_index = local_index.data();
+  v.gid = gid.data(); v.owned = nullptr;
+  v.blk_xmin = xmin.data(); v.blk_xmax = xmax.data(); v.blk_dx = dxs.data();
+  v.blk_level = level.data(); v.blk_nbr_lev = nbr_lev.data();
+  v.rho = fptr[0].data(); v.sie = fptr[1].data(); v.u = fptr[2].data(); v.fleck = fptr[3].data();
+  v.tally = fptr[4].data(); v.edelta = fptr[5].data(); v.src_ew = fptr[6].data(); v.src_num = fptr[7].data();
+  jb_mesh *mesh = nullptr;
+  JB_OK(jb_mesh_create(ctx, &v, &mesh));
+
+  // ---- swarm: one pool per rank, room for every photon of the problem (they may all come here)
+  jb_swarm_view sw{};
+  sw.capacity = nparticles + nparticles / 4 + 4096;
+  sw.x = dev_alloc<double>(sw.capacity); sw.y = dev_alloc<double>(sw.capacity); sw.z = dev_alloc<double>(sw.capacity);
+  sw.vx = dev_alloc<double>(sw.capacity); sw.vy = dev_alloc<double>(sw.capacity); sw.vz = dev_alloc<double>(sw.capacity);
+  sw.t = dev_alloc<double>(sw.capacity); sw.w = dev_alloc<double>(sw.capacity); sw.e = dev_alloc<double>(sw.capacity);
+  sw.ip = dev_alloc<int32_t>(sw.capacity); sw.jp = dev_alloc<int32_t>(sw.capacity); sw.kp = dev_alloc<int32_t>(sw.capacity);
+  sw.blk = dev_alloc<int32_t>(sw.capacity); sw.status = dev_alloc<int32_t>(sw.capacity);
+  sw.id = dev_alloc<uint64_t>(sw.capacity); sw.rng = dev_alloc<uint64_t>(sw.capacity);
+  int32_t *prefix = dev_alloc<int32_t>((size_t)nb * nx);
+
+  // ---- InitializeRadiation (jaybenne.cpp:570-578): thermal source block by block; stream ids
+  //      are global creation indices, so every rank must know every block's count
+  std::vector<int32_t> nper(nb);
+  JB_OK(jb_update_derived_transport_fields(ctx, mesh, p.dt));
+  JB_OK(jb_source_photons_count(ctx, mesh, JB_SOURCE_THERMAL, 0.0, 1, 0u, nper.data(), prefix));
+  std::vector<long long> counts(nblocks_total, 0), all_counts(nblocks_total, 0);
+  for (int l = 0; l < nb; ++l) counts[b0 + l] = nper[l];
+  MPI_Allreduce(counts.data(), all_counts.data(), nblocks_total, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+  std::vector<int64_t> slot(nb);
+  std::vector<uint64_t> idb(nb);
+  long long run = 0, mine = 0;
+  for (int g = 0; g < nblocks_total; ++g) {
+    if (g >= b0 && g < b1) { idb[g - b0] = (uint64_t)run; slot[g - b0] = mine; mine += all_counts[g]; }
+    run += all_counts[g];
+  }
+  const long long n_global0 = run;
+  JB_OK(jb_source_photons_fill(ctx, mesh, &sw, JB_SOURCE_THERMAL, 0.0, 0.0, nper.data(), prefix, slot.data(), idb.data()));
+  sw.n = mine;
+
+  // total weight (host sum of this rank's photons), reduced over ranks
+  auto total_weight = [&]() {
+    std::vector<double> w((size_t)sw.n);
+    std::vector<int32_t> st((size_t)sw.n);
+    if (sw.n) {
+      HIP_OK(hipMemcpy(w.data(), sw.w, sw.n * sizeof(double), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(st.data(), sw.status, sw.n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    double s = 0.0;
+    for (long long i = 0; i < sw.n; ++i) if (st[i] == JB_ST_ACTIVE) s += w[i];
+    double g = 0.0;
+    MPI_Allreduce(&s, &g, 1, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+    return g;
+  };
+  const double e0 = total_weight();
+
+  // ---- cycles
+  int64_t *rec_dev = dev_alloc<int64_t>((size_t)sw.capacity / 4 * JB_RECORD_WORDS + JB_RECORD_WORDS);
+  const int64_t rec_cap = sw.capacity / 4;
+  std::vector<int64_t> send_counts(nranks), recv_counts(nranks);
+  std::vector<int> sc(nranks), sd(nranks), rc(nranks), rd(nranks);
+  long long handed_total = 0, iterations_total = 0;
+  bool ok = true;
+  double time = 0.0;
+  for (int cyc = 0; cyc < cycles; ++cyc) {
+    JB_OK(jb_update_derived_transport_fields(ctx, mesh, p.dt));
+    JB_OK(jb_zero_energy_tally(ctx, mesh));
+    int64_t first = 0;
+    for (int it = 0; it < p.max_transport_iterations; ++it) {
+      const int64_t last = sw.n;
+      JB_OK(jb_transport_photons(ctx, mesh, &sw, time, p.dt, first, last, /*fuse_census_tally=*/1));
+      // MeshSend: records grouped by destination rank, counts on the host
+      JB_OK(jb_pack_outgoing(ctx, mesh, &sw, first, last, nranks, rec_dev, rec_cap, send_counts.data()));
+      MPI_Alltoall(send_counts.data(), 1, MPI_INT64_T, recv_counts.data(), 1, MPI_INT64_T, MPI_COMM_WORLD);
+      long long nsend = 0, nrecv = 0;
+      for (int r = 0; r < nranks; ++r) {
+        sd[r] = (int)(nsend * JB_RECORD_WORDS); sc[r] = (int)(send_counts[r] * JB_RECORD_WORDS);
+        rd[r] = (int)(nrecv * JB_RECORD_WORDS); rc[r] = (int)(recv_counts[r] * JB_RECORD_WORDS);
+        nsend += send_counts[r]; nrecv += recv_counts[r];
+      }
+      // completion test of the sublist (jaybenne.cpp:130-131): did anything move anywhere?
+      long long moved = 0;
+      MPI_Allreduce(&nsend, &moved, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+      ++iterations_total;
+      if (moved == 0) break;
+      handed_total += nsend;
+      std::vector<int64_t> sbuf((size_t)nsend * JB_RECORD_WORDS + 1), rbuf((size_t)nrecv * JB_RECORD_WORDS + 1);
+      if (nsend) HIP_OK(hipMemcpy(sbuf.data(), rec_dev, nsend * JB_RECORD_WORDS * sizeof(int64_t), hipMemcpyDeviceToHost));
+      MPI_Alltoallv(sbuf.data(), sc.data(), sd.data(), MPI_INT64_T, rbuf.data(), rc.data(), rd.data(),
+                    MPI_INT64_T, MPI_COMM_WORLD);
+      // MeshReceive: append the arrivals; the next transport pass covers only them
+      if (sw.n + nrecv > sw.capacity) JB_OK(jb_remove_marked_particles(ctx, &sw));  // close the holes
+      first = sw.n;
+      if (nrecv) {
+        HIP_OK(hipMemcpy(rec_dev, rbuf.data(), nrecv * JB_RECORD_WORDS * sizeof(int64_t), hipMemcpyHostToDevice));
+        JB_OK(jb_unpack_incoming(ctx, mesh, &sw, rec_dev, nrecv));
+      }
+    }
+    JB_OK(jb_remove_marked_particles(ctx, &sw));
+    time += p.dt;
+    // checks
+    int64_t unfinished = 0;
+    JB_OK(jb_check_completion(ctx, &sw, time, &unfinished));
+    long long n_local = sw.n, n_global = 0, unf = unfinished, unf_g = 0;
+    MPI_Allreduce(&n_local, &n_global, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+    MPI_Allreduce(&unf, &unf_g, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+    double tally_local = 0.0, tally_global = 0.0;
+    std::vector<double> tl(ni);
+    for (int l = 0; l < nb; ++l) {
+      HIP_OK(hipMemcpy(tl.data(), fptr[4][l], ni * sizeof(double), hipMemcpyDeviceToHost));
+      for (int i = ng; i < ng + nx; ++i) tally_local += tl[i] * dx;
+    }
+    MPI_Allreduce(&tally_local, &tally_global, 1, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+    const double e = total_weight();
+    const bool cyc_ok = n_global == n_global0 && unf_g == 0 && std::fabs(e - e0) <= 1e-12 * e0 &&
+                        std::fabs(tally_global - e0) <= 1e-10 * e0;
+    ok = ok && cyc_ok;
+    if (rank == 0)
+      std::printf("cycle %d: photons %lld (start %lld), unfinished %lld, weight %.15e (start %.15e), "
+                  "tally integral %.15e  %s\n", cyc + 1, n_global, n_global0, unf_g, e, e0, tally_global,
+                  cyc_ok ? "ok" : "MISMATCH");
+  }
+  jb_transport_stats st{};
+  JB_OK(jb_get_transport_stats(ctx, &st, 0));
+  long long ev = st.n_events, ev_g = 0, handed_g = 0;
+  MPI_Allreduce(&ev, &ev_g, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+  MPI_Allreduce(&handed_total, &handed_g, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+  if (rank == 0)
+    std::printf("%d rank(s), %d blocks: %lld events, %lld photons handed between ranks in %lld transport "
+                "iterations  -> %s\n", nranks, nblocks_total, ev_g, handed_g, iterations_total,
+                ok && (nranks == 1 || handed_g > 0) ? "HANDOFF OK" : "HANDOFF FAILED");
+  const int rcode = ok && (nranks == 1 || handed_g > 0) ? 0 : 1;
+  jb_mesh_destroy(mesh);
+  jb_finalize(ctx);
+  MPI_Finalize();
+  return rcode;
+}

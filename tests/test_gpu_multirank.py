@@ -192,3 +192,23 @@ def test_two_ranks_with_material_feedback(gpu_device, tmp_path):
         sl = mesh.interior()
         np.testing.assert_allclose(p["fleck"][sl], O.fields["fleck"][p["gids"]][sl], rtol=1e-12)
         np.testing.assert_allclose(p["tally"][sl], O.fields["tally"][p["gids"]][sl], rtol=1e-11)
+
+
+def test_c_level_mpi_handoff(gpu_device):
+    """examples/handoff_mpi.cpp: the hand-off driven from C++ over MPI (no Python, no PyTorch in
+    the rank processes): three ranks that own disjoint runs of blocks and keep no halo copies,
+    so every block-boundary crossing between ranks goes through jb_pack_outgoing ->
+    MPI_Alltoallv -> jb_unpack_incoming; photon count, total weight, census time and the tally
+    integral are checked by the program every cycle."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec) or not os.path.exists("/opt/conda/lib/libmpi.so"):
+        pytest.skip("no MPI installation in this image")
+    build = subprocess.run(["make", "-C", os.path.join(root, "examples"), "mpi"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stdout + build.stderr
+    run = subprocess.run([mpiexec, "-n", "3", os.path.join(root, "examples", "handoff_mpi"), "16", "8",
+                          "200000", "3"], capture_output=True, text=True, timeout=240)
+    assert run.returncode == 0 and "HANDOFF OK" in run.stdout, run.stdout + run.stderr
+    assert run.stdout.count(" ok") == 3
