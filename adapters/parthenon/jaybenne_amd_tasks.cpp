@@ -1,0 +1,465 @@
+// jaybenne_amd_tasks.cpp -- the reference's tasks (src/jaybenne/jaybenne.hpp:59-76) as calls into
+// libjaybenne_amd.so.  SOURCE ONLY: written against Parthenon's public API as the reference uses
+// it (call sites cited per function); never compiled in this repository -- Parthenon, Kokkos and
+// singularity are absent from its image.  The compiled, tested twin of this layer is
+// include/jaybenne_amd.hpp + examples/mcblock_amd.cpp (stand-ins for MeshData / StateDescriptor)
+// and examples/handoff_mpi.cpp (the MPI hand-off).
+#include "jaybenne_amd_tasks.hpp"
+
+#include <mpi.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <numeric>
+
+namespace jaybenne {
+
+namespace fj = field::jaybenne;
+namespace fjh = field::jaybenne::host;
+namespace ph = particle::photons;
+
+#define JB_REQUIRE(call) PARTHENON_REQUIRE((call) >= 0, jb_last_error())
+
+static TaskStatus Status(jb_status s) {
+  PARTHENON_REQUIRE(s >= 0, jb_last_error());
+  return s == JB_ITERATE ? TaskStatus::iterate
+                         : (s == JB_INCOMPLETE ? TaskStatus::incomplete : TaskStatus::complete);
+}
+
+AmdState::~AmdState() {
+  if (mesh) jb_mesh_destroy(mesh);
+  if (ctx) jb_finalize(ctx);
+}
+
+static AmdState &State(Mesh *pm) {
+  return *pm->packages.Get("jaybenne")->Param<std::shared_ptr<AmdState>>("amd_state");
+}
+
+//----------------------------------------------------------------------------------------
+// jaybenne::Initialize -- jaybenne.cpp:158-266: same keys, defaults, requirements, fields and
+// swarm registration; the random pool of jaybenne.cpp:192-197 is replaced by one stream per
+// photon inside the library (keyed by the same, unadjusted, seed).
+std::shared_ptr<StateDescriptor> Initialize(ParameterInput *pin, Opacity &opacity,
+                                            Scattering &scattering, EOS &eos) {
+  auto pkg = std::make_shared<StateDescriptor>("jaybenne");
+  jb_params p{};
+  p.num_particles = pin->GetInteger("jaybenne", "num_particles");
+  p.dt = pin->GetOrAddReal("jaybenne", "dt", std::numeric_limits<Real>::max());
+  p.min_swarm_occupancy = pin->GetOrAddReal("jaybenne", "min_swarm_occupancy", 0.0);
+  PARTHENON_REQUIRE(p.min_swarm_occupancy >= 0.0 && p.min_swarm_occupancy < 1.0,
+                    "Minimum allowable swarm occupancy must be >= 0 and less than 1");
+  p.numin = pin->GetOrAddReal("jaybenne", "numin", std::numeric_limits<Real>::min());
+  p.numax = pin->GetOrAddReal("jaybenne", "numax", std::numeric_limits<Real>::max());
+  p.unique_rank_seeds = pin->GetOrAddBoolean("jaybenne", "unique_rank_seeds", true);
+  p.seed = pin->GetOrAddInteger("jaybenne", "seed", 123);
+  p.max_transport_iterations = pin->GetOrAddInteger("jaybenne", "max_transport_iterations", 10000);
+  p.use_ddmc = pin->GetOrAddBoolean("jaybenne", "use_ddmc", false);
+  p.tau_ddmc = pin->GetOrAddReal("jaybenne", "tau_ddmc", 5.0);
+  const std::string strategy = pin->GetOrAddString("jaybenne", "source_strategy", "uniform");
+  if (strategy == "uniform") {
+    p.source_strategy = JB_STRATEGY_UNIFORM;
+  } else if (strategy == "energy") {
+    p.source_strategy = JB_STRATEGY_ENERGY;
+  } else {
+    PARTHENON_FAIL("Only uniform or energy source strategies supported!");
+  }
+  p.do_emission = pin->GetOrAddBoolean("jaybenne", "do_emission", true);
+  p.do_feedback = pin->GetOrAddBoolean("jaybenne", "do_feedback", true);
+  p.rank = Globals::my_rank;
+
+  // the host's model objects as tagged POD (jaybenne_amd.h): singularity IdealGas / Gray / GrayS
+  auto units = opacity.GetRuntimePhysicalConstants();
+  jb_eos e{JB_EOS_IDEAL_GAS, 0, eos.GruneisenParamFromDensityTemperature(1.0, 1.0),
+           eos.SpecificHeatFromDensityTemperature(1.0, 1.0)};
+  jb_opacity o{JB_OPAC_GRAY, 0, opacity.AbsorptionCoefficient(1.0, 1.0, 1.0), units.c, units.sb};
+  jb_scattering s{JB_SCAT_GRAY, 0, scattering.TotalScatteringCoefficient(1.0, 1.0, 1.0), 1.0};
+
+  auto st = std::make_shared<AmdState>();
+  int device = 0;
+  (void)hipGetDevice(&device);   // the device Kokkos::initialize selected for this rank
+  JB_REQUIRE(jb_initialize(&p, &e, &o, &s, device, &st->ctx));
+  pkg->AddParam<>("amd_state", st);
+  pkg->AddParam<>("num_particles", (int)p.num_particles);
+  pkg->AddParam<>("dt", p.dt);
+  pkg->AddParam<>("min_swarm_occupancy", p.min_swarm_occupancy);
+  pkg->AddParam<>("numin", p.numin);
+  pkg->AddParam<>("numax", p.numax);
+  pkg->AddParam<>("speed_of_light", units.c);
+  pkg->AddParam<>("stefan_boltzmann", units.sb);
+  pkg->AddParam<>("unique_rank_seeds", (bool)p.unique_rank_seeds);
+  pkg->AddParam<>("seed", jb_param_seed(st->ctx));
+  pkg->AddParam<>("max_transport_iterations", (int)p.max_transport_iterations);
+  pkg->AddParam<>("use_ddmc", (bool)p.use_ddmc);
+  pkg->AddParam<>("tau_ddmc", p.tau_ddmc);
+  pkg->AddParam<>("do_emission", (bool)p.do_emission);
+  pkg->AddParam<>("do_feedback", (bool)p.do_feedback);
+  pkg->AddParam<>("eos_d", eos.GetOnDevice());
+  pkg->AddParam<>("opacity_d", opacity.GetOnDevice());
+  pkg->AddParam<>("scattering_d", scattering.GetOnDevice());
+
+  // swarm + fields exactly as jaybenne.cpp:236-260 (the swarm is an output view of the pool)
+  Metadata swarm_metadata({Metadata::Provides, Metadata::None});
+  pkg->AddSwarm(photons_swarm_name, swarm_metadata);
+  Metadata real_swarmvalue_metadata({Metadata::Real});
+  pkg->AddSwarmValue(ph::weight::name(), photons_swarm_name, real_swarmvalue_metadata);
+  pkg->AddSwarmValue(ph::energy::name(), photons_swarm_name, real_swarmvalue_metadata);
+  pkg->AddSwarmValue(ph::time::name(), photons_swarm_name, real_swarmvalue_metadata);
+  Metadata vec(std::vector<MetadataFlag>{Metadata::Real}, std::vector<int>{3});
+  pkg->AddSwarmValue(ph::v::name(), photons_swarm_name, vec);
+  Metadata ivec(std::vector<MetadataFlag>{Metadata::Integer}, std::vector<int>{3});
+  pkg->AddSwarmValue(ph::ijk::name(), photons_swarm_name, ivec);
+  Metadata m({Metadata::Cell, Metadata::Independent});
+  pkg->AddField(fj::energy_tally::name(), m);
+  pkg->AddField(fj::fleck_factor::name(), m);
+  Metadata m_onecopy({Metadata::Cell, Metadata::OneCopy});
+  pkg->AddField(fj::source_ew_per_cell::name(), m_onecopy);
+  pkg->AddField(fj::source_num_per_cell::name(), m_onecopy);
+  pkg->AddField(fj::energy_delta::name(), m_onecopy);
+  Metadata m_face({Metadata::Face, Metadata::Derived, Metadata::FillGhost});
+  pkg->AddField(fj::ddmc_face_prob::name(), m_face);
+  pkg->EstimateTimestepMesh = EstimateTimestepMesh;
+  return pkg;
+}
+
+//----------------------------------------------------------------------------------------
+// MeshData -> jb_mesh_view.  Rebuilt when the block list changes.
+static void EnsureMeshView(MeshData<Real> *md) {
+  auto pm = md->GetParentPointer();
+  AmdState &st = State(pm);
+  if (st.mesh && st.mesh_generation == pm->nbtotal) return;
+  if (st.mesh) jb_mesh_destroy(st.mesh);
+  static auto desc =
+      MakePackDescriptor<fjh::density, fjh::sie, fjh::update_energy, fj::fleck_factor,
+                         fj::energy_tally, fj::energy_delta, fj::source_ew_per_cell,
+                         fj::source_num_per_cell, fj::ddmc_face_prob>(pm->resolved_packages.get());
+  auto vmesh = desc.GetPack(md);
+  const int nb = md->NumBlocks();
+  const int ndim = pm->ndim;
+  const auto ib = md->GetBoundsI(IndexDomain::interior);
+  const auto jb = md->GetBoundsJ(IndexDomain::interior);
+  const auto kb = md->GetBoundsK(IndexDomain::interior);
+
+  jb_mesh_view v{};
+  v.ndim = ndim;
+  v.ng = Globals::nghost;
+  v.nblocks = nb;
+  v.nblocks_total = pm->nbtotal;
+  v.rank = Globals::my_rank;
+  v.nx[0] = ib.e - ib.s + 1; v.nx[1] = jb.e - jb.s + 1; v.nx[2] = kb.e - kb.s + 1;
+  const auto &ms = pm->mesh_size;
+  for (int d = 0; d < 3; ++d) { v.gmin[d] = ms.xmin(static_cast<CoordinateDirection>(d + 1));
+                                v.gmax[d] = ms.xmax(static_cast<CoordinateDirection>(d + 1)); }
+  // <parthenon/swarm> boundaries: the names registered by mcblock::ProblemModifier (mcblock.cpp:271-282)
+  auto bc_of = [&](const std::string &name) {
+    return name == "jaybenne_reflecting" ? JB_BC_REFLECT : (name == "periodic" ? JB_BC_PERIODIC : JB_BC_OUTFLOW);
+  };
+  for (int f = 0; f < 6; ++f) v.bc[f] = bc_of(pm->mesh_swarm_bc_names[f]);   // ix1, ox1, ix2, ...
+
+  // leaves of the block tree: every global block with its logical location, level and rank
+  const int maxlev = pm->GetCurrentLevel() - pm->GetRootLevel();
+  const auto nrb = pm->nrbx;                       // root-grid blocks per dimension
+  std::vector<int32_t> owner(pm->nbtotal), local_index(pm->nbtotal, -1), gid(nb), level(nb),
+      nbr_lev(6 * nb);
+  for (int d = 0; d < 3; ++d) v.nleaf[d] = d < ndim ? nrb[d] << maxlev : 1;
+  std::vector<int32_t> leaf_map((size_t)v.nleaf[0] * v.nleaf[1] * v.nleaf[2], 0);
+  const auto &locs = pm->GetLocList();             // logical location of every global block
+  const auto &ranks = pm->GetRankList();
+  for (int g = 0; g < pm->nbtotal; ++g) {
+    owner[g] = ranks[g];
+    const int lev = locs[g].level() - pm->GetRootLevel();
+    const int span = 1 << (maxlev - lev);
+    const int l0[3] = {(int)locs[g].lx1() * span, ndim > 1 ? (int)locs[g].lx2() * span : 0,
+                       ndim > 2 ? (int)locs[g].lx3() * span : 0};
+    for (int k = 0; k < (ndim > 2 ? span : 1); ++k)
+      for (int j = 0; j < (ndim > 1 ? span : 1); ++j)
+        for (int i = 0; i < span; ++i)
+          leaf_map[((size_t)(l0[2] + k) * v.nleaf[1] + (l0[1] + j)) * v.nleaf[0] + (l0[0] + i)] = g;
+  }
+  std::vector<double> xmin(3 * nb), xmax(3 * nb), dxs(3 * nb);
+  std::vector<double *> tab[11];
+  for (auto &t : tab) t.resize(nb);
+  auto vmesh_h = vmesh;   // (device pack: element addresses are taken on the host, not dereferenced)
+  for (int b = 0; b < nb; ++b) {
+    auto pmb = md->GetBlockData(b)->GetBlockPointer();
+    gid[b] = pmb->gid;
+    local_index[pmb->gid] = b;
+    level[b] = pmb->loc.level() - pm->GetRootLevel();
+    const auto &coords = pmb->coords;
+    for (int d = 0; d < 3; ++d) {
+      const auto dir = static_cast<CoordinateDirection>(d + 1);
+      const auto &bs = pmb->block_size;
+      xmin[3 * b + d] = bs.xmin(dir); xmax[3 * b + d] = bs.xmax(dir);
+      dxs[3 * b + d] = coords.Dxc(dir);   // (inactive dimensions: the full extent, one cell)
+    }
+    // neighbour level per face; own level at a physical boundary (jaybenne.cpp:341-351)
+    const int off[6][3] = {{0, 0, -1}, {0, 0, 1}, {0, -1, 0}, {0, 1, 0}, {-1, 0, 0}, {1, 0, 0}};
+    for (int f = 0; f < 6; ++f)
+      nbr_lev[6 * b + f] = vmesh.IsPhysicalBoundary(b, off[f][0], off[f][1], off[f][2])
+                               ? level[b]
+                               : vmesh.GetLevel(b, off[f][0], off[f][1], off[f][2]) - pm->GetRootLevel();
+    tab[0][b] = &vmesh_h(b, fjh::density(), 0, 0, 0);
+    tab[1][b] = &vmesh_h(b, fjh::sie(), 0, 0, 0);
+    tab[2][b] = &vmesh_h(b, fjh::update_energy(), 0, 0, 0);
+    tab[3][b] = &vmesh_h(b, fj::fleck_factor(), 0, 0, 0);
+    tab[4][b] = &vmesh_h(b, fj::energy_tally(), 0, 0, 0);
+    tab[5][b] = &vmesh_h(b, fj::energy_delta(), 0, 0, 0);
+    tab[6][b] = &vmesh_h(b, fj::source_ew_per_cell(), 0, 0, 0);
+    tab[7][b] = &vmesh_h(b, fj::source_num_per_cell(), 0, 0, 0);
+    tab[8][b] = &vmesh_h(b, TopologicalElement::F1, fj::ddmc_face_prob(), 0, 0, 0);
+    tab[9][b] = &vmesh_h(b, TopologicalElement::F2, fj::ddmc_face_prob(), 0, 0, 0);
+    tab[10][b] = &vmesh_h(b, TopologicalElement::F3, fj::ddmc_face_prob(), 0, 0, 0);
+  }
+  v.leaf_map = leaf_map.data(); v.owner = owner.data(); v.local_index = local_index.data();
+  v.gid = gid.data(); v.owned = nullptr;     // no halo copies: a rank holds the blocks it owns
+  v.blk_xmin = xmin.data(); v.blk_xmax = xmax.data(); v.blk_dx = dxs.data();
+  v.blk_level = level.data(); v.blk_nbr_lev = nbr_lev.data();
+  v.rho = tab[0].data(); v.sie = tab[1].data(); v.u = tab[2].data(); v.fleck = tab[3].data();
+  v.tally = tab[4].data(); v.edelta = tab[5].data(); v.src_ew = tab[6].data(); v.src_num = tab[7].data();
+  v.P1 = tab[8].data(); v.P2 = tab[9].data(); v.P3 = tab[10].data();
+  JB_REQUIRE(jb_mesh_create(st.ctx, &v, &st.mesh));
+  st.mesh_generation = pm->nbtotal;
+  if (st.prefix.size() < (size_t)nb * v.nx[0] * v.nx[1] * v.nx[2])
+    st.prefix = ParArray1D<int>("jb prefix", (size_t)nb * v.nx[0] * v.nx[1] * v.nx[2]);
+}
+
+// pool growth: the role of Swarm::AddEmptyParticles (sourcing.cpp:123-131)
+static void Reserve(AmdState &st, std::int64_t nslots) {
+  if (nslots <= st.sw.capacity) return;
+  const std::int64_t cap = 2 * nslots;
+  auto grow = [&](auto &view, const char *name) {
+    using V = std::decay_t<decltype(view)>;
+    V bigger(name, cap);
+    if (st.sw.n > 0)
+      Kokkos::deep_copy(Kokkos::subview(bigger, std::make_pair((std::int64_t)0, st.sw.n)),
+                        Kokkos::subview(view, std::make_pair((std::int64_t)0, st.sw.n)));
+    view = bigger;
+  };
+  if (st.pool_f64.empty()) { st.pool_f64.resize(9); st.pool_i32.resize(5); }
+  for (auto &a : st.pool_f64) grow(a, "jb pool f64");
+  for (auto &a : st.pool_i32) grow(a, "jb pool i32");
+  grow(st.pool_id, "jb pool id");
+  grow(st.pool_rng, "jb pool rng");
+  double **f[9] = {&st.sw.x, &st.sw.y, &st.sw.z, &st.sw.vx, &st.sw.vy, &st.sw.vz, &st.sw.t, &st.sw.w, &st.sw.e};
+  for (int q = 0; q < 9; ++q) *f[q] = st.pool_f64[q].data();
+  int32_t **ii[5] = {&st.sw.ip, &st.sw.jp, &st.sw.kp, &st.sw.blk, &st.sw.status};
+  for (int q = 0; q < 5; ++q) *ii[q] = st.pool_i32[q].data();
+  st.sw.id = st.pool_id.data();
+  st.sw.rng = st.pool_rng.data();
+  st.sw.capacity = cap;
+}
+
+//----------------------------------------------------------------------------------------
+TaskStatus UpdateDerivedTransportFields(MeshData<Real> *md, const Real dt) {   // jaybenne.cpp:285-492
+  EnsureMeshView(md);
+  AmdState &st = State(md->GetParentPointer());
+  return Status(jb_update_derived_transport_fields(st.ctx, st.mesh, dt));
+}
+
+// sourcing.cpp:25-208.  T = MeshData<Real> (cycle loop) or MeshBlockData<Real> (initialisation,
+// one call per block: `nblocks` of sourcing.cpp:68-69 is then 1).
+template <typename T, SourceType ST>
+TaskStatus SourcePhotons(T *md, const Real t_start, const Real dt) {
+  auto pm = md->GetParentPointer();
+  AmdState &st = State(pm);
+  auto &jbn = pm->packages.Get("jaybenne");
+  if constexpr (ST == SourceType::emission) {
+    if (!jbn->template Param<bool>("do_emission")) return TaskStatus::complete;   // sourcing.cpp:41-43
+  }
+  constexpr bool per_block = std::is_same_v<T, MeshBlockData<Real>>;
+  auto *mesh_md = pm->mesh_data.Get().get();
+  EnsureMeshView(mesh_md);
+  const int nb = mesh_md->NumBlocks();
+  std::vector<int32_t> nper(nb);
+  const int src = ST == SourceType::thermal ? JB_SOURCE_THERMAL : JB_SOURCE_EMISSION;
+  JB_REQUIRE(jb_source_photons_count(st.ctx, st.mesh, src, dt, per_block ? 1 : nb, st.epoch++,
+                                     nper.data(), st.prefix.data()));
+  if constexpr (per_block) {   // only the calling block sources in this call
+    const int mine = md->GetBlockPointer()->lid;
+    for (int b = 0; b < nb; ++b)
+      if (b != mine) nper[b] = 0;
+  }
+  // stream ids are global creation indices: every rank learns every block's count
+  std::vector<long long> counts(pm->nbtotal, 0), all(pm->nbtotal, 0);
+  for (int b = 0; b < nb; ++b) counts[mesh_md->GetBlockData(b)->GetBlockPointer()->gid] = nper[b];
+  MPI_Allreduce(counts.data(), all.data(), pm->nbtotal, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+  std::vector<std::int64_t> slot(nb);
+  std::vector<std::uint64_t> idb(nb);
+  std::vector<long long> excl(pm->nbtotal);
+  std::exclusive_scan(all.begin(), all.end(), excl.begin(), 0ll);
+  std::int64_t tot = 0;
+  for (int b = 0; b < nb; ++b) {
+    slot[b] = st.sw.n + tot;
+    idb[b] = st.next_id + (std::uint64_t)excl[mesh_md->GetBlockData(b)->GetBlockPointer()->gid];
+    tot += nper[b];
+  }
+  Reserve(st, st.sw.n + tot);
+  JB_REQUIRE(jb_source_photons_fill(st.ctx, st.mesh, &st.sw, src, t_start, dt, nper.data(),
+                                    st.prefix.data(), slot.data(), idb.data()));
+  st.sw.n += tot;
+  st.next_id += (std::uint64_t)std::accumulate(all.begin(), all.end(), 0ll);
+  return TaskStatus::complete;
+}
+template TaskStatus SourcePhotons<MeshBlockData<Real>, SourceType::thermal>(MeshBlockData<Real> *, const Real, const Real);
+template TaskStatus SourcePhotons<MeshBlockData<Real>, SourceType::emission>(MeshBlockData<Real> *, const Real, const Real);
+template TaskStatus SourcePhotons<MeshData<Real>, SourceType::thermal>(MeshData<Real> *, const Real, const Real);
+template TaskStatus SourcePhotons<MeshData<Real>, SourceType::emission>(MeshData<Real> *, const Real, const Real);
+
+// transport.cpp:28-181 / transport_ddmc.cpp:28-237.  `first` of the iterate sublist: the photons
+// that arrived in the last MeshReceive (everything on the first pass).
+static std::int64_t &FirstUntracked(AmdState &st) {
+  static std::int64_t first = 0;
+  return first;
+}
+TaskStatus TransportPhotons(MeshData<Real> *md, const Real t_start, const Real dt) {
+  AmdState &st = State(md->GetParentPointer());
+  return Status(jb_transport_photons(st.ctx, st.mesh, &st.sw, t_start, dt, FirstUntracked(st), st.sw.n, 0));
+}
+TaskStatus TransportPhotons_DDMC(MeshData<Real> *md, const Real t_start, const Real dt) {
+  AmdState &st = State(md->GetParentPointer());
+  return Status(jb_transport_photons_ddmc(st.ctx, st.mesh, &st.sw, t_start, dt, FirstUntracked(st), st.sw.n, 0));
+}
+
+// MeshResetCommunication / MeshSend / MeshReceive -- jaybenne.cpp:26-61 -- as one task: records
+// per destination rank, counts by all-to-all, payload by all-to-all-v (device pointers: needs a
+// GPU-aware MPI; otherwise stage through host buffers as examples/handoff_mpi.cpp does).
+TaskStatus MeshSendReceive(MeshData<Real> *md) {
+  AmdState &st = State(md->GetParentPointer());
+  const int nranks = Globals::nranks;
+  std::vector<std::int64_t> send(nranks), recv(nranks);
+  const std::int64_t first = FirstUntracked(st), last = st.sw.n;
+  if ((std::int64_t)st.records.size() < (last - first + 1) * JB_RECORD_WORDS)
+    st.records = ParArray1D<std::int64_t>("jb records", (last - first + 1) * JB_RECORD_WORDS);
+  JB_REQUIRE(jb_pack_outgoing(st.ctx, st.mesh, &st.sw, first, last, nranks, st.records.data(),
+                              st.records.size() / JB_RECORD_WORDS, send.data()));
+  MPI_Alltoall(send.data(), 1, MPI_INT64_T, recv.data(), 1, MPI_INT64_T, MPI_COMM_WORLD);
+  std::vector<int> sc(nranks), sd(nranks), rc(nranks), rd(nranks);
+  std::int64_t ns = 0, nr = 0;
+  for (int r = 0; r < nranks; ++r) {
+    sd[r] = ns * JB_RECORD_WORDS; sc[r] = send[r] * JB_RECORD_WORDS; ns += send[r];
+    rd[r] = nr * JB_RECORD_WORDS; rc[r] = recv[r] * JB_RECORD_WORDS; nr += recv[r];
+  }
+  ParArray1D<std::int64_t> inbox("jb inbox", std::max<std::int64_t>(nr, 1) * JB_RECORD_WORDS);
+  MPI_Alltoallv(st.records.data(), sc.data(), sd.data(), MPI_INT64_T, inbox.data(), rc.data(),
+                rd.data(), MPI_INT64_T, MPI_COMM_WORLD);
+  if (st.sw.n + nr > st.sw.capacity) JB_REQUIRE(jb_remove_marked_particles(st.ctx, &st.sw));
+  Reserve(st, st.sw.n + nr);
+  FirstUntracked(st) = st.sw.n;                      // the next transport pass covers the arrivals
+  JB_REQUIRE(jb_unpack_incoming(st.ctx, st.mesh, &st.sw, inbox.data(), nr));
+  return TaskStatus::complete;
+}
+
+TaskStatus SampleDDMCBlockFace(MeshData<Real> *md) {   // sample_ddmc_bface.cpp:81-427
+  AmdState &st = State(md->GetParentPointer());
+  return Status(jb_sample_ddmc_block_face(st.ctx, st.mesh, &st.sw, FirstUntracked(st), st.sw.n));
+}
+
+TaskStatus CheckCompletion(MeshData<Real> *md, const Real t_end) {   // transport.cpp:187-216
+  AmdState &st = State(md->GetParentPointer());
+  std::int64_t unfinished = 0;
+  const jb_status s = jb_check_completion(st.ctx, &st.sw, t_end, &unfinished);
+  if (s == JB_COMPLETE) FirstUntracked(st) = 0;       // the sublist is done: next cycle starts over
+  return Status(s);
+}
+
+template <typename T>
+TaskStatus EvaluateRadiationEnergy(T *md) {   // jaybenne.cpp:514-564
+  auto pm = md->GetParentPointer();
+  EnsureMeshView(pm->mesh_data.Get().get());
+  AmdState &st = State(pm);
+  return Status(jb_evaluate_radiation_energy(st.ctx, st.mesh, &st.sw));
+}
+template TaskStatus EvaluateRadiationEnergy<MeshBlockData<Real>>(MeshBlockData<Real> *);
+template TaskStatus EvaluateRadiationEnergy<MeshData<Real>>(MeshData<Real> *);
+
+TaskStatus UpdateFluid(MeshData<Real> *md) {   // jaybenne.cpp:583-615
+  AmdState &st = State(md->GetParentPointer());
+  JB_REQUIRE(jb_remove_marked_particles(st.ctx, &st.sw));   // (transport.cpp:176-178, once per cycle)
+  return Status(jb_update_fluid(st.ctx, st.mesh));
+}
+
+TaskStatus DefragParticles(MeshBlock *) { return TaskStatus::complete; }   // jaybenne.cpp:499-509 (unscheduled)
+
+Real EstimateTimestepMesh(MeshData<Real> *md) {   // jaybenne.cpp:271-275
+  return jb_estimate_timestep(State(md->GetParentPointer()).ctx);
+}
+
+void InitializeRadiation(MeshBlockData<Real> *mbd, const bool is_thermal) {   // jaybenne.cpp:570-578
+  if (is_thermal) SourcePhotons<MeshBlockData<Real>, SourceType::thermal>(mbd, 0.0, 0.0);
+  EvaluateRadiationEnergy<MeshBlockData<Real>>(mbd);
+}
+
+//----------------------------------------------------------------------------------------
+// jaybenne::RadiationStep -- jaybenne.cpp:68-151: the same regions, task list and iterate sublist
+// with the same completion semantics; MeshResetCommunication / MeshSend / MeshReceive are one task.
+TaskCollection RadiationStep(Mesh *pmesh, const Real t_start, const Real dt) {
+  auto &jb_pkg = pmesh->packages.Get("jaybenne");
+  const auto &max_transport_iterations = jb_pkg->Param<int>("max_transport_iterations");
+  const bool &use_ddmc = jb_pkg->Param<bool>("use_ddmc");
+  TaskCollection tc;
+  TaskID none(0);
+  const int num_partitions = pmesh->DefaultNumPartitions();
+  PARTHENON_REQUIRE(num_partitions == 1,
+                    "Iterative tasking may not support multiple partitions per rank as of 2024/5/14")
+  auto &reg = tc.AddRegion(num_partitions);
+  for (int i = 0; i < num_partitions; i++) {
+    auto &tl = reg[i];
+    auto &base = pmesh->mesh_data.GetOrAdd("base", i);
+    auto derived = tl.AddTask(none, UpdateDerivedTransportFields, base.get(), dt);
+    auto source = tl.AddTask(derived, SourcePhotons<MeshData<Real>, SourceType::emission>,
+                             base.get(), t_start, dt);
+    // (no ghost exchange of ddmc_face_prob: no kernel reads a ghost face)
+    auto [itl, push] = tl.AddSublist(source, {1, max_transport_iterations});
+    auto transport = use_ddmc ? itl.AddTask(none, TransportPhotons_DDMC, base.get(), t_start, dt)
+                              : itl.AddTask(none, TransportPhotons, base.get(), t_start, dt);
+    auto exchange = itl.AddTask(transport, MeshSendReceive, base.get());
+    auto sample_ddmc_bface = use_ddmc ? itl.AddTask(exchange, SampleDDMCBlockFace, base.get()) : exchange;
+    auto complete = itl.AddTask(TQ::once_per_region | TQ::global_sync | TQ::completion,
+                                sample_ddmc_bface, CheckCompletion, base.get(), t_start + dt);
+    auto eval_rad = tl.AddTask(push, EvaluateRadiationEnergy<MeshData<Real>>, base.get());
+    auto update_fluid = tl.AddTask(eval_rad, UpdateFluid, base.get());
+  }
+  return tc;
+}
+
+//----------------------------------------------------------------------------------------
+// Output view: copy the pool into the registered swarm, block by block (positions, the five
+// variables of jaybenne.cpp:236-245); called before an output that lists `swarms = photons`.
+TaskStatus ExportToParthenonSwarm(MeshData<Real> *md) {
+  auto pm = md->GetParentPointer();
+  AmdState &st = State(pm);
+  const int nb = md->NumBlocks();
+  // particles per block (host histogram of the blk attribute), then one gather kernel per block
+  auto blk_h = Kokkos::create_mirror_view_and_copy(Kokkos::HostSpace(),
+                                                   Kokkos::subview(st.pool_i32[3], std::make_pair((std::int64_t)0, st.sw.n)));
+  std::vector<std::vector<std::int64_t>> members(nb);
+  for (std::int64_t n = 0; n < st.sw.n; ++n) members[blk_h(n)].push_back(n);
+  for (int b = 0; b < nb; ++b) {
+    auto swarm = md->GetSwarmData(b)->Get(photons_swarm_name);
+    swarm->RemoveMarkedParticles();
+    auto ctx_new = swarm->AddEmptyParticles(members[b].size());
+    ParArray1D<std::int64_t> idx("jb members", std::max<size_t>(members[b].size(), 1));
+    auto idx_h = Kokkos::create_mirror_view(idx);
+    for (size_t q = 0; q < members[b].size(); ++q) idx_h(q) = members[b][q];
+    Kokkos::deep_copy(idx, idx_h);
+    auto &x = swarm->Get<Real>(swarm_position::x::name()).Get();
+    auto &y = swarm->Get<Real>(swarm_position::y::name()).Get();
+    auto &z = swarm->Get<Real>(swarm_position::z::name()).Get();
+    auto &w = swarm->Get<Real>(ph::weight::name()).Get();
+    auto &e = swarm->Get<Real>(ph::energy::name()).Get();
+    auto &t = swarm->Get<Real>(ph::time::name()).Get();
+    auto &vel = swarm->Get<Real>(ph::v::name()).Get();
+    const auto sw = st.sw;
+    parthenon::par_for(
+        DEFAULT_LOOP_PATTERN, "jaybenne_amd::ExportToParthenonSwarm", DevExecSpace(), 0,
+        (int)members[b].size() - 1, KOKKOS_LAMBDA(const int q) {
+          const int n = ctx_new.GetNewParticleIndex(q);
+          const std::int64_t s = idx(q);
+          x(n) = sw.x[s]; y(n) = sw.y[s]; z(n) = sw.z[s];
+          w(n) = sw.w[s]; e(n) = sw.e[s]; t(n) = sw.t[s];
+          vel(0, n) = sw.vx[s]; vel(1, n) = sw.vy[s]; vel(2, n) = sw.vz[s];
+        });
+  }
+  return TaskStatus::complete;
+}
+
+}  // namespace jaybenne
