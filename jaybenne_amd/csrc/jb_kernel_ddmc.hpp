@@ -285,13 +285,10 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           if constexpr (TALLY) {  // jaybenne.cpp:547-561
             const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
             if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
-#ifndef JB_EXPERIMENT_NOTALLY
             else atomicAdd(&block_tally(M, lds_blocks, b)[cidx(M, kp, jp, ip)], wgt / dv);
-#endif
           }
         }
       }
-#ifndef JB_EXPERIMENT_NOSTORE   // (timing experiment only: results are wrong without the stores)
       S.blk[n] = b;
       S.t[n] = t;
       S.x[n] = x; S.y[n] = y; S.z[n] = z;
@@ -301,9 +298,6 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
       S.status[n] = status;
       S.rng[n] = rng.s;
-#else
-      S.t[n] = t;
-#endif
       if (status == ST_ACTIVE) ++c_census;
       else if (status == ST_ABSORBED) ++c_abs;
       else if (status == ST_ESCAPED) ++c_esc;

@@ -98,3 +98,50 @@ def test_cpp_mirror_header_is_self_contained():
                  "EvaluateRadiationEnergy", "UpdateFluid", "InitializeRadiation", "RadiationStep",
                  "EstimateTimestepMesh", "Initialize"):
         assert f" {task}(" in text, task
+
+
+def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
+    """The tracking kernels are tuned for three waves per SIMD (512 / 3 -> 168 vector registers,
+    allocated in eights); a change that pushes one of them over the edge silently costs a wave
+    (measured: 90 -> 121 ms on the headline workload).  Compile the device code to assembly and
+    read each hot kernel's register count and scratch use from its kernel descriptor."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "jaybenne_amd", "csrc", "jb_api.hip")
+    flags = None
+    for line in open(os.path.join(ROOT, "jaybenne_amd", "csrc", "Makefile")):
+        if line.startswith("FLAGS"):
+            flags = line.split("?=", 1)[1].replace("\\", " ")
+        elif flags is not None and line.startswith(" "):
+            flags += " " + line.replace("\\", " ")
+        elif flags is not None:
+            break
+    flags = [f for f in flags.replace("$(ARCH)", "gfx950").split() if f not in ("-fPIC", "-Wall")]
+    out = tmp_path / "jb.s"
+    res = subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", src, "-o", str(out)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    text = out.read_text()
+    found = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+        name, body = m.group(1), m.group(2)
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        found[name] = (vgpr, scratch)
+    hot = {
+        "IMC, 3-D, exact geometry (BASELINE configs[1])": "k_transportILi3ELb0ELb1ELi2ELb1E",
+        "IMC, 2-D, exact geometry (configs[3])": "k_transportILi2ELb0ELb1ELi2ELb1E",
+        "IMC, 1-D, exact geometry (configs[0])": "k_transportILi1ELb0ELb1ELi2ELb1E",
+        "all-DDMC, 3-D (configs[2])": "k_ddmc_allILi3ELb1E",
+        "all-DDMC, 1-D": "k_ddmc_allILi1ELb1E",
+    }
+    for what, key in hot.items():
+        names = [n for n in found if key in n]
+        assert len(names) == 1, (what, names)
+        vgpr, scratch = found[names[0]]
+        assert vgpr <= 168, f"{what}: {vgpr} vector registers (> 168: two waves per SIMD)"
+        assert scratch == 0, f"{what}: {scratch} bytes of scratch per lane (register spills)"
