@@ -272,6 +272,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
                 std::fabs(q) < 1099511627776.0;  // 2^40: (q + i + 0.5) dx is exact
       }
     m->exact_geom = exact;
+    D.exact = exact ? 1 : 0;
   }
   int maxrank = 0;
   for (int g = 0; g < v->nblocks_total; ++g) maxrank = v->owner[g] > maxrank ? v->owner[g] : maxrank;
@@ -384,6 +385,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
     D.not_all_ddmc = (int *)flag;
   }
   D.ddmc_base = nullptr;
+  D.lam_hyb = nullptr;
   // gray (frequency-independent) opacities: library-owned per-cell mean-free-path arrays
   D.lam_base = nullptr;
   D.lam_abs = nullptr;
@@ -422,6 +424,12 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
       if ((st = upload(m, (const double *const *)pp.data(), (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
       D.ddmc_cell = (double *const *)tmp;
       D.ddmc_base = pack;
+      double *hyb = nullptr;
+      e = hipMalloc(&hyb, sizeof(double) * per * (size_t)v->nblocks);
+      if (e != hipSuccess) { jb_mesh_destroy(m); return fail(JB_ERR_HIP, "hipMalloc of the hybrid mean-free-path array failed: %s", hipGetErrorString(e)); }
+      m->owned.push_back(hyb);
+      (void)hipMemset(hyb, 0, sizeof(double) * per * (size_t)v->nblocks);
+      D.lam_hyb = hyb;
     }
   }
   *out = m;

@@ -43,6 +43,14 @@ struct DevMesh {
   // in one 64-byte record
   double *const *ddmc_cell;
   const double *ddmc_base;  // ddmc_cell[b] = ddmc_base + 8 b ntot
+  // ... and one double per cell (block b at lam_hyb + b ntot) for the hybrid kernel: the cell's
+  // scattering mean free path lam_sc, with the sign bit set when the cell takes DDMC steps
+  // (dx_push (sigma_a + sigma_s) > tau_ddmc) -- a lane in an IMC cell gathers nothing else
+  double *lam_hyb;
+  // 1 = every resident block has power-of-two cell widths and a lower corner that is a whole
+  // number of them (jb_mesh_exact_geometry): the DDMC kernels form cell faces as the EXACT gray
+  // IMC kernels do
+  int exact;
   // set to 1 by UpdateDerivedTransportFields when some interior cell of a resident block takes
   // IMC steps (dx_push (sigma_a + sigma_s) <= tau_ddmc, transport_ddmc.cpp:135); 0 = every step
   // of every particle is a DDMC step (k_ddmc_all)

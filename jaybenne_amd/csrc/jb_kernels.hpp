@@ -152,7 +152,10 @@ __global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P) {
     double *o = M.ddmc_cell[b] + 8 * q;
     o[0] = ff * aa;
     o[1] = aa + ss;
-    if (!(B.dx_push * o[1] > P.tau_ddmc)) atomicOr(M.not_all_ddmc, 1);  // an IMC cell
+    const bool ddmc_cell = B.dx_push * o[1] > P.tau_ddmc;  // transport_ddmc.cpp:135
+    if (!ddmc_cell) atomicOr(M.not_all_ddmc, 1);
+    const double ls = M.lam_sc[b][q];  // (k_fleck, this cycle)
+    M.lam_hyb[(long long)b * M.ntot + q] = ddmc_cell ? -ls : ls;
     o[2] = M.P1[b][q] / dx;
     o[3] = M.P1[b][cidx(M, k, j, i + 1)] / dx;
     o[4] = multi_d ? M.P2[b][q] / dy : 0.0;
@@ -372,6 +375,9 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
     if (tally_in_lds)
       for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) lds_tally[q] = 0.0;
   }
+  // DDMC kernels re-read the block geometry at the top of every event pass (below): from LDS
+  __shared__ std::conditional_t<DDMC, LdsBlockTable, int> blk_tab;
+  if constexpr (DDMC) fill_block_table(M, blk_tab);
   load_math_tables();  // (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   constexpr bool kFastGray = GRAY != 0 && !DDMC;
@@ -420,26 +426,41 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   // deferred direction of the last DDMC leak (packed-record DDMC kernels; see ddmc_step_event)
   int pend = -1;
   double pz1 = 0.0, pz2 = 0.0;
+  // hybrid kernels: lam_hyb of the lane's cell (its sign picks the IMC or the DDMC step), requested
+  // as soon as the cell is known -- at the end of the previous pass -- so that the choice at the
+  // top of a pass does not wait for a gather
+  double lam_cur = 0.0;
 
-  auto bind_block = [&](int blk) {
-    load_block(M, blk, B);
-    if constexpr (EXACT) {  // nudge widths eps_imc (upper - lower) = eps_imc dx, exactly
-      fd[0] = kEpsImc * B.dx[0]; fd[1] = kEpsImc * B.dx[1]; fd[2] = kEpsImc * B.dx[2];
-    }
+  auto bind_arrays = [&](int blk) {
     if constexpr (kFastGray) {  // (library-owned, contiguous: no pointer-table load)
       f0 = (gcptr)(M.lam_base + (long long)(2 * blk) * M.ntot);
       f1 = (gcptr)(M.lam_base + (long long)(2 * blk + 1) * M.ntot);
     } else if constexpr (kPackedDdmc) {
-      f0 = (gcptr)M.ddmc_cell[blk];
-      f1 = (gcptr)M.lam_abs[blk];
-      f2 = (gcptr)M.lam_sc[blk];
+      f0 = (gcptr)(M.ddmc_base + (long long)(8 * blk) * M.ntot);
+      f1 = (gcptr)(M.lam_base + (long long)(2 * blk) * M.ntot);
+      f2 = (gcptr)(M.lam_hyb + (long long)blk * M.ntot);
     } else {
       f0 = (gcptr)M.rho[blk];
       f1 = (gcptr)M.sie[blk];
       f2 = (gcptr)M.fleck[blk];
     }
   };
+  auto bind_block = [&](int blk) {
+    load_block(M, blk, B);
+    if constexpr (EXACT) {  // nudge widths eps_imc (upper - lower) = eps_imc dx, exactly
+      fd[0] = kEpsImc * B.dx[0]; fd[1] = kEpsImc * B.dx[1]; fd[2] = kEpsImc * B.dx[2];
+    }
+    bind_arrays(blk);
+  };
   auto cell_faces = [&](Step &s, const Blk &Bq) {  // transport.cpp:114-119
+    if constexpr (DDMC) {
+      if (M.exact) {  // (uniform) the same doubles in 3 instead of 8 operations per axis
+        s.xl = m_fma((double)ip, Bq.dx[0], Bq.x0[0]); s.xu = s.xl + Bq.dx[0];
+        s.yl = m_fma((double)jp, Bq.dx[1], Bq.x0[1]); s.yu = s.yl + Bq.dx[1];
+        s.zl = m_fma((double)kp, Bq.dx[2], Bq.x0[2]); s.zu = s.zl + Bq.dx[2];
+        return;
+      }
+    }
     s.xl = xc(Bq, 0, ip) - 0.5 * Bq.dx[0];
     s.xu = xc(Bq, 0, ip) + 0.5 * Bq.dx[0];
     s.yl = xc(Bq, 1, jp) - 0.5 * Bq.dx[1];
@@ -468,11 +489,13 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
         xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // next launch's transport.cpp:96
         ls = (t < t_end) ? LS_RUN : LS_DONE;
+        if constexpr (kPackedDdmc) lam_cur = f2[cidx(M, kp, jp, ip)];
       }
     }
   };
 
-  // One face of the lane's block crossed (kFastGray kernels): destination and the one geometry
+  // One face of the lane's block crossed (gray kernels; in a DDMC kernel: by an IMC step, whose
+  // particle SampleDDMCBlockFace leaves alone): destination and the one geometry
   // value that changes come from the per-(block, face) table; returns false when the general
   // relocation has to run.
   auto cross_face = [&](auto axis_c, bool up, double &pos, double &vel, int &idx, int first_i,
@@ -480,7 +503,8 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
     constexpr int AXIS = decltype(axis_c)::value;
     const int slot = 6 * b + 2 * AXIS + (int)up;
     const int ent = M.nbr_ent[slot];
-    const double nx0 = ((gcptr)M.nbr_x0)[slot];
+    double nx0 = 0.0;  // (the DDMC kernels re-read the block geometry every pass)
+    if constexpr (kFastGray) nx0 = ((gcptr)M.nbr_x0)[slot];
     if (ent < 0) return false;
     const int kind = ent >> 28;
     bool at_first = up;  // entered through the destination's lower face
@@ -495,11 +519,11 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
       }
     }
     b = ent & 0x0fffffff;
-    B.x0[AXIS] = nx0;
+    if constexpr (kFastGray) B.x0[AXIS] = nx0;
     idx = at_first ? first_i : last_i;
-    f0 = (gcptr)(M.lam_base + (long long)(2 * b) * M.ntot);
-    f1 = (gcptr)(M.lam_base + (long long)(2 * b + 1) * M.ntot);
+    bind_arrays(b);
     ls = (t < t_end) ? LS_RUN : LS_DONE;
+    if constexpr (kPackedDdmc) lam_cur = f2[cidx(M, kp, jp, ip)];
     return true;
   };
 
@@ -519,7 +543,10 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
       // (a particle relocated to a block that is not resident carries the GLOBAL id in b: the
       // geometry tables only cover resident blocks, and nothing below reads B for it)
       if constexpr (kReloadBlock) {
-        if (status != ST_OUTGOING) load_block(M, b, B);
+        if (status != ST_OUTGOING) {
+          if constexpr (DDMC) load_block(M, blk_tab, b, B);
+          else load_block(M, b, B);
+        }
       }
       if constexpr (kPackedDdmc) {
         if (pend >= 0 && !resample) {  // (absorbed right after a leak: the record still gets it)
@@ -651,6 +678,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
             resample = false;
             xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:96
             ls = (t < t_end) ? LS_RUN : LS_DONE;      // already at census: nothing to track
+            if constexpr (kPackedDdmc) lam_cur = f2[cidx(M, kp, jp, ip)];
           }
         }
         chunk_pos += give;
@@ -740,7 +768,10 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
       } else if (ls == LS_RUN) {
         Step s;
         Blk Bl;
-        if constexpr (kReloadBlock) load_block(M, b, Bl);
+        if constexpr (kReloadBlock) {
+          if constexpr (DDMC) load_block(M, blk_tab, b, Bl);
+          else load_block(M, b, Bl);
+        }
         const Blk &Bp = kReloadBlock ? Bl : B;
         s.t_start = t_start; s.dt = dt; s.vv = vv; s.rvv = P.rc; s.dx_push = Bp.dx_push;
         cell_faces(s, Bp);
@@ -753,19 +784,31 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         if constexpr (kPackedDdmc) {
           typedef double v4d __attribute__((ext_vector_type(4)));
           typedef const v4d __attribute__((address_space(1))) *grec;
-          const grec rec = (grec)(f0 + 8 * q);
-          const v4d r0 = rec[0];
-          const v4d r1 = rec[1];  // (same cache line; requested before r0 is looked at)
-          s.ffaa = r0.x; s.sig = r0.y;
-          is_ddmc_step = Bp.dx_push * s.sig > P.tau_ddmc;  // transport_ddmc.cpp:135
+          const double lam = lam_cur;  // lam_sc, sign bit set in a DDMC cell (k_ddmc_pack)
+          is_ddmc_step = lam < 0.0;    // transport_ddmc.cpp:135
           if (is_ddmc_step) {
+            const grec rec = (grec)(f0 + 8 * q);
+            const v4d r0 = rec[0];
+            const v4d r1 = rec[1];  // (same cache line; requested before r0 is looked at)
+            s.ffaa = r0.x; s.sig = r0.y;
             s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
             ptcl_ddmc_albedo<NDIM, true>(s, rng);
             if (!s.is_rejected) resample = ddmc_step_event<NDIM, true, true>(s, rng);
           } else {
             if (s.pend >= 0) materialise_dir(s);  // an IMC step reads the direction
-            if constexpr (kNoAbs) imc_step_core<NDIM, true>(s, 0.0, f2[q], rng);
-            else imc_step_core<NDIM, false>(s, f1[q], f2[q], rng);
+            // the fused step of the gray IMC kernels: it hands back the cell index of the new
+            // position (see imc_step_fast), so these lanes skip the Xtoijk below
+            ImcCell c;
+            c.xl = s.xl; c.xu = s.xu; c.yl = s.yl; c.yu = s.yu; c.zl = s.zl; c.zu = s.zu;
+            if (M.exact) {
+              c.fdx = kEpsImc * Bp.dx[0]; c.fdy = kEpsImc * Bp.dx[1]; c.fdz = kEpsImc * Bp.dx[2];
+            } else {
+              c.fdx = kEpsImc * (s.xu - s.xl); c.fdy = kEpsImc * (s.yu - s.yl);
+              c.fdz = kEpsImc * (s.zu - s.zl);
+            }
+            imc_step_fast<NDIM, kNoAbs>(c, vv, P.rc, t_end, Bp.dx_push, kNoAbs ? 0.0 : f1[q], lam,
+                                        rng, s.t, s.x, s.y, s.z, s.vx, s.vy, s.vz, s.ip, s.jp, s.kp,
+                                        s.is_absorbed, s.is_scattered);
           }
         } else {
           const double rho = f0[q];
@@ -795,22 +838,42 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
         if constexpr (kPackedDdmc) { pend = s.pend; pz1 = s.pz1; pz2 = s.pz2; }
 
-        xtoijk<NDIM>(M, Bp, x, y, z, ip, jp, kp);  // transport.cpp:146
+        if (kPackedDdmc && !is_ddmc_step) {
+          ip = s.ip; jp = s.jp; kp = s.kp;
+        } else {
+          xtoijk<NDIM>(M, Bp, x, y, z, ip, jp, kp);  // transport.cpp:146
+        }
 
         if (!on_block(M, ip, jp, kp)) {
-          if constexpr (DDMC) {  // transport_ddmc.cpp:203-211: zero velocity flags a DDMC leak
-            const bool flag = is_ddmc_step && multi_d && !s.is_rejected;
-            if constexpr (kPackedDdmc) {
-              if (pend >= 0 && !flag) {  // (1-D: the direction travels with the particle)
-                materialise_dir(s);
-                vx = s.vx; vy = s.vy; vz = s.vz;
-              }
-              pend = -1;
+          bool crossed = false;
+          if constexpr (kPackedDdmc) {
+            // an IMC step of a hybrid deck through one face into a block of the same size, a
+            // periodic wrap or a reflection: served from the face table at once, as in the gray
+            // IMC kernels (the particle has a real velocity, which SampleDDMCBlockFace skips)
+            if (!is_ddmc_step) {
+              const bool xo = ip < M.is || ip > M.ie;
+              const bool yo = multi_d && (jp < M.js || jp > M.je);
+              const bool zo = three_d && (kp < M.ks || kp > M.ke);
+              if (xo && !yo && !zo) crossed = cross_face(std::integral_constant<int, 0>{}, ip > M.ie, x, vx, ip, M.is, M.ie);
+              else if (yo && !xo && !zo) crossed = cross_face(std::integral_constant<int, 1>{}, jp > M.je, y, vy, jp, M.js, M.je);
+              else if (zo && !xo && !yo) crossed = cross_face(std::integral_constant<int, 2>{}, kp > M.ke, z, vz, kp, M.ks, M.ke);
             }
-            const double vmask = flag ? 0.0 : 1.0;
-            vx *= vmask; vy *= vmask; vz *= vmask;
           }
-          ls = LS_RELOC;  // comm phase: in the service phase
+          if (!crossed) {
+            if constexpr (DDMC) {  // transport_ddmc.cpp:203-211: zero velocity flags a DDMC leak
+              const bool flag = is_ddmc_step && multi_d && !s.is_rejected;
+              if constexpr (kPackedDdmc) {
+                if (pend >= 0 && !flag) {  // (1-D: the direction travels with the particle)
+                  materialise_dir(s);
+                  vx = s.vx; vy = s.vy; vz = s.vz;
+                }
+                pend = -1;
+              }
+              const double vmask = flag ? 0.0 : 1.0;
+              vx *= vmask; vy *= vmask; vz *= vmask;
+            }
+            ls = LS_RELOC;  // comm phase: in the service phase
+          }
         } else if (s.is_absorbed) {  // transport.cpp:157-163
           if (M.owned[b]) {
             atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
@@ -820,6 +883,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           }
           ls = LS_DONE;
         } else {
+          if constexpr (kPackedDdmc) lam_cur = f2[cidx(M, kp, jp, ip)];  // (for the next pass)
           if (s.is_scattered) scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
           if (!(t < t_end)) ls = LS_DONE;                    // census
         }
