@@ -580,7 +580,7 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
                                                      kBlock, 0) != hipSuccess || occ < 1)          \
       occ = 3;                                                                                     \
     const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
-    const int *pair_flag = (DDMC && G != 0) ? M.not_all_ddmc : nullptr;                            \
+    const int *pair_flag = (DDMC && G != 0 && M.nblocks <= kLdsBlocks) ? M.not_all_ddmc : nullptr; \
     hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G, X>), dim3(g), dim3(kBlock), 0, ctx->stream,  \
                        M, ctx->dp, S, t_start, dt, first, last, ctx->counters_d, pair_flag);       \
     mesh->last_variant = NDIM == 1 ? "k_transport<1, " #T ", " #G ", " #X ">"                      \
@@ -599,7 +599,9 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
   } while (0)
   mesh->last_pair = "";
   if constexpr (DDMC) {
-    if (gray && M.ddmc_cell) {  // every cell a DDMC cell: the lean kernel (else it returns at once)
+    // every cell a DDMC cell: the lean kernel (else it returns at once); it keeps the per-block
+    // tables in LDS, so meshes with more resident blocks than fit there stay with k_transport
+    if (gray && M.ddmc_cell && M.nblocks <= kLdsBlocks) {
       mesh->last_pair = NDIM == 1 ? (tally ? "k_ddmc_all<1, true>" : "k_ddmc_all<1, false>")
                         : NDIM == 2 ? (tally ? "k_ddmc_all<2, true>" : "k_ddmc_all<2, false>")
                                     : (tally ? "k_ddmc_all<3, true>" : "k_ddmc_all<3, false>");

@@ -127,7 +127,7 @@ __device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
 // The same from a copy of the per-block tables in LDS (kernels whose service phase would wait
 // for these small dependent loads behind its own stores: vector-memory operations complete in
 // issue order, LDS reads have their own counter).  Up to kLdsBlocks resident blocks.
-constexpr int kLdsBlocks = 128;
+constexpr int kLdsBlocks = 256;
 struct LdsBlockTable {
   double xmin[kLdsBlocks][3], dx[kLdsBlocks][3], inv_dx[kLdsBlocks][3];
   double *tally[kLdsBlocks];
@@ -170,6 +170,32 @@ __device__ __forceinline__ void load_block(const DevMesh &M, const LdsBlockTable
     B.inv_dx[d] = T.inv_dx[b][d];
   }
   B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));
+}
+
+// ... and without the fallback to the global tables (k_ddmc_all: the host only launches it when
+// the resident blocks fit the LDS table)
+__device__ __forceinline__ void load_block_lds(const DevMesh &M, const LdsBlockTable &T, int b, Blk &B) {
+  const int first[3] = {M.is, M.js, M.ks};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    B.xmin[d] = T.xmin[b][d];
+    B.dx[d] = T.dx[b][d];
+    B.x0[d] = B.xmin[d] - (double)first[d] * B.dx[d];
+    B.inv_dx[d] = T.inv_dx[b][d];
+  }
+  B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));
+}
+
+// A uniform value in scalar registers of its own (see k_ddmc_all).
+__device__ __forceinline__ unsigned sgpr_copy(unsigned v) {
+  unsigned r;
+  asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(v));
+  return r;
+}
+__device__ __forceinline__ const double *sgpr_copy_ptr(const double *p) {
+  unsigned long long r;
+  asm volatile("s_mov_b64 %0, %1" : "=s"(r) : "s"((unsigned long long)p));
+  return (const double *)r;
 }
 
 // Parthenon UniformCartesian: Xc(idx) = x0 + (idx + 0.5) dx

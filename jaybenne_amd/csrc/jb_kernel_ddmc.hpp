@@ -94,11 +94,26 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     s.yl = xc(Bq, 1, j) - 0.5 * Bq.dx[1]; s.yu = xc(Bq, 1, j) + 0.5 * Bq.dx[1];
     s.zl = xc(Bq, 2, k) - 0.5 * Bq.dx[2]; s.zu = xc(Bq, 2, k) + 0.5 * Bq.dx[2];
   };
+  // Uniform values the event loop reads, as scalar registers of their own: the kernel arguments
+  // arrive in 16-dword groups, and a group the compiler parks in VGPR lanes comes back whole
+  // (16 v_readlane per pass for one dword of it).
+  const unsigned ntot_u = sgpr_copy((unsigned)M.ntot);
+  const double *rec_base = sgpr_copy_ptr(M.ddmc_base);
+  const int l_ni = (int)sgpr_copy((unsigned)M.ni), l_nj = (int)sgpr_copy((unsigned)M.nj);
+  const int l_is = (int)sgpr_copy((unsigned)M.is), l_ie = (int)sgpr_copy((unsigned)M.ie);
+  const int l_js = (int)sgpr_copy((unsigned)M.js), l_je = (int)sgpr_copy((unsigned)M.je);
+  const int l_ks = (int)sgpr_copy((unsigned)M.ks), l_ke = (int)sgpr_copy((unsigned)M.ke);
+  auto cidx_l = [&](int k, int j, int i) { return __mul24(__mul24(k, l_nj) + j, l_ni) + i; };
+  auto on_block_l = [&](int i, int j, int k) {
+    return i >= l_is && i <= l_ie && j >= l_js && j <= l_je && k >= l_ks && k <= l_ke;
+  };
   auto load_record = [&](Step &s, int blk, int q) {
     typedef double v4d __attribute__((ext_vector_type(4)));
     typedef const v4d __attribute__((address_space(1))) *grec;
     // (library-owned, contiguous: no pointer-table load in front of the gather)
-    const grec rec = (grec)((gcptr)M.ddmc_base + 8 * ((long long)blk * M.ntot + q));
+    // (one 32 x 32 -> 64-bit multiply-add: jb_mesh_create keeps ntot below 2^31)
+    const grec rec = (grec)((gcptr)rec_base +
+                            8 * ((unsigned long long)(unsigned)blk * ntot_u + (unsigned)q));
     const v4d r0 = rec[0];
     const v4d r1 = rec[1];
     s.ffaa = r0.x; s.sig = r0.y;
@@ -138,7 +153,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     // -- 1. block crossings: the comm phase of the reference for one particle in flight
     if (ls == DS_RELOC) {
       Blk Bo;
-      load_block(M, lds_blocks, b, Bo);
+      load_block_lds(M, lds_blocks, b, Bo);
       Step s;
       s.vv = vv; s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
       if (!real_pos) {
@@ -181,7 +196,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         } else {
           b = li;
           Blk Bn;
-          load_block(M, lds_blocks, b, Bn);
+          load_block_lds(M, lds_blocks, b, Bn);
           if constexpr (multi_d)
             sample_block_face<NDIM>(M, P, Bn, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
           xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);
@@ -251,7 +266,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       bool write_v = real_pos;  // else: unchanged since it was loaded (or parked), or set below
       if (status != ST_OUTGOING && status != ST_ESCAPED) {
         Blk Bd;
-        load_block(M, lds_blocks, b, Bd);
+        load_block_lds(M, lds_blocks, b, Bd);
         Step s;
         s.vv = vv;
         faces_of(s, Bd, ip, jp, kp);
@@ -278,14 +293,14 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           pend = -1;
           write_v = true;
         }
-        if ((status == ST_ACTIVE || status == ST_OUTGOING_ABSORBED) && !block_owned(M, lds_blocks, b)) {
+        if ((status == ST_ACTIVE || status == ST_OUTGOING_ABSORBED) && lds_blocks.owned[b] == 0) {
           if (status == ST_ACTIVE) status = ST_OUTGOING;  // the owner of the block tallies it
           b = M.gid[b];
         } else if (status == ST_ACTIVE) {
           if constexpr (TALLY) {  // jaybenne.cpp:547-561
             const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
             if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
-            else atomicAdd(&block_tally(M, lds_blocks, b)[cidx(M, kp, jp, ip)], wgt / dv);
+            else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], wgt / dv);
           }
         }
       }
@@ -319,7 +334,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       pend = -1;
       real_pos = true;
       Blk Bn;
-      load_block(M, lds_blocks, b, Bn);
+      load_block_lds(M, lds_blocks, b, Bn);
       xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);  // transport.cpp:96
       if (t < t_end) enter(Bn);
       else ls = DS_DONE;  // already at census: nothing to track
@@ -330,7 +345,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     if (ls == DS_REAL) {
       ++c_ev_real;
       Blk Br;
-      load_block(M, lds_blocks, b, Br);
+      load_block_lds(M, lds_blocks, b, Br);
       Step s;
       s.t_start = t_start; s.dt = dt; s.vv = vv; s.rvv = P.rc; s.dx_push = Br.dx_push;
       faces_of(s, Br, ip, jp, kp);
@@ -338,7 +353,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       s.ip = ip; s.jp = jp; s.kp = kp;
       s.is_absorbed = false; s.is_scattered = false; s.is_rejected = false;
       s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
-      load_record(s, b, cidx(M, kp, jp, ip));
+      load_record(s, b, cidx_l(kp, jp, ip));
       ptcl_ddmc_albedo<NDIM, true>(s, rng);
       bool census = false;
       if (!s.is_rejected) census = ddmc_step_event<NDIM, true, true>(s, rng);
@@ -347,12 +362,12 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       xtoijk<NDIM>(M, Br, x, y, z, ip, jp, kp);  // transport.cpp:146
       if (!s.is_rejected) resample = census;  // (as k_transport: the flag of the last step)
       real_pos = true;
-      if (!on_block(M, ip, jp, kp)) {
+      if (!on_block_l(ip, jp, kp)) {
         // (a rejected particle keeps its direction: pend < 0; a leak is flagged in step 1)
         ls = DS_RELOC;
       } else if (s.is_absorbed) {  // transport.cpp:157-163
-        if (block_owned(M, lds_blocks, b)) {
-          atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], wgt);
+        if (lds_blocks.owned[b] != 0) {
+          atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], wgt);
           status = ST_ABSORBED;
         } else {
           status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
@@ -396,13 +411,13 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         // (faces and position feed nothing that is read below: the cell record holds the leak
         // opacities P / dx, the step's position output is never formed)
         s.xl = s.yl = s.zl = 0.0; s.xu = s.yu = s.zu = 1.0;
-        load_record(s, b, cidx(M, kp, jp, ip));
+        load_record(s, b, cidx_l(kp, jp, ip));
         const bool census = ddmc_step_event<NDIM, true, true>(s, rng);
         t = s.t;
         ip = s.ip; jp = s.jp; kp = s.kp;  // = Xtoijk of the position the step gives (see header)
         pend = s.pend; pz1 = s.pz1; pz2 = s.pz2;
         resample = census;
-        if (!on_block(M, ip, jp, kp)) {
+        if (!on_block_l(ip, jp, kp)) {
           // A leak through a block face (0.4 per history on BASELINE configs[2]).  Into a resident
           // block of the same size -- directly or through a periodic boundary -- nothing happens
           // to the particle beyond the new block and cell: SampleDDMCBlockFace only acts on an
@@ -412,23 +427,23 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           // (transport_ddmc.cpp:203-211).  Everything else goes through the service phase.
           const int axis = pend >> 1;
           const bool up = (pend & 1) != 0;
-          const int ent = block_nbr_ent(M, lds_blocks, b, pend);
+          const int ent = lds_blocks.nbr_ent[b][pend];
           // (a reflecting boundary puts the particle back into the cell it left, eps_ddmc dx
           // inside the wall; in 1-D its direction would have to be mirrored: service phase)
           if (ent >= 0 && (multi_d || (ent >> 28) != 2)) {
             const bool at_first = ((ent >> 28) == 2) != up;
             b = ent & 0x0fffffff;
-            if (axis == 0) ip = at_first ? M.is : M.ie;
-            else if (axis == 1) jp = at_first ? M.js : M.je;
-            else kp = at_first ? M.ks : M.ke;
+            if (axis == 0) ip = at_first ? l_is : l_ie;
+            else if (axis == 1) jp = at_first ? l_js : l_je;
+            else kp = at_first ? l_ks : l_ke;
             if constexpr (multi_d) pend = -2;
             if (!(t < t_end)) ls = DS_DONE;
           } else {
             ls = DS_RELOC;
           }
         } else if (s.is_absorbed) {  // transport.cpp:157-163
-          if (block_owned(M, lds_blocks, b)) {
-            atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], wgt);
+          if (lds_blocks.owned[b] != 0) {
+            atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], wgt);
             status = ST_ABSORBED;
           } else {
             status = ST_OUTGOING_ABSORBED;
