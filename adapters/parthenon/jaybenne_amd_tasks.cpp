@@ -67,12 +67,25 @@ std::shared_ptr<StateDescriptor> Initialize(ParameterInput *pin, Opacity &opacit
   p.do_feedback = pin->GetOrAddBoolean("jaybenne", "do_feedback", true);
   p.rank = Globals::my_rank;
 
-  // the host's model objects as tagged POD (jaybenne_amd.h): singularity IdealGas / Gray / GrayS
+  // the host's model objects as tagged POD (jaybenne_amd.h): singularity IdealGas, Gray or
+  // EPBremss, GrayS or ThomsonS.  The variants (opacity.hpp:23-30) carry no type tag the adapter
+  // could read back, so the host says which alternative it built and with which code -> CGS
+  // scales: the optional <jaybenne> keys below default to the gray models in CGS, for which the
+  // coefficients are read off the objects themselves (frequency independent, linear in rho).
   auto units = opacity.GetRuntimePhysicalConstants();
   jb_eos e{JB_EOS_IDEAL_GAS, 0, eos.GruneisenParamFromDensityTemperature(1.0, 1.0),
            eos.SpecificHeatFromDensityTemperature(1.0, 1.0)};
-  jb_opacity o{JB_OPAC_GRAY, 0, opacity.AbsorptionCoefficient(1.0, 1.0, 1.0), units.c, units.sb};
-  jb_scattering s{JB_SCAT_GRAY, 0, scattering.TotalScatteringCoefficient(1.0, 1.0, 1.0), 1.0};
+  const bool epbremss = pin->GetOrAddString("jaybenne", "amd_opacity_model", "gray") == "ep_bremss";
+  const bool thomson = pin->GetOrAddString("jaybenne", "amd_scattering_model", "gray") == "thomson";
+  const Real ts = pin->GetOrAddReal("mcblock", "time_scale", 1.), ms = pin->GetOrAddReal("mcblock", "mass_scale", 1.),
+             ls = pin->GetOrAddReal("mcblock", "length_scale", 1.), tks = pin->GetOrAddReal("mcblock", "temperature_scale", 1.);
+  const Real apm = pin->GetOrAddReal("mcblock", "apm", 1.);
+  jb_opacity o{epbremss ? JB_OPAC_EPBREMSS : JB_OPAC_GRAY, 0,
+               epbremss ? 0.0 : opacity.AbsorptionCoefficient(1.0, 1.0, 1.0), units.c, units.sb,
+               ts, ms, ls, tks};
+  jb_scattering s{thomson ? JB_SCAT_THOMSON : JB_SCAT_GRAY, 0,
+                  thomson ? 0.0 : scattering.TotalScatteringCoefficient(1.0, 1.0, 1.0) * apm, apm,
+                  ts, ms, ls, tks};
 
   auto st = std::make_shared<AmdState>();
   int device = 0;

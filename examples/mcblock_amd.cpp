@@ -215,14 +215,21 @@ int main(int argc, char **argv) {
     const double gamma = pin.GetOrAddReal("mcblock", "gamma", 1.66666666667);
     const double cv = pin.GetOrAddReal("mcblock", "cv", 1. / (gamma - 1.));
     jb_eos eos = {JB_EOS_IDEAL_GAS, 0, gamma - 1., cv};
+    // units: conversion factors from code to CGS (mcblock.cpp:84-91), the NonCGSUnits arguments
+    const double ts = pin.GetOrAddReal("mcblock", "time_scale", 1.), ms = pin.GetOrAddReal("mcblock", "mass_scale", 1.),
+                 ls = pin.GetOrAddReal("mcblock", "length_scale", 1.), tks = pin.GetOrAddReal("mcblock", "temperature_scale", 1.);
     const std::string om = pin.GetString("mcblock", "opacity_model");
-    if (om != "none" && om != "constant") throw std::runtime_error("Only none or constant opacity models supported!");
-    jb_opacity opacity = {JB_OPAC_GRAY, 0, om == "constant" ? pin.GetReal("mcblock", "opacity_constant_value") : 0.0,
-                          2.99792458e10, 5.670373e-5};
+    if (om != "none" && om != "constant" && om != "ep_bremss") throw std::runtime_error("Only none or constant opacity models supported!");
+    // (the library takes kappa and the physical constants in code units)
+    jb_opacity opacity = {om == "ep_bremss" ? JB_OPAC_EPBREMSS : JB_OPAC_GRAY, 0,
+                          (om == "constant" ? pin.GetReal("mcblock", "opacity_constant_value") : 0.0) * (ms / (ls * ls)),
+                          2.99792458e10 * (ts / ls), 5.670373e-5 * (ts * ts * ts * (tks * tks) * (tks * tks) / ms),
+                          ts, ms, ls, tks};
     const std::string sm = pin.GetOrAddString("mcblock", "scattering_model", "none");
     if (sm != "none" && sm != "constant") throw std::runtime_error("Only none or constant scattering models supported!");
-    jb_scattering scattering = {JB_SCAT_GRAY, 0, sm == "constant" ? pin.GetReal("mcblock", "scattering_constant_value") : 0.0,
-                                pin.GetOrAddReal("mcblock", "apm", 1.)};
+    jb_scattering scattering = {JB_SCAT_GRAY, 0,
+                                (sm == "constant" ? pin.GetReal("mcblock", "scattering_constant_value") : 0.0) * (ms / (ls * ls)),
+                                pin.GetOrAddReal("mcblock", "apm", 1.), ts, ms, ls, tks};
 
     // ---- jaybenne::Initialize (jaybenne.cpp:158-266) -------------------------------------------
     jb_params p;

@@ -79,11 +79,23 @@ typedef struct jb_eos {
 typedef struct jb_opacity {
   int32_t model, pad;
   double kappa;          /* Gray: sigma_a = rho kappa, j = sigma_a 4 sb T^4 */
-  double c, sb;          /* GetRuntimePhysicalConstants(): speed of light, Stefan-Boltzmann */
+  double c, sb;          /* GetRuntimePhysicalConstants(): speed of light, Stefan-Boltzmann,
+                            in code units */
+  /* NonCGSUnits<...>(opac, time, mass, length, temperature): code -> CGS conversion factors
+   * (mcblock.cpp:84-91); read by JB_OPAC_EPBREMSS only (Gray takes kappa in code units):
+   * electron-proton bremsstrahlung of fully ionised hydrogen, n_e = n_i = rho / m_p,
+   *   alpha_nu = 4 e^6 / (3 m_e h c) sqrt(2 pi / (3 k m_e)) T^-1/2 n_e n_i nu^-3 (1 - e^(-h nu / k T))
+   *   j        = sqrt(2 pi k T / (3 m_e)) 2^5 pi e^6 / (3 h m_e c^3) n_e n_i
+   * (Rybicki & Lightman 5.18a, 5.15a, Gaunt factor 1) -- singularity-opac is not vendored in the
+   * reference tree, so its constants could not be compared: parity unpinned for this model. */
+  double time_scale, mass_scale, length_scale, temperature_scale;
 } jb_opacity;
 typedef struct jb_scattering {
   int32_t model, pad;
-  double kappa_s, apm;   /* GrayS: sigma_s = (rho / apm) kappa_s */
+  double kappa_s, apm;   /* GrayS: sigma_s = (rho / apm) kappa_s; apm also read by ThomsonS */
+  /* JB_SCAT_THOMSON: sigma_s = n_e sigma_T with n_e = rho / apm (apm in code mass units, as
+   * mcblock.cpp:124 passes it), i.e. GrayS with kappa_s = sigma_T / length_scale^2 */
+  double time_scale, mass_scale, length_scale, temperature_scale;
 } jb_scattering;
 
 /* The slice of the mesh this rank owns (the MeshData / SparsePack role).  All pointers in this
@@ -288,8 +300,15 @@ jb_status jb_debug_stream_start(jb_context *ctx, uint32_t seed, uint64_t id, uin
 jb_status jb_debug_draw_stream(jb_context *ctx, uint64_t state, int n, double *out_host,
                                uint64_t *final_state);
 /* which: 0 log, 1 sin, 2 cos, 3 acos, 4 sqrt, 5 reciprocal, 6 lean sqrt, 7 lean x[i] / x[i+1],
- * 8 lean x[i] / c, 9 sin(2 pi x), 10 cos(2 pi x) */
+ * 8 lean x[i] / c, 9 sin(2 pi x), 10 cos(2 pi x), 11 1 - exp(-x) */
 jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n, double *out_host);
+/* the opacity / scattering models as the kernels evaluate them: out[0..3] = EPBremss A, B, E
+ * (sigma_a = A rho^2 T^-1/2 (1 - e^(-B nu / T)) nu^-3, j = E rho^2 T^1/2, code units) and the
+ * effective GrayS kappa_s; and one evaluation: which 0 absorption(rho, T, nu), 1 emissivity(rho,
+ * T), 2 scattering(rho, T, nu) for n triples x_host[3 i .. 3 i + 2] */
+jb_status jb_debug_model_coefficients(jb_context *ctx, double out[4]);
+jb_status jb_debug_model_eval(jb_context *ctx, int which, const double *x_host, int n,
+                              double *out_host);
 /* step functions on a tape of uniforms.  st: jb_debug_step record (see below); which:
  * 0 ptcl_transport_step, 1 ptcl_ddmc_step, 2 ptcl_ddmc_albedo */
 typedef struct jb_debug_step {

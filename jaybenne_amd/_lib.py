@@ -38,12 +38,15 @@ class Eos(C.Structure):
 
 class Opacity(C.Structure):
     _fields_ = [("model", C.c_int32), ("pad", C.c_int32), ("kappa", C.c_double),
-                ("c", C.c_double), ("sb", C.c_double)]
+                ("c", C.c_double), ("sb", C.c_double), ("time_scale", C.c_double),
+                ("mass_scale", C.c_double), ("length_scale", C.c_double),
+                ("temperature_scale", C.c_double)]
 
 
 class Scattering(C.Structure):
     _fields_ = [("model", C.c_int32), ("pad", C.c_int32), ("kappa_s", C.c_double),
-                ("apm", C.c_double)]
+                ("apm", C.c_double), ("time_scale", C.c_double), ("mass_scale", C.c_double),
+                ("length_scale", C.c_double), ("temperature_scale", C.c_double)]
 
 
 FIELD_IDS = {"rho": 0, "sie": 1, "u": 2, "fleck": 3, "tally": 4, "edelta": 5}   # enum jb_field
@@ -131,6 +134,8 @@ PROTOTYPES = {
     "jb_debug_stream_start": (_int, [_vp, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jb_debug_draw_stream": (_int, [_vp, C.c_uint64, _int, _vp, C.POINTER(C.c_uint64)]),
     "jb_debug_math": (_int, [_vp, _int, _vp, _int, _vp]),
+    "jb_debug_model_coefficients": (_int, [_vp, C.POINTER(C.c_double * 4)]),
+    "jb_debug_model_eval": (_int, [_vp, _int, _vp, _int, _vp]),
     "jb_debug_step_call": (_int, [_vp, _int, C.POINTER(DebugStep), _vp, _int, C.POINTER(_int)]),
     "jb_debug_sample_call": (_int, [_vp, _int, _vp, _vp, _vp, _int, _vp, _vp, C.POINTER(_int)]),
 }

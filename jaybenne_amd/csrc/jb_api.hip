@@ -107,10 +107,16 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   if (params->num_particles < 0) return fail(JB_ERR_INVALID, "num_particles must be >= 0");
   if (eos->model != JB_EOS_IDEAL_GAS)
     return fail(JB_ERR_UNSUPPORTED, "only the IdealGas EOS is built");
-  if (opacity->model != JB_OPAC_GRAY)
-    return fail(JB_ERR_UNSUPPORTED, "only the Gray absorption opacity is built");
-  if (scattering->model != JB_SCAT_GRAY)
-    return fail(JB_ERR_UNSUPPORTED, "only the GrayS scattering opacity is built");
+  if (opacity->model != JB_OPAC_GRAY && opacity->model != JB_OPAC_EPBREMSS)
+    return fail(JB_ERR_UNSUPPORTED, "unknown absorption opacity model (Gray, EPBremss)");
+  if (scattering->model != JB_SCAT_GRAY && scattering->model != JB_SCAT_THOMSON)
+    return fail(JB_ERR_UNSUPPORTED, "unknown scattering model (GrayS, ThomsonS)");
+  if (opacity->model == JB_OPAC_EPBREMSS &&
+      !(opacity->time_scale > 0.0 && opacity->mass_scale > 0.0 && opacity->length_scale > 0.0 &&
+        opacity->temperature_scale > 0.0))
+    return fail(JB_ERR_INVALID, "EPBremss needs positive time / mass / length / temperature scales");
+  if (scattering->model == JB_SCAT_THOMSON && !(scattering->length_scale > 0.0))
+    return fail(JB_ERR_INVALID, "ThomsonS needs a positive length scale");
   JB_HIP(hipSetDevice(device));
   jb_context *ctx = new (std::nothrow) jb_context();
   if (!ctx) return fail(JB_ERR_HIP, "out of host memory");
@@ -129,6 +135,32 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   ctx->dp.kappa_a = opacity->kappa;
   ctx->dp.kappa_s = scattering->kappa_s;
   ctx->dp.apm = scattering->apm;
+  ctx->dp.opac_model = opacity->model;
+  ctx->dp.pad_ = 0;
+  ctx->dp.ep_A = ctx->dp.ep_B = ctx->dp.ep_E = 0.0;
+  {
+    // CGS constants (CODATA 2018): electron charge (esu), electron / proton mass, Planck,
+    // Boltzmann, speed of light, Thomson cross-section
+    const double qe = 4.803204712570263e-10, me = 9.1093837015e-28, mp = 1.67262192369e-24,
+                 hp = 6.62607015e-27, kb = 1.380649e-16, cl = 2.99792458e10,
+                 sigma_t = 6.6524587321e-25, pi = 3.14159265358979323846;
+    if (opacity->model == JB_OPAC_EPBREMSS) {
+      const double tau = opacity->time_scale, mu = opacity->mass_scale, lam = opacity->length_scale,
+                   th = opacity->temperature_scale;
+      const double e6 = (qe * qe) * (qe * qe) * (qe * qe);
+      const double k_abs = (4.0 * e6) / (3.0 * me * hp * cl) * std::sqrt((2.0 * pi) / (3.0 * kb * me));
+      const double k_em = std::sqrt((2.0 * pi * kb) / (3.0 * me)) *
+                          ((32.0 * pi * e6) / (3.0 * hp * me * (cl * cl * cl)));
+      const double n_per_rho = (mu / (lam * lam * lam)) / mp;  // n_e = n_i per unit code density
+      const double n2 = n_per_rho * n_per_rho, tau3 = tau * tau * tau;
+      ctx->dp.ep_A = lam * k_abs * n2 / std::sqrt(th) * tau3;
+      ctx->dp.ep_B = hp / (kb * th * tau);
+      ctx->dp.ep_E = k_em * std::sqrt(th) * n2 * (tau3 * lam / mu);
+      ctx->dp.kappa_a = 0.0;
+    }
+    if (scattering->model == JB_SCAT_THOMSON)
+      ctx->dp.kappa_s = sigma_t / (scattering->length_scale * scattering->length_scale);
+  }
   // (a failure below must not leak the context: jb_finalize releases whatever exists)
   auto init_device_state = [&]() -> jb_status {
     hipDeviceProp_t prop;
@@ -396,7 +428,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   // models; it is what a frequency-dependent opacity would run, and the tests exercise it
   const char *general = getenv("JB_PER_EVENT_OPACITY");
   const bool per_event = general && general[0] == '1';
-  if (!per_event && ctx->opac.model == JB_OPAC_GRAY && ctx->scat.model == JB_SCAT_GRAY) {
+  if (!per_event && ctx->opac.model == JB_OPAC_GRAY) {  // (ThomsonS has the GrayS form)
     const size_t per = (size_t)D.ntot;
     double *base = nullptr;
     hipError_t e = hipMalloc(&base, sizeof(double) * per * 2 * (size_t)v->nblocks);
@@ -1055,8 +1087,16 @@ __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
     case 7: out[i] = m_div(x[i], x[(i + 1) % n]); break;
     case 8: out[i] = m_div_r(x[i], 2.99792458e10, m_rcp_refined(2.99792458e10)); break;
     case 9: m_sincos2pi(x[i], s, c); out[i] = s; break;
-    default: m_sincos2pi(x[i], s, c); out[i] = c; break;
+    case 10: m_sincos2pi(x[i], s, c); out[i] = c; break;
+    default: out[i] = m_one_minus_exp_neg(x[i]); break;
     }
+  }
+}
+__global__ void k_dbg_model(DevParams P, int which, const double *x, int n, double *out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double rho = x[3 * i], temp = x[3 * i + 1], nu = x[3 * i + 2];
+    out[i] = which == 0 ? opac_absorption(P, rho, temp, nu)
+             : which == 1 ? opac_emissivity(P, rho, temp) : opac_scattering(P, rho, temp, nu);
   }
 }
 __global__ void k_dbg_step(int which, jb_debug_step *d, const double *tape, int ntape, int *ndraws) {
@@ -1182,6 +1222,23 @@ extern "C" jb_status jb_debug_draw_stream(jb_context *ctx, uint64_t state, int n
   JB_HIP(hipStreamSynchronize(ctx->stream));
   JB_HIP(o.get(out_host, sizeof(double) * n));
   JB_HIP(f.get(final_state, 8));
+  return JB_COMPLETE;
+}
+extern "C" jb_status jb_debug_model_coefficients(jb_context *ctx, double out[4]) {
+  if (!ctx || !out) return fail(JB_ERR_INVALID, "bad argument");
+  out[0] = ctx->dp.ep_A; out[1] = ctx->dp.ep_B; out[2] = ctx->dp.ep_E; out[3] = ctx->dp.kappa_s;
+  return JB_COMPLETE;
+}
+extern "C" jb_status jb_debug_model_eval(jb_context *ctx, int which, const double *x_host, int n,
+                                         double *out_host) {
+  if (!ctx || n < 0 || which < 0 || which > 2) return fail(JB_ERR_INVALID, "bad argument");
+  JB_HIP(hipSetDevice(ctx->device));
+  DbgBuf x, o;
+  JB_HIP(x.put(x_host, sizeof(double) * 3 * n));
+  JB_HIP(o.put(nullptr, sizeof(double) * n));
+  hipLaunchKernelGGL(k_dbg_model, dim3(64), dim3(256), 0, ctx->stream, ctx->dp, which, (const double *)x.d, n, (double *)o.d);
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  JB_HIP(o.get(out_host, sizeof(double) * n));
   return JB_COMPLETE;
 }
 extern "C" jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n,

@@ -65,7 +65,10 @@ struct DevParams {
   double rc;          // m_rcp_refined(c), evaluated on the device at jb_initialize
   double cv;          // IdealGas
   double kappa_a;     // Gray
-  double kappa_s, apm;  // GrayS
+  double kappa_s, apm;  // GrayS (ThomsonS: kappa_s = sigma_T / length_scale^2)
+  // EPBremss (opac_model 1): sigma_a = A rho^2 T^-1/2 (1 - e^(-B nu / T)) nu^-3, j = E rho^2 T^1/2
+  int opac_model, pad_;
+  double ep_A, ep_B, ep_E;
 };
 
 struct DevSwarm {
@@ -92,10 +95,15 @@ __device__ __forceinline__ double eos_temperature(const DevParams &P, double rho
 }
 __device__ __forceinline__ double opac_absorption(const DevParams &P, double rho, double temp,
                                                   double nu) {
-  (void)temp; (void)nu;
+  if (P.opac_model == 1) {  // (uniform) EPBremss, include/jaybenne_amd.h
+    if (!(temp > 0.0)) return 0.0;
+    const double g = m_one_minus_exp_neg((P.ep_B * nu) / temp);
+    return ((P.ep_A * (rho * rho)) / sqrt(temp)) * (g / ((nu * nu) * nu));
+  }
   return rho * P.kappa_a;
 }
 __device__ __forceinline__ double opac_emissivity(const DevParams &P, double rho, double temp) {
+  if (P.opac_model == 1) return (P.ep_E * (rho * rho)) * sqrt(temp > 0.0 ? temp : 0.0);
   const double t2 = temp * temp;
   return (rho * P.kappa_a) * ((4.0 * P.sb) * (t2 * t2));
 }

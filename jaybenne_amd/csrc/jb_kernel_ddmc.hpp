@@ -42,7 +42,10 @@ namespace jb {
 enum { DS_IDLE = 0, DS_VIRT = 1, DS_REAL = 2, DS_DONE = 3, DS_RELOC = 4 };
 
 template <int NDIM, bool TALLY>
-__global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
+#ifndef JB_DDMC_ALL_ATTR
+#define JB_DDMC_ALL_ATTR
+#endif
+__global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_ALL_ATTR
     k_ddmc_all(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
                long long last, unsigned long long *counters, const int *not_all_ddmc) {
   if (*not_all_ddmc != 0) return;  // (uniform) some cell takes IMC steps: k_transport runs instead

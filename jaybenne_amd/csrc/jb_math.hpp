@@ -178,6 +178,33 @@ __device__ __forceinline__ void m_sincos2pi(double u, double &sn, double &cs) {
   cs = m_fma(ci, cm1, m_fnma(si, sr, ci));
 }
 
+// 1 - exp(-x) for x >= 0 (the stimulated-emission factor of a thermal absorption coefficient),
+// fully specified like the functions above: Taylor coefficients 1/n! (correctly rounded), Horner
+// steps as fma, argument reduction x = k ln2 + r with k ln2_hi exact.  ~1 ulp of 1 - e^-x.
+__device__ __forceinline__ double m_one_minus_exp_neg(double x) {
+  constexpr double c[17] = {0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p-1,
+                            0x1.5555555555555p-3, 0x1.5555555555555p-5, 0x1.1111111111111p-7,
+                            0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-16,
+                            0x1.71de3a556c734p-19, 0x1.27e4fb7789f5cp-22, 0x1.ae64567f544e4p-26,
+                            0x1.1eed8eff8d898p-29, 0x1.6124613a86d09p-33, 0x1.93974a8c07c9dp-37,
+                            0x1.ae7f3e733b81fp-41, 0x1.ae7f3e733b81fp-45};
+  if (!(x < 40.0)) return 1.0;  // e^-40 < 2^-54
+  if (x < 0.25) {               // x (1 - x/2! + x^2/3! - ...): no cancellation
+    const double z = -x;
+    double q = c[14];
+    for (int n = 13; n >= 1; --n) q = fma(q, z, c[n]);
+    return x * q;
+  }
+  const double kf = floor(fma(x, 0x1.71547652b82fep+0, 0.5));
+  double r = fma(kf, -0x1.62e42fee00000p-1, x);
+  r = fma(kf, -0x1.a39ef35793c76p-33, r);
+  const double z = -r;  // |r| <= ln2 / 2 (+ rounding of k)
+  double p = c[16];
+  for (int n = 15; n >= 0; --n) p = fma(p, z, c[n]);
+  const double scale = __longlong_as_double((long long)(1023 - (int)kf) << 52);  // 2^-k, k <= 58
+  return 1.0 - p * scale;
+}
+
 __device__ __forceinline__ double m_acos_R(double z) {
   constexpr double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
                    pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,

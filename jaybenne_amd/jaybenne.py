@@ -105,8 +105,13 @@ def Initialize(pin: ParameterInput, opacity, scattering, eos, device: Optional[t
                     source_strategy=int(source_strategy), do_emission=int(do_emission),
                     do_feedback=int(do_feedback), rank=my_rank)
     e = _lib.Eos(model=eos.model, gm1=eos.gm1, cv=eos.cv)
-    o = _lib.Opacity(model=opacity.model, kappa=opacity.kappa, c=units.c, sb=units.sb)
-    s = _lib.Scattering(model=scattering.model, kappa_s=scattering.kappa_s, apm=scattering.apm)
+    scales = {k: float(getattr(opacity, k, 1.0)) for k in
+              ("time_scale", "mass_scale", "length_scale", "temperature_scale")}
+    o = _lib.Opacity(model=opacity.model, kappa=opacity.kappa, c=units.c, sb=units.sb, **scales)
+    scales_s = {k: float(getattr(scattering, k, 1.0)) for k in
+                ("time_scale", "mass_scale", "length_scale", "temperature_scale")}
+    s = _lib.Scattering(model=scattering.model, kappa_s=scattering.kappa_s, apm=scattering.apm,
+                        **scales_s)
     ctx = C.c_void_p()
     _lib.check(lib.jb_initialize(C.byref(p), C.byref(e), C.byref(o), C.byref(s),
                                  device.index or 0, C.byref(ctx)))

@@ -43,11 +43,29 @@ class EOS:
 
 @dataclass
 class Opacity:
-    """singularity::photons::Gray(kappa) in code units (reference mcblock.cpp:95-121)."""
+    """``NonCGSUnits<Gray | EPBremss>(opac, time, mass, length, temperature)`` (reference
+    mcblock.cpp:95-121, opacity.hpp:23-25): ``kappa`` is the Gray opacity in cm^2/g; the scales
+    are the deck's code -> CGS conversion factors (mcblock.cpp:84-91).  What the library receives
+    is in code units: kappa mass / length^2, and the constants of GetRuntimePhysicalConstants."""
     kappa: float
     model: int = OPAC_GRAY
-    c: float = constants.SPEED_OF_LIGHT
-    sb: float = constants.STEFAN_BOLTZMANN
+    time_scale: float = 1.0
+    mass_scale: float = 1.0
+    length_scale: float = 1.0
+    temperature_scale: float = 1.0
+
+    def __post_init__(self):
+        # sigma_code = rho_code (mass / length^3) kappa length
+        self.kappa = self.kappa * (self.mass_scale / (self.length_scale * self.length_scale))
+
+    @property
+    def c(self) -> float:
+        return constants.SPEED_OF_LIGHT * (self.time_scale / self.length_scale)
+
+    @property
+    def sb(self) -> float:   # erg cm^-2 s^-1 K^-4 = g s^-3 K^-4
+        return constants.STEFAN_BOLTZMANN * (self.time_scale ** 3 * self.temperature_scale ** 4 /
+                                             self.mass_scale)
 
     def GetRuntimePhysicalConstants(self):
         return self
@@ -55,10 +73,19 @@ class Opacity:
 
 @dataclass
 class Scattering:
-    """singularity::photons::GrayS(kappa_s, apm) (reference mcblock.cpp:126-145)."""
+    """``NonCGSUnitsS<GrayS | ThomsonS>`` (reference mcblock.cpp:126-145, opacity.hpp:28-30):
+    GrayS(kappa_s, apm) has sigma_s = (rho / apm) kappa_s; ThomsonS(apm) has kappa_s = sigma_T.
+    ``apm`` is passed on as the deck gives it (mcblock.cpp:124: "code units")."""
     kappa_s: float
     apm: float
     model: int = SCAT_GRAY
+    time_scale: float = 1.0
+    mass_scale: float = 1.0
+    length_scale: float = 1.0
+    temperature_scale: float = 1.0
+
+    def __post_init__(self):
+        self.kappa_s = self.kappa_s * (self.mass_scale / (self.length_scale * self.length_scale))
 
 
 @dataclass
@@ -85,25 +112,24 @@ def Initialize(pin: ParameterInput) -> McblockPackage:
     gamma = pin.GetOrAddReal("mcblock", "gamma", 1.66666666667)
     cv = pin.GetOrAddReal("mcblock", "cv", 1.0 / (gamma - 1.0))
     eos = EOS(gamma - 1.0, cv)
-    for key in ("time_scale", "mass_scale", "length_scale", "temperature_scale"):
-        if pin.GetOrAddReal("mcblock", key, 1.0) != 1.0:
-            raise NotImplementedError("non-CGS unit scales are not supported")
+    scales = {key: pin.GetOrAddReal("mcblock", key, 1.0)   # code -> CGS, mcblock.cpp:84-91
+              for key in ("time_scale", "mass_scale", "length_scale", "temperature_scale")}
     name = pin.GetString("mcblock", "opacity_model")
     if name == "none":
-        opacity = Opacity(0.0)
+        opacity = Opacity(0.0, **scales)
     elif name == "constant":
-        opacity = Opacity(pin.GetReal("mcblock", "opacity_constant_value"))
+        opacity = Opacity(pin.GetReal("mcblock", "opacity_constant_value"), **scales)
     elif name == "ep_bremss":
-        raise NotImplementedError("EPBremss opacity is not built (no stepdiff deck uses it)")
+        opacity = Opacity(0.0, model=OPAC_EPBREMSS, **scales)
     else:
         raise ValueError("Only none or constant opacity models supported!")
     apm = pin.GetOrAddReal("mcblock", "apm", 1.0)
     sname = pin.GetOrAddString("mcblock", "scattering_model", "none")
     if sname == "none":
-        scattering = Scattering(0.0, apm)
+        scattering = Scattering(0.0, apm, **scales)
     elif sname == "constant":
-        scattering = Scattering(pin.GetReal("mcblock", "scattering_constant_value"), apm)
-    else:
+        scattering = Scattering(pin.GetReal("mcblock", "scattering_constant_value"), apm, **scales)
+    else:   # (the reference's variant also holds ThomsonS, but its host cannot select it)
         raise ValueError("Only none or constant scattering models supported!")
     return McblockPackage(problem_id, t0, rho0, initial_radiation, eos, opacity, scattering)
 

@@ -50,6 +50,9 @@ void orc_math_sincos(const double *x, int n, double *sn, double *cs) {
 void orc_math_sincos2pi(const double *u, int n, double *sn, double *cs) {
   for (int i = 0; i < n; ++i) orc_sincos2pi(u[i], &sn[i], &cs[i]);
 }
+void orc_math_one_minus_exp_neg(const double *x, int n, double *out) {
+  for (int i = 0; i < n; ++i) out[i] = orc_one_minus_exp_neg(x[i]);
+}
 void orc_math_acos(const double *x, int n, double *out) {
   for (int i = 0; i < n; ++i) out[i] = orc_acos(x[i]);
 }
@@ -164,16 +167,46 @@ static inline double eos_temperature(const orc_params *P, double rho, double sie
   return t > 0.0 ? t : 0.0;
 }
 static inline double opac_absorption(const orc_params *P, double rho, double temp, double nu) {
-  (void)temp; (void)nu;
+  if (P->opac_model == 1) { /* EPBremss, orc.h */
+    if (!(temp > 0.0)) return 0.0;
+    const double g = orc_one_minus_exp_neg((P->ep_B * nu) / temp);
+    return ((P->ep_A * (rho * rho)) / sqrt(temp)) * (g / ((nu * nu) * nu));
+  }
   return rho * P->kappa_a;
 }
 static inline double opac_emissivity(const orc_params *P, double rho, double temp) {
+  if (P->opac_model == 1) return (P->ep_E * (rho * rho)) * sqrt(temp > 0.0 ? temp : 0.0);
   const double t2 = temp * temp;
   return (rho * P->kappa_a) * ((4.0 * P->sb) * (t2 * t2));
 }
 static inline double opac_scattering(const orc_params *P, double rho, double temp, double nu) {
   (void)temp; (void)nu;
   return (rho / P->apm) * P->kappa_s;
+}
+void orc_model_coefficients(const double scales[4], double out[4]) {
+  /* CGS, CODATA 2018: e (esu), m_e, m_p, h, k_B, c, sigma_Thomson */
+  const double qe = 4.803204712570263e-10, me = 9.1093837015e-28, mp = 1.67262192369e-24,
+               hp = 6.62607015e-27, kb = 1.380649e-16, cl = 2.99792458e10,
+               sigma_t = 6.6524587321e-25, pi = 3.14159265358979323846;
+  const double tau = scales[0], mu = scales[1], lam = scales[2], th = scales[3];
+  const double e6 = (qe * qe) * (qe * qe) * (qe * qe);
+  /* Rybicki & Lightman 5.18a and 5.15a, Z = 1, Gaunt factor 1 */
+  const double k_abs = (4.0 * e6) / (3.0 * me * hp * cl) * sqrt((2.0 * pi) / (3.0 * kb * me));
+  const double k_em = sqrt((2.0 * pi * kb) / (3.0 * me)) *
+                      ((32.0 * pi * e6) / (3.0 * hp * me * (cl * cl * cl)));
+  const double n_per_rho = (mu / (lam * lam * lam)) / mp; /* n_e = n_i per unit code density */
+  const double n2 = n_per_rho * n_per_rho, tau3 = tau * tau * tau;
+  out[0] = lam * k_abs * n2 / sqrt(th) * tau3;    /* alpha: 1/cm -> 1/length; nu^-3 -> tau^3 */
+  out[1] = hp / (kb * th * tau);                  /* x = h nu / k T */
+  out[2] = k_em * sqrt(th) * n2 * (tau3 * lam / mu); /* erg s^-1 cm^-3 -> code */
+  out[3] = sigma_t / (lam * lam);                 /* n_e = rho / apm, apm in code mass units */
+}
+void orc_model_eval(const orc_params *P, int which, const double *x, int n, double *out) {
+  for (int i = 0; i < n; ++i) {
+    const double rho = x[3 * i], temp = x[3 * i + 1], nu = x[3 * i + 2];
+    out[i] = which == 0 ? opac_absorption(P, rho, temp, nu)
+             : which == 1 ? opac_emissivity(P, rho, temp) : opac_scattering(P, rho, temp, nu);
+  }
 }
 
 /* ---------------------------------------------------------------------------------------- */

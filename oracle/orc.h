@@ -42,6 +42,12 @@ typedef struct orc_params {
   int32_t use_ddmc;
   int32_t do_emission;
   int32_t do_feedback;
+  /* absorption model: 0 Gray (kappa_a), 1 electron-proton bremsstrahlung in code units,
+   * sigma_a = A rho^2 T^-1/2 (1 - e^(-B nu / T)) nu^-3, j = E rho^2 T^1/2 (mcblock.cpp:108-113
+   * selects singularity-opac's EPBremss, which is not vendored: the published free-free formulas
+   * of Rybicki & Lightman 5.18a / 5.15a with Gaunt factor 1 stand in; see orc_model_coefficients) */
+  int32_t opac_model, pad_model;
+  double ep_A, ep_B, ep_E;
 } orc_params;
 
 /* Whole mesh (the oracle is single-process).  All cell/face fields are block-major arrays
@@ -83,12 +89,18 @@ void orc_math_log(const double *x, int n, double *out);
 void orc_math_sincos(const double *x, int n, double *sn, double *cs);
 void orc_math_sincos2pi(const double *u, int n, double *sn, double *cs); /* of 2 pi u */
 void orc_math_acos(const double *x, int n, double *out);
+void orc_math_one_minus_exp_neg(const double *x, int n, double *out);
 
 /* step functions driven by a tape of uniforms; `st` is an orc_step (orc_steps.h) laid out as
  * doubles/ints exactly as declared there.  Returns the number of uniforms consumed. */
 int orc_call_transport_step(void *st, const double *tape, int ntape);
 int orc_call_ddmc_step(void *st, const double *tape, int ntape);
 int orc_call_ddmc_albedo(void *st, const double *tape, int ntape);
+/* EPBremss A, B, E and the ThomsonS-as-GrayS kappa_s for the code -> CGS scales {time, mass,
+ * length, temperature} (mcblock.cpp:84-91) */
+void orc_model_coefficients(const double scales[4], double out[4]);
+/* which: 0 absorption(rho, T, nu), 1 emissivity(rho, T), 2 scattering(rho, T, nu); x = n triples */
+void orc_model_eval(const orc_params *P, int which, const double *x, int n, double *out);
 int orc_call_scatter(double vv, const double *tape, int ntape, double v[3]);
 int orc_call_face_iso_dir(double vv, const double *tape, int ntape, double v[3]);
 int orc_call_planck(double sb, double temp, const double *tape, int ntape, double *e);

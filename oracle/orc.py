@@ -34,7 +34,8 @@ class Params(C.Structure):
                 ("c", C.c_double), ("sb", C.c_double), ("cv", C.c_double),
                 ("kappa_a", C.c_double), ("kappa_s", C.c_double), ("apm", C.c_double),
                 ("seed", C.c_int32), ("use_ddmc", C.c_int32), ("do_emission", C.c_int32),
-                ("do_feedback", C.c_int32)]
+                ("do_feedback", C.c_int32), ("opac_model", C.c_int32), ("pad_model", C.c_int32),
+                ("ep_A", C.c_double), ("ep_B", C.c_double), ("ep_E", C.c_double)]
 
 
 class MeshC(C.Structure):
@@ -174,6 +175,34 @@ def math_sincos2pi(u):
     s, c = np.empty_like(u), np.empty_like(u)
     lib().orc_math_sincos2pi(_d(u), u.size, _d(s), _d(c))
     return s, c
+
+
+def math_one_minus_exp_neg(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().orc_math_one_minus_exp_neg(_d(x), x.size, _d(out))
+    return out
+
+
+def model_coefficients(time_scale=1.0, mass_scale=1.0, length_scale=1.0, temperature_scale=1.0):
+    """EPBremss coefficients in code units and the ThomsonS-as-GrayS kappa_s (orc.h)."""
+    sc = (C.c_double * 4)(time_scale, mass_scale, length_scale, temperature_scale)
+    out = (C.c_double * 4)()
+    lib().orc_model_coefficients(sc, out)
+    return dict(ep_A=out[0], ep_B=out[1], ep_E=out[2], kappa_s_thomson=out[3])
+
+
+def model_eval(params: dict, which: int, rho, temp, nu):
+    """which: 0 absorption coefficient, 1 emissivity, 2 scattering coefficient."""
+    P = Params()
+    for k, v in params.items():
+        setattr(P, k, v)
+    x = np.ascontiguousarray(np.stack([np.asarray(rho, dtype=np.float64),
+                                       np.asarray(temp, dtype=np.float64),
+                                       np.asarray(nu, dtype=np.float64)], axis=-1).reshape(-1, 3))
+    out = np.empty(x.shape[0])
+    lib().orc_model_eval(C.byref(P), int(which), _d(x), x.shape[0], _d(out))
+    return out
 
 
 def math_acos(x):

@@ -123,6 +123,31 @@ static inline double orc_pm_acos(double x) {
   }
 }
 
+/* 1 - exp(-x), x >= 0: the sequence of jb_math.hpp m_one_minus_exp_neg */
+static inline double orc_pm_one_minus_exp_neg(double x) {
+  static const double c[17] = {0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p-1,
+                               0x1.5555555555555p-3, 0x1.5555555555555p-5, 0x1.1111111111111p-7,
+                               0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-16,
+                               0x1.71de3a556c734p-19, 0x1.27e4fb7789f5cp-22, 0x1.ae64567f544e4p-26,
+                               0x1.1eed8eff8d898p-29, 0x1.6124613a86d09p-33, 0x1.93974a8c07c9dp-37,
+                               0x1.ae7f3e733b81fp-41, 0x1.ae7f3e733b81fp-45};
+  if (!(x < 40.0)) return 1.0;
+  if (x < 0.25) {
+    const double z = -x;
+    double q = c[14];
+    for (int n = 13; n >= 1; --n) q = fma(q, z, c[n]);
+    return x * q;
+  }
+  const double kf = floor(fma(x, 0x1.71547652b82fep+0, 0.5));
+  double r = fma(kf, -0x1.62e42fee00000p-1, x);
+  r = fma(kf, -0x1.a39ef35793c76p-33, r);
+  const double z = -r;
+  double p = c[16];
+  for (int n = 15; n >= 0; --n) p = fma(p, z, c[n]);
+  const double scale = orc_u2d((uint64_t)(1023 - (int)kf) << 52);
+  return 1.0 - p * scale;
+}
+
 /* ---- dispatch ---------------------------------------------------------------------------- */
 static inline double orc_log(double x) {
   return orc_math_mode == ORC_MATH_LIBM ? log(x) : orc_pm_log(x);
@@ -148,6 +173,9 @@ static inline void orc_sincos2pi(double u, double *sn, double *cs) {
 }
 static inline double orc_acos(double x) {
   return orc_math_mode == ORC_MATH_LIBM ? acos(x) : orc_pm_acos(x);
+}
+static inline double orc_one_minus_exp_neg(double x) {
+  return orc_math_mode == ORC_MATH_LIBM ? -expm1(-x) : orc_pm_one_minus_exp_neg(x);
 }
 /* T^4: std::pow(T, 4.0) in the reference (sourcing.cpp:93); portable flavour = (T*T)*(T*T) */
 static inline double orc_pow4(double t) {

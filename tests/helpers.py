@@ -29,11 +29,24 @@ def load_deck(name: str, overrides=None) -> ParameterInput:
 
 
 def oracle_params(pin: ParameterInput, pkg) -> dict:
+    from jaybenne_amd.mcblock import OPAC_EPBREMSS, SCAT_THOMSON
+    model = {}
+    kappa_s = pkg.scattering.kappa_s
+    if pkg.opacity.model == OPAC_EPBREMSS or pkg.scattering.model == SCAT_THOMSON:
+        from oracle import orc
+        o = pkg.opacity
+        if pkg.opacity.model == OPAC_EPBREMSS:
+            co = orc.model_coefficients(o.time_scale, o.mass_scale, o.length_scale, o.temperature_scale)
+            model = dict(opac_model=1, ep_A=co["ep_A"], ep_B=co["ep_B"], ep_E=co["ep_E"])
+        if pkg.scattering.model == SCAT_THOMSON:
+            sc = pkg.scattering
+            kappa_s = orc.model_coefficients(sc.time_scale, sc.mass_scale, sc.length_scale,
+                                             sc.temperature_scale)["kappa_s_thomson"]
     return dict(num_particles=pin.GetInteger("jaybenne", "num_particles"),
                 dt=pin.GetReal("jaybenne", "dt"),
                 tau_ddmc=pin.GetOrAddReal("jaybenne", "tau_ddmc", 5.0),
-                c=constants.SPEED_OF_LIGHT, sb=constants.STEFAN_BOLTZMANN, cv=pkg.eos.cv,
-                kappa_a=pkg.opacity.kappa, kappa_s=pkg.scattering.kappa_s, apm=pkg.scattering.apm,
+                c=pkg.opacity.c, sb=pkg.opacity.sb, cv=pkg.eos.cv,
+                kappa_a=pkg.opacity.kappa, kappa_s=kappa_s, apm=pkg.scattering.apm, **model,
                 seed=pin.GetOrAddInteger("jaybenne", "seed", 123),
                 use_ddmc=int(pin.GetOrAddBoolean("jaybenne", "use_ddmc", False)),
                 do_emission=int(pin.GetOrAddBoolean("jaybenne", "do_emission", True)),

@@ -339,6 +339,72 @@ def test_per_event_opacity_path_bit_exact(gpu_device, deck, overrides, monkeypat
     assert drv.md.events == O.events
 
 
+EPBREMSS = {"mcblock/opacity_model": "ep_bremss", "mcblock/mass_scale": 1e-9,
+            "mcblock/scattering_constant_value": 1e12, "jaybenne/num_particles": 4000,
+            "jaybenne/do_emission": "true", "jaybenne/do_feedback": "false"}
+
+
+@pytest.mark.parametrize("deck,extra", [
+    ("stepdiff", {}),
+    ("stepdiff_ddmc", {"mcblock/scattering_constant_value": 3e15}),
+    ("stepdiff_smr", {"jaybenne/num_particles": 20000})])
+def test_epbremss_opacity_bit_exact(gpu_device, deck, extra):
+    """The frequency-dependent absorption model (mcblock.cpp:108-113, opacity.hpp:25): opacities
+    from rho, T and the photon's energy at every event, emission from its frequency-integrated
+    emissivity, non-trivial code -> CGS scales -- same bits as the oracle's statement of the same
+    formulas (include/jaybenne_amd.h; singularity-opac itself is not vendored)."""
+    from oracle import orc
+    over = dict(EPBREMSS, **extra)
+    pin = load_deck(deck, over)
+    drv = _gpu_problem(pin, gpu_device)
+    O, mesh, _ = make_oracle(load_deck(deck, over), orc.MATH_PORTABLE)
+    # (no feedback: the material state never sees the order of the absorption atomics, so the
+    # particles stay bit-identical over the cycles; compaction reorders the survivors)
+    for _ in range(2):
+        drv.Step()
+    run_oracle_cycles(O, pin, 2)
+    _compare_swarm_by_id(drv.md, O)
+    _compare_fields(drv.md, O, ("tally", "fleck", "src_num", "src_ew"))
+    assert drv.md.events == O.events
+    assert drv.md.stats()["n_absorbed"] > 500 and O.n > 100   # absorbing, not everything absorbed
+
+
+def test_model_coefficients_and_functions(gpu_device):
+    """jb_initialize's EPBremss / ThomsonS coefficients and the device functions against the
+    oracle's: same doubles."""
+    from oracle import orc
+    from jaybenne_amd import _lib
+    lib = _lib.load()
+    scales = dict(time_scale=3e-9, mass_scale=2e-7, length_scale=0.5, temperature_scale=1.1e3)
+    p, e = _lib.Params(num_particles=10, dt=1.0), _lib.Eos(model=0, gm1=0.6, cv=1.5)
+    o = _lib.Opacity(model=1, kappa=0.0, c=3e10, sb=5.67e-5, **scales)
+    s = _lib.Scattering(model=1, kappa_s=0.0, apm=1.3, **scales)
+    ctx = C.c_void_p()
+    assert lib.jb_initialize(C.byref(p), C.byref(e), C.byref(o), C.byref(s), 0, C.byref(ctx)) == _lib.JB_COMPLETE
+    out = (C.c_double * 4)()
+    assert lib.jb_debug_model_coefficients(ctx, C.byref(out)) == _lib.JB_COMPLETE
+    co = orc.model_coefficients(**scales)
+    assert [out[0], out[1], out[2], out[3]] == [co["ep_A"], co["ep_B"], co["ep_E"], co["kappa_s_thomson"]]
+    rng = np.random.default_rng(11)
+    n = 20000
+    x = np.stack([10 ** rng.uniform(-3, 3, n), 10 ** rng.uniform(-2, 4, n), 10 ** rng.uniform(-4, 12, n)], axis=1)
+    x[:50, 1] = 0.0      # T = 0
+    P = dict(opac_model=1, ep_A=co["ep_A"], ep_B=co["ep_B"], ep_E=co["ep_E"],
+             kappa_s=co["kappa_s_thomson"], apm=1.3)
+    orc.set_math_mode(orc.MATH_PORTABLE)
+    for which in (0, 1, 2):
+        got = np.empty(n)
+        assert lib.jb_debug_model_eval(ctx, which, np.ascontiguousarray(x).ctypes.data, n, got.ctypes.data) == _lib.JB_COMPLETE
+        want = orc.model_eval(P, which, x[:, 0], x[:, 1], x[:, 2])
+        assert np.array_equal(got, want), which
+    # 1 - exp(-x)
+    xs = np.concatenate([10 ** rng.uniform(-300, 2, 50000), rng.uniform(0, 45, 50000), [0.0, 0.25, 40.0, 1e300]])
+    got = np.empty_like(xs)
+    assert lib.jb_debug_math(ctx, 11, xs.ctypes.data, xs.size, got.ctypes.data) == _lib.JB_COMPLETE
+    assert np.array_equal(got, orc.math_one_minus_exp_neg(xs))
+    lib.jb_finalize(ctx)
+
+
 def test_absorption_emission_feedback_bit_exact(gpu_device):
     """Absorbing, emitting material with feedback (the inf.in regime): exercises absorption
     tallies, removal/compaction, the emission source and UpdateFluid."""
@@ -569,9 +635,12 @@ def test_c_abi_error_paths(gpu_device):
                              None, None) == _lib.JB_COMPLETE
     # unsupported opacity model is rejected at Initialize
     p, e = _lib.Params(num_particles=10, dt=1.0), _lib.Eos(model=0, gm1=0.6, cv=1.5)
-    o, s = _lib.Opacity(model=1, kappa=0.0, c=3e10, sb=5.67e-5), _lib.Scattering(model=0, kappa_s=1.0, apm=1.0)
+    o, s = _lib.Opacity(model=7, kappa=0.0, c=3e10, sb=5.67e-5), _lib.Scattering(model=0, kappa_s=1.0, apm=1.0)
     ctx = C.c_void_p()
     assert lib.jb_initialize(C.byref(p), C.byref(e), C.byref(o), C.byref(s), 0, C.byref(ctx)) == _lib.JB_ERR_UNSUPPORTED
+    # ... and EPBremss without its code -> CGS scales
+    o = _lib.Opacity(model=1, kappa=0.0, c=3e10, sb=5.67e-5)
+    assert lib.jb_initialize(C.byref(p), C.byref(e), C.byref(o), C.byref(s), 0, C.byref(ctx)) == _lib.JB_ERR_INVALID
     # the energy source strategy is accepted by Initialize and rejected by SourcePhotons (sourcing.cpp:38)
     pin = load_deck("stepdiff", {"jaybenne/source_strategy": "energy", "jaybenne/num_particles": 100})
     with pytest.raises(NotImplementedError, match="Energy source strategy"):

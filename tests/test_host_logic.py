@@ -245,3 +245,20 @@ def test_transverse_average_and_energy_matching():
     smr = Mesh.from_deck(load_deck("stepdiff_smr"))
     with pytest.raises(ValueError):
         analysis.analytic_errors(smr, smr.new_field(1.0), t, transverse_average=True)
+
+
+def test_mcblock_unit_scales_and_epbremss_deck():
+    """mcblock.cpp:84-121: the code -> CGS scales reach every model; ep_bremss is selectable,
+    ThomsonS is not (the reference's host cannot select it either)."""
+    sc = {"mcblock/time_scale": 2.0, "mcblock/mass_scale": 3.0, "mcblock/length_scale": 5.0,
+          "mcblock/temperature_scale": 7.0}
+    pkg = mcblock.Initialize(load_deck("stepdiff", dict(sc, **{"mcblock/opacity_model": "constant",
+                                                                "mcblock/opacity_constant_value": 4.0})))
+    assert pkg.opacity.kappa == pytest.approx(4.0 * 3.0 / 25.0)
+    assert pkg.scattering.kappa_s == pytest.approx(1.0e3 * 3.0 / 25.0)
+    assert pkg.opacity.c == pytest.approx(2.99792458e10 * 2.0 / 5.0)
+    assert pkg.opacity.sb == pytest.approx(5.670373e-5 * 8.0 * 7.0 ** 4 / 3.0)
+    pkg = mcblock.Initialize(load_deck("stepdiff", dict(sc, **{"mcblock/opacity_model": "ep_bremss"})))
+    assert pkg.opacity.model == mcblock.OPAC_EPBREMSS and pkg.opacity.mass_scale == 3.0
+    with pytest.raises(ValueError, match="scattering models"):
+        mcblock.Initialize(load_deck("stepdiff", {"mcblock/scattering_model": "thomson"}))

@@ -79,3 +79,48 @@ def test_exact_values():
     assert list(c) == [0.0, -1.0, 0.0] and list(s) == [1.0, 0.0, -1.0]
     assert orc.math_acos(np.array([1.0]))[0] == 0.0
     assert orc.math_acos(np.array([-1.0]))[0] == np.pi
+
+
+def test_one_minus_exp_neg_close_to_libm():
+    """1 - exp(-x) (EPBremss stimulated-emission factor): the specified sequence is within 4 ulp
+    of -expm1(-x) and exact at its edges."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([10 ** rng.uniform(-300, 2, 200000), rng.uniform(0.0, 45.0, 200000),
+                        np.linspace(0.24, 0.26, 20001)])
+    a, b = _both(orc.math_one_minus_exp_neg, x)
+    assert _ulp_diff(a, -np.expm1(-x)).max() <= 1.0     # (numpy's expm1 is not glibc's)
+    assert _ulp_diff(a, b).max() <= 4.0
+    orc.set_math_mode(orc.MATH_PORTABLE)
+    assert list(orc.math_one_minus_exp_neg(np.array([0.0, 40.0, 1e300, np.inf]))) == [0.0, 1.0, 1.0, 1.0]
+
+
+def test_epbremss_model_is_consistent():
+    """The stand-in for singularity-opac's EPBremss: Kirchhoff's law ties the absorption
+    coefficient to the frequency-integrated emissivity (4 pi int alpha_nu B_nu dnu = j), the CGS
+    coefficients are Rybicki & Lightman's 3.692e8 / 1.426e-27, and the code -> CGS scales commute
+    with the evaluation."""
+    h, kb, cl, mp = 6.62607015e-27, 1.380649e-16, 2.99792458e10, 1.67262192369e-24
+    co = orc.model_coefficients()
+    assert abs(co["ep_A"] * mp * mp / 3.692e8 - 1.0) < 2e-4
+    assert abs(co["ep_E"] * mp * mp / 1.426e-27 - 1.0) < 4e-4
+    assert abs(co["kappa_s_thomson"] / 6.6524587e-25 - 1.0) < 1e-8
+    P = dict(opac_model=1, ep_A=co["ep_A"], ep_B=co["ep_B"], ep_E=co["ep_E"], kappa_s=0.0, apm=1.0)
+    orc.set_math_mode(orc.MATH_PORTABLE)
+    for rho, T in ((1e-3, 1e6), (2.0, 3e4)):
+        nu = np.logspace(6, 19, 200001)
+        al = orc.model_eval(P, 0, np.full_like(nu, rho), np.full_like(nu, T), nu)
+        B = 2 * h * nu ** 3 / cl ** 2 / np.expm1(np.minimum(h * nu / (kb * T), 700.0))
+        f = al * B
+        j = 4 * np.pi * np.sum(0.5 * (f[1:] + f[:-1]) * np.diff(nu))
+        assert abs(j / orc.model_eval(P, 1, [rho], [T], [1.0])[0] - 1.0) < 1e-6
+    tau, mu, lam, th = 3e-9, 2e-7, 0.5, 1.1e3
+    cs = orc.model_coefficients(tau, mu, lam, th)
+    Ps = dict(opac_model=1, ep_A=cs["ep_A"], ep_B=cs["ep_B"], ep_E=cs["ep_E"], kappa_s=0.0, apm=1.0)
+    rho, T, nu = 3.0, 40.0, 2.5e4
+    a_code = orc.model_eval(Ps, 0, [rho], [T], [nu])[0]
+    a_cgs = orc.model_eval(P, 0, [rho * mu / lam ** 3], [T * th], [nu / tau])[0]
+    assert abs(a_code / (a_cgs * lam) - 1.0) < 1e-13
+    j_code = orc.model_eval(Ps, 1, [rho], [T], [nu])[0]
+    j_cgs = orc.model_eval(P, 1, [rho * mu / lam ** 3], [T * th], [1.0])[0]
+    assert abs(j_code / (j_cgs * tau ** 3 * lam / mu) - 1.0) < 1e-13
+    assert abs(cs["kappa_s_thomson"] * lam ** 2 / co["kappa_s_thomson"] - 1.0) < 1e-15
