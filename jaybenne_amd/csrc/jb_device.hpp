@@ -135,7 +135,7 @@ __device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
 // The same from a copy of the per-block tables in LDS (kernels whose service phase would wait
 // for these small dependent loads behind its own stores: vector-memory operations complete in
 // issue order, LDS reads have their own counter).  Up to kLdsBlocks resident blocks.
-constexpr int kLdsBlocks = 256;
+constexpr int kLdsBlocks = 128;
 struct LdsBlockTable {
   double xmin[kLdsBlocks][3], dx[kLdsBlocks][3], inv_dx[kLdsBlocks][3];
   double *tally[kLdsBlocks];

@@ -293,7 +293,9 @@ __device__ __forceinline__ bool ddmc_step_event(Step &s, Rng &rng) {
   const double leak_tot = leakx_l + leakx_u + leaky_l + leaky_u + leakz_l + leakz_u;
 
   const double cdf_ddmc = s.ffaa + leak_tot + rmin;
-  const double dt_ddmc = -m_log(rng.drand()) / (s.vv * cdf_ddmc);
+  // (-ln u in [1e-16, 37], c cdf in [c DBL_MIN, ~1e30]: inside the range where the lean division
+  // sequence of jb_math.hpp gives the IEEE quotient -- no scaling or fix-up step needed)
+  const double dt_ddmc = m_div(-m_log(rng.drand()), s.vv * cdf_ddmc);
   const double dt_end = (s.t_start + s.dt) - s.t;
   const bool is_ddmc_event = dt_ddmc < dt_end;
 
