@@ -121,6 +121,7 @@ def accuracy(device, threads: int):
     from oracle import orc
     ov = {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128}
     drv = mcblock.McblockDriver(load_deck("stepdiff", ov), device=device)
+    arithmetic = drv.pkg.arithmetic()
     drv.Execute()
     sl = drv.mesh.interior()
     g = drv.md.get_field("tally")
@@ -138,12 +139,14 @@ def accuracy(device, threads: int):
     return {"config": "BASELINE configs[0]: stepdiff 1-D, 128 cells, 1e5 photons, 10 cycles",
             "metric": "weighted mean fractional error vs the analytic erf profile "
                       "(tst/regression_test.py:383-406), gate 0.05",
+            "arithmetic": arithmetic,
             "gpu_error": e_gpu, "cpu_libm_error": e_cpu, "gate": 0.05,
             "gpu_minus_cpu": e_gpu - e_cpu,
             "max_cell_difference_in_sigma": float(z.max()),
             "rms_cell_difference_in_sigma": float(np.sqrt((z * z).mean())),
-            "note": "same random streams; the HIP path evaluates log / sincos by table, the CPU "
-                    "path by libm (<= 1 ulp, <= 9e-16 apart): a history parts ways with its twin "
+            "note": "same random streams; the HIP path evaluates log / sincos by table and (lean "
+                    "arithmetic, the default) face distances / position updates within 2 ulp of "
+                    "the CPU path's libm / IEEE operations: a history parts ways with its twin "
                     "only where a last-bit difference flips a branch, and the tally moves only if "
                     "that photon ends the cycle in another cell.  Stated tolerance "
                     "(tests/test_gpu_accuracy.py): gpu_error <= cpu_libm_error + 0.01 and every "
@@ -188,6 +191,8 @@ def main() -> None:
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c3-1d", "c4", "c5"],
                     help="c2 = headline (BASELINE configs[1]); c3* = DDMC side measurements")
     ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--arithmetic", choices=("lean", "exact"), default=None,
+                    help="arithmetic of the gray IMC tracking step (default: the library's, lean)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -230,6 +235,8 @@ def main() -> None:
             comm.barrier()
             torch.cuda.synchronize(device)
 
+    if args.arithmetic is not None:
+        drv.pkg.set_arithmetic(args.arithmetic)
     for _ in range(args.warmup):
         drv.Step()
     if os.environ.get("JB_PHASE_TIMES"):     # diagnostic: per-phase wall time (adds syncs)
@@ -250,6 +257,26 @@ def main() -> None:
         wall = comm.allreduce_max_float(wall)
         histories, events = (int(v) for v in comm.allreduce_sum_int64(np.array([histories, events])))
 
+    # the other arithmetic variant of the gray IMC kernel, one step, for the record (1 GPU only;
+    # outside the timed region above)
+    other = None
+    main_variant = md.lib.jb_last_transport_variant(md.handle).decode()
+    main_stats = md.stats()
+    if args.gpus == 1 and not md.pkg.Param("use_ddmc"):
+        kept = list(md.kernel_events)
+        mode = md.pkg.arithmetic()
+        md.pkg.set_arithmetic("exact" if mode == "lean" else "lean")
+        n_before = md.n
+        sync_all()
+        t1 = time.perf_counter()
+        drv.Step()
+        sync_all()
+        other = {"arithmetic": md.pkg.arithmetic(), "ms_per_step": 1e3 * (time.perf_counter() - t1),
+                 "value": n_before / (time.perf_counter() - t1), "steps": 1,
+                 "kernel": md.lib.jb_last_transport_variant(md.handle).decode()}
+        md.pkg.set_arithmetic(mode)
+        md.kernel_events = kept
+
     # hand-off statistics of the timed steps (all ranks): records are 104 bytes
     handoff_records = int(getattr(md, "handoff_records", 0))
     exchange_s = float(getattr(md, "exchange_seconds", 0.0))
@@ -268,7 +295,7 @@ def main() -> None:
         ddmc_bound = args.workload in ("c3", "c3-1d")            # the two regimes
         per_event = 72.0 if args.workload in ("c3", "c3-1d", "c5") else BYTES_PER_EVENT_IMC
         k_bytes = k_hist * BYTES_PER_HISTORY + k_events * per_event
-        variant = md.lib.jb_last_transport_variant(md.handle).decode()
+        variant = main_variant
         variant = ("TransportPhotons_DDMC: " if md.pkg.Param("use_ddmc") else "TransportPhotons: ") + variant
         # counters of this very command under rocprofv3 (separate --pmc passes), if a committed
         # summary matches workload and size: labelled as read from that file, not measured now
@@ -363,8 +390,16 @@ def main() -> None:
                         "note": "particles handed to another rank (all ranks summed); exchange = "
                                 "count kernel + read-back + count all-gather + pack + all-to-all-v "
                                 "+ unpack, wall time on the slowest rank"},
-            "kernel_diagnostics": md.stats(),
+            "kernel_diagnostics": main_stats,
             "roofline": roof,
+            "arithmetic": {"mode": md.pkg.arithmetic(),
+                           "note": "gray IMC tracking step: 'lean' (default) = face distance by a "
+                                   "once-refined reciprocal, fused position update, uncompensated "
+                                   "log, each within 2 ulp of 'exact', whose results equal the CPU "
+                                   "oracle's bit for bit; stated tolerance of lean: every particle "
+                                   "attribute within 1e-9 after full cycles, integer attributes "
+                                   "equal (tests/test_gpu_lean.py); DDMC / hybrid kernels: exact only",
+                           "other_variant": other},
         }
         if md.phase_times is not None:
             out["phase_ms_per_step"] = {k: 1e3 * v / args.steps for k, v in md.phase_times.items()}

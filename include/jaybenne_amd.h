@@ -210,9 +210,25 @@ jb_status jb_transport_photons(jb_context *ctx, jb_mesh *mesh, const jb_swarm_vi
 jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
                                     double t_start, double dt, int64_t first, int64_t last,
                                     int fuse_census_tally);
+/* Arithmetic of the tracking step of the gray IMC kernels (the headline path).
+ *   JB_ARITH_EXACT: every operation is the one the CPU oracle's portable flavour performs --
+ *     correctly rounded quotients, the reference's unfused position update -- and the particles
+ *     come out bit-identical to it.
+ *   JB_ARITH_LEAN (default): distance to a face as numerator times a once-refined reciprocal,
+ *     time step as distance times 1/c, position update as one fused multiply-add per axis,
+ *     logarithm without its compensated sum: each within 2 ulp of the exact variant's result,
+ *     ~8 % fewer instructions.  Stated tolerance (tests/test_gpu_lean.py): after full cycles
+ *     every particle attribute within 1e-9 (relative; positions relative to the domain size) of
+ *     the exact variant's and of the oracle's, integer attributes equal.
+ * The DDMC / hybrid / per-event-opacity kernels have the exact arithmetic only.  JB_EXACT_ARITH=1
+ * in the environment makes exact the default of jb_initialize. */
+enum { JB_ARITH_EXACT = 0, JB_ARITH_LEAN = 1 };
+jb_status jb_set_arithmetic(jb_context *ctx, int mode);
+int jb_get_arithmetic(const jb_context *ctx);
 /* the k_transport instantiation the last transport call on this mesh launched, e.g.
- * "k_transport<3, true, 2, true>" = <NDIM, TALLY (census tally fused), GRAY (0 per-event
- * opacities, 1 gray, 2 gray without absorption), EXACT (exact cell-face arithmetic)>; "" before
+ * "k_transport<3, true, 2, true, true>" = <NDIM, TALLY (census tally fused), GRAY (0 per-event
+ * opacities, 1 gray, 2 gray without absorption), EXACT (exact cell-face arithmetic), LEAN (lean
+ * arithmetic)>; "" before
  * the first launch.  jb_mesh_exact_geometry: 1 if every resident block has power-of-two cell
  * widths and a lower corner that is a whole number of them. */
 const char *jb_last_transport_variant(const jb_mesh *mesh);

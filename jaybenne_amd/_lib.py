@@ -49,6 +49,8 @@ class Scattering(C.Structure):
                 ("length_scale", C.c_double), ("temperature_scale", C.c_double)]
 
 
+ARITH_EXACT, ARITH_LEAN = 0, 1   # enum of jb_set_arithmetic
+
 FIELD_IDS = {"rho": 0, "sie": 1, "u": 2, "fleck": 3, "tally": 4, "edelta": 5}   # enum jb_field
 FIELD_NAMES = ("rho", "sie", "u", "fleck", "tally", "edelta", "src_ew", "src_num", "P1", "P2", "P3")
 
@@ -133,6 +135,8 @@ PROTOTYPES = {
     "jb_debug_seed_state": (_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jb_debug_stream_start": (_int, [_vp, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jb_debug_draw_stream": (_int, [_vp, C.c_uint64, _int, _vp, C.POINTER(C.c_uint64)]),
+    "jb_set_arithmetic": (_int, [_vp, _int]),
+    "jb_get_arithmetic": (_int, [_vp]),
     "jb_debug_math": (_int, [_vp, _int, _vp, _int, _vp]),
     "jb_debug_model_coefficients": (_int, [_vp, C.POINTER(C.c_double * 4)]),
     "jb_debug_model_eval": (_int, [_vp, _int, _vp, _int, _vp]),

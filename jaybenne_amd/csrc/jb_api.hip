@@ -51,6 +51,9 @@ struct jb_context {
   unsigned long long *counters_h = nullptr;   // pinned
   long long *scratch_d = nullptr;             // holes / movers / small tables
   size_t scratch_words = 0;
+  // arithmetic of the gray IMC tracking step: lean (default) or exact (JB_EXACT_ARITH=1 in the
+  // environment at jb_initialize, or jb_set_arithmetic)
+  bool lean_arith = true;
 };
 constexpr int kCounterWords = 1024;  // CNT_N.. | 16..17 cursors | 32.. per-rank counts (<= 480 ranks)
 constexpr int kCursorBase = 16;
@@ -125,6 +128,10 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   ctx->eos = *eos;
   ctx->opac = *opacity;
   ctx->scat = *scattering;
+  {
+    const char *ex = getenv("JB_EXACT_ARITH");
+    ctx->lean_arith = !(ex && ex[0] == '1');
+  }
   ctx->dp.key0 = (uint32_t)params->seed;  // RngPool rng_pool(seed): unadjusted (quirk 1)
   ctx->dp.use_ddmc = params->use_ddmc;
   ctx->dp.do_feedback = params->do_feedback;
@@ -605,28 +612,35 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
   if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) per_cu_env = atoi(e);
   const bool gray = M.lam_abs != nullptr;
   (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream);
-#define JB_LAUNCH_X(T, G, X)                                                                       \
+#define JB_LAUNCH_X(T, G, X, L)                                                                    \
   do {                                                                                             \
     int occ = 0;                                                                                   \
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_transport<NDIM, DDMC, T, G, X>,       \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_transport<NDIM, DDMC, T, G, X, L>,    \
                                                      kBlock, 0) != hipSuccess || occ < 1)          \
       occ = 3;                                                                                     \
     const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
     const int *pair_flag = (DDMC && G != 0 && M.nblocks <= kLdsBlocks) ? M.not_all_ddmc : nullptr; \
-    hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G, X>), dim3(g), dim3(kBlock), 0, ctx->stream,  \
-                       M, ctx->dp, S, t_start, dt, first, last, ctx->counters_d, pair_flag);       \
-    mesh->last_variant = NDIM == 1 ? "k_transport<1, " #T ", " #G ", " #X ">"                      \
-                         : NDIM == 2 ? "k_transport<2, " #T ", " #G ", " #X ">"                    \
-                                     : "k_transport<3, " #T ", " #G ", " #X ">";                   \
+    hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G, X, L>), dim3(g), dim3(kBlock), 0,            \
+                       ctx->stream, M, ctx->dp, S, t_start, dt, first, last, ctx->counters_d,      \
+                       pair_flag);                                                                 \
+    mesh->last_variant = NDIM == 1 ? "k_transport<1, " #T ", " #G ", " #X ", " #L ">"              \
+                         : NDIM == 2 ? "k_transport<2, " #T ", " #G ", " #X ", " #L ">"            \
+                                     : "k_transport<3, " #T ", " #G ", " #X ", " #L ">";           \
   } while (0)
-  // (variant string: NDIM, TALLY, GRAY, EXACT; the DDMC flag is the entry point that was called)
+  // (variant string: NDIM, TALLY, GRAY, EXACT geometry, LEAN arithmetic; the DDMC flag is the
+  // entry point that was called)
 #define JB_LAUNCH(T, G)                                                                            \
   do {                                                                                             \
     if constexpr (!DDMC && G != 0) {                                                               \
-      if (mesh->exact_geom) JB_LAUNCH_X(T, G, true);                                               \
-      else JB_LAUNCH_X(T, G, false);                                                               \
+      if (mesh->exact_geom) {                                                                      \
+        if (ctx->lean_arith) JB_LAUNCH_X(T, G, true, true);                                        \
+        else JB_LAUNCH_X(T, G, true, false);                                                       \
+      } else {                                                                                     \
+        if (ctx->lean_arith) JB_LAUNCH_X(T, G, false, true);                                       \
+        else JB_LAUNCH_X(T, G, false, false);                                                      \
+      }                                                                                            \
     } else {                                                                                       \
-      JB_LAUNCH_X(T, G, false);                                                                    \
+      JB_LAUNCH_X(T, G, false, false);                                                             \
     }                                                                                              \
   } while (0)
   mesh->last_pair = "";
@@ -718,6 +732,14 @@ extern "C" const char *jb_last_transport_variant(const jb_mesh *mesh) {
   return mesh->last_variant;
 }
 extern "C" int jb_mesh_exact_geometry(const jb_mesh *mesh) { return mesh && mesh->exact_geom; }
+extern "C" jb_status jb_set_arithmetic(jb_context *ctx, int mode) {
+  if (!ctx || (mode != JB_ARITH_EXACT && mode != JB_ARITH_LEAN)) return fail(JB_ERR_INVALID, "bad argument");
+  ctx->lean_arith = mode == JB_ARITH_LEAN;
+  return JB_COMPLETE;
+}
+extern "C" int jb_get_arithmetic(const jb_context *ctx) {
+  return ctx && ctx->lean_arith ? JB_ARITH_LEAN : JB_ARITH_EXACT;
+}
 
 static jb_status fetch_counters(jb_context *ctx) {
   JB_HIP(hipMemcpyAsync(ctx->counters_h, ctx->counters_d, sizeof(unsigned long long) * kRankBase,

@@ -110,6 +110,13 @@ __device__ __forceinline__ double m_rcp_refined(double b) {
   e = fma(-b, y, 1.0);
   return fma(y, e, y);
 }
+// Lean arithmetic (the opt-out-able default of the gray IMC kernels):
+// a reciprocal with ONE Newton step (relative error <= 2^-51 instead of the correctly rounded
+// quotient's 2^-53) ...
+__device__ __forceinline__ double m_rcp_once(double b) {
+  const double y = __builtin_amdgcn_rcp(b);
+  return fma(y, fma(-b, y, 1.0), y);
+}
 __device__ __forceinline__ double m_div_r(double a, double b, double y) {  // y = m_rcp_refined(b)
   const double q = a * y;
   const double r = fma(-b, q, a);
@@ -142,6 +149,31 @@ __device__ __forceinline__ double m_log(double x) {  // x positive, finite, norm
   p = m_fma(r, p, 1.0 / 3.0);
   p = m_fma(r, p, -0.5);
   return fma(r2, p, lo) + hi;
+}
+
+// ... and the logarithm without the compensated low-order sum: k ln2 + log c + (r + r^2 P(r))
+// added in plain double (error <= 2 ulp of the result for the arguments in (0, 1) the kernels
+// feed it; next to x = 1 the table row is {1, 0, 0} and the result is r + r^2 P(r) itself).
+__device__ __forceinline__ double m_log_lean(double x) {
+  constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const uint32_t hx = (uint32_t)__double2hiint(x);
+  const uint32_t th = hx - (uint32_t)(JB_LOG_OFF >> 32);
+  const int i = (int)((th >> 13) & (JB_LOG_N - 1));
+  const int k = (int)th >> 20;
+  const double z = __hiloint2double((int)(hx - (th & 0xfff00000u)), __double2loint(x));
+  const double invc = lds_log_tab[i][0], lc_hi = lds_log_tab[i][1], lc_lo = lds_log_tab[i][2];
+  const double r = fma(z, invc, -1.0);
+  const double kd = (double)k;
+  const double w = fma(kd, ln2_hi, lc_hi);
+  const double wl = fma(kd, ln2_lo, lc_lo);
+  const double r2 = r * r;
+  double p = m_fma(r, -0.125, 1.0 / 7.0);
+  p = m_fma(r, p, -1.0 / 6.0);
+  p = m_fma(r, p, 0.2);
+  p = m_fma(r, p, -0.25);
+  p = m_fma(r, p, 1.0 / 3.0);
+  p = m_fma(r, p, -0.5);
+  return w + (wl + fma(r2, p, r));
 }
 
 __device__ __forceinline__ void m_sincos(double x, double &sn, double &cs) {  // 0 <= x <= 2 pi

@@ -189,7 +189,14 @@ struct ImcCell {
   double xl, xu, yl, yu, zl, zu;  // faces
   double fdx, fdy, fdz;           // eps_imc_offset * (upper - lower)
 };
-template <int NDIM, bool NOABS, class Rng>
+//  * LEAN: the same step in lean arithmetic -- distance to a face as (c (face - x)) times a
+//    once-refined reciprocal of the velocity component, time step as distance times 1/c, position
+//    update as one fused multiply-add per axis, logarithm without its compensated sum.  Every
+//    operation is within 2 ulp of the exact variant's (whose quotients are correctly rounded and
+//    whose position update rounds twice); a history parts ways with its exact twin only where
+//    such a difference flips a comparison.  A zero velocity component still yields NaN in the
+//    reciprocal's Newton step and v_min_f64 ignores it.
+template <int NDIM, bool NOABS, bool LEAN = false, class Rng>
 __device__ __forceinline__ void imc_step_fast(const ImcCell &c, double vv, double rvv, double t_end,
                                               double dx_push0, double lam_abs, double lam_sc,
                                               Rng &rng, double &t, double &x, double &y, double &z,
@@ -198,25 +205,39 @@ __device__ __forceinline__ void imc_step_fast(const ImcCell &c, double vv, doubl
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   double dx_abs = 0.0;
   if constexpr (NOABS) rng.skip();
-  else dx_abs = -lam_abs * m_log(rng.drand());
-  const double dx_sc = -lam_sc * m_log(rng.drand());
+  else dx_abs = -lam_abs * (LEAN ? m_log_lean(rng.drand()) : m_log(rng.drand()));
+  const double dx_sc = -lam_sc * (LEAN ? m_log_lean(rng.drand()) : m_log(rng.drand()));
   const double dx_end = vv * (t_end - t);
   // std::min of two numbers is one v_min_f64.  A velocity component that is exactly zero makes
   // m_div return NaN (0 x inf in its first step), and minNum(x, NaN) = x: the distance stays as
   // it is, which is what the reference's `(v > 0) ? ... : (v < 0) ? ... : dx_push` says.
   double dx_push = m_min(dx_push0, dx_end);
-  dx_push = m_min(dx_push, m_div(vv * ((vx > 0.0 ? c.xu : c.xl) - x), vx));
-  if (multi_d) dx_push = m_min(dx_push, m_div(vv * ((vy > 0.0 ? c.yu : c.yl) - y), vy));
-  if (three_d) dx_push = m_min(dx_push, m_div(vv * ((vz > 0.0 ? c.zu : c.zl) - z), vz));
+  if constexpr (LEAN) {
+    dx_push = m_min(dx_push, (vv * ((vx > 0.0 ? c.xu : c.xl) - x)) * m_rcp_once(vx));
+    if (multi_d) dx_push = m_min(dx_push, (vv * ((vy > 0.0 ? c.yu : c.yl) - y)) * m_rcp_once(vy));
+    if (three_d) dx_push = m_min(dx_push, (vv * ((vz > 0.0 ? c.zu : c.zl) - z)) * m_rcp_once(vz));
+  } else {
+    dx_push = m_min(dx_push, m_div(vv * ((vx > 0.0 ? c.xu : c.xl) - x), vx));
+    if (multi_d) dx_push = m_min(dx_push, m_div(vv * ((vy > 0.0 ? c.yu : c.yl) - y), vy));
+    if (three_d) dx_push = m_min(dx_push, m_div(vv * ((vz > 0.0 ? c.zu : c.zl) - z), vz));
+  }
   is_absorbed = NOABS ? false : (dx_abs < dx_push) && (dx_abs < dx_sc);
   is_scattered = !is_absorbed && (dx_sc < dx_push);
-  const double dt_push =
-      m_div_r(NOABS ? m_min(dx_push, dx_sc)
-                    : (is_absorbed ? dx_abs : (is_scattered ? dx_sc : dx_push)), vv, rvv);
-  t += dt_push;
-  x += vx * dt_push;
-  y += (multi_d ? 1.0 : 0.0) * vy * dt_push;
-  z += (three_d ? 1.0 : 0.0) * vz * dt_push;
+  const double dx_move =
+      NOABS ? m_min(dx_push, dx_sc) : (is_absorbed ? dx_abs : (is_scattered ? dx_sc : dx_push));
+  if constexpr (LEAN) {
+    const double dt_push = dx_move * rvv;
+    t += dt_push;
+    x = fma(vx, dt_push, x);
+    if (multi_d) y = fma(vy, dt_push, y);
+    if (three_d) z = fma(vz, dt_push, z);
+  } else {
+    const double dt_push = m_div_r(dx_move, vv, rvv);
+    t += dt_push;
+    x += vx * dt_push;
+    y += (multi_d ? 1.0 : 0.0) * vy * dt_push;
+    z += (three_d ? 1.0 : 0.0) * vz * dt_push;
+  }
   {
     const bool lo = fabs(x - c.xl) < c.fdx, hi = fabs(x - c.xu) < c.fdx;
     x = lo ? c.xl - c.fdx : (hi ? c.xu + c.fdx : x);

@@ -54,6 +54,15 @@ class StateDescriptor:
     def Param(self, name: str):
         return self._params[name]
 
+    # arithmetic of the gray IMC tracking step (include/jaybenne_amd.h): "lean" (default) or
+    # "exact" (bit-identical to the CPU oracle's portable flavour)
+    def set_arithmetic(self, mode: str) -> None:
+        code = {"exact": _lib.ARITH_EXACT, "lean": _lib.ARITH_LEAN}[mode]
+        _lib.check(self.lib.jb_set_arithmetic(self.ctx, code))
+
+    def arithmetic(self) -> str:
+        return "lean" if self.lib.jb_get_arithmetic(self.ctx) == _lib.ARITH_LEAN else "exact"
+
     def AllParams(self) -> Dict[str, object]:
         return dict(self._params)
 

@@ -10,6 +10,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "lean: runs the library's default (lean) arithmetic")
+
+
+@pytest.fixture(autouse=True)
+def _arithmetic(request, monkeypatch):
+    """The gray IMC kernels come in two arithmetic variants (include/jaybenne_amd.h): the bit-parity
+    tests run the exact one, whose results equal the oracle's bit for bit; tests marked ``lean``
+    run the library's default and state its tolerance."""
+    if request.node.get_closest_marker("lean"):
+        monkeypatch.delenv("JB_EXACT_ARITH", raising=False)
+    else:
+        monkeypatch.setenv("JB_EXACT_ARITH", "1")
 
 
 def pytest_collection_modifyitems(config, items):

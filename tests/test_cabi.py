@@ -133,9 +133,10 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
         found[name] = (vgpr, scratch)
     hot = {
-        "IMC, 3-D, exact geometry (BASELINE configs[1])": "k_transportILi3ELb0ELb1ELi2ELb1E",
-        "IMC, 2-D, exact geometry (configs[3])": "k_transportILi2ELb0ELb1ELi2ELb1E",
-        "IMC, 1-D, exact geometry (configs[0])": "k_transportILi1ELb0ELb1ELi2ELb1E",
+        "IMC, 3-D, exact geometry, lean arithmetic (BASELINE configs[1])": "k_transportILi3ELb0ELb1ELi2ELb1ELb1E",
+        "IMC, 3-D, exact geometry, exact arithmetic": "k_transportILi3ELb0ELb1ELi2ELb1ELb0E",
+        "IMC, 2-D, exact geometry, lean arithmetic (configs[3])": "k_transportILi2ELb0ELb1ELi2ELb1ELb1E",
+        "IMC, 1-D, exact geometry, lean arithmetic (configs[0])": "k_transportILi1ELb0ELb1ELi2ELb1ELb1E",
         "all-DDMC, 3-D (configs[2])": "k_ddmc_allILi3ELb1E",
         "all-DDMC, 1-D": "k_ddmc_allILi1ELb1E",
     }

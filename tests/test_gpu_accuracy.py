@@ -26,11 +26,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_c1_profile_within_stated_tolerance_of_libm_cpu_path(gpu_device):
+@pytest.mark.parametrize("arithmetic", [pytest.param("lean", marks=pytest.mark.lean), "exact"])
+def test_c1_profile_within_stated_tolerance_of_libm_cpu_path(gpu_device, arithmetic):
+    """(both arithmetic variants of the gray IMC kernel: the library's default and the exact one)"""
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     import bench
     acc = bench.accuracy(gpu_device, threads=8)
+    assert acc["arithmetic"] == arithmetic
     assert acc["gpu_error"] <= 0.05 and acc["cpu_libm_error"] <= 0.05          # the reference's gate
     assert acc["gpu_error"] <= acc["cpu_libm_error"] + 0.01                      # (ii)
     assert acc["max_cell_difference_in_sigma"] < 6.0                             # (i)

@@ -1,0 +1,105 @@
+"""The library's default arithmetic in the gray IMC tracking kernels ("lean", include/jaybenne_amd.h)
+and its stated tolerance.
+
+The exact variant performs the oracle's operations one for one and is held to it bit for bit
+(tests/test_gpu_parity.py).  The lean variant replaces four of them by cheaper ones that agree to
+2 ulp -- face distance as numerator times a once-refined reciprocal, time step as distance / c by
+multiplication, position update as one fused multiply-add per axis, logarithm without its
+compensated sum.  A 2-ulp difference moves a photon by ~1e-16 of its path and changes its history
+only where it flips a comparison (which event comes first, which side of a nudge threshold), so
+the tolerance stated and tested here is:
+
+  after full radiation cycles, every particle has the same integer attributes (cell, block,
+  status, random-stream state) as in the oracle / the exact variant, and every floating-point
+  attribute within 1e-9 -- relative to the domain size for positions, to c for velocities, to the
+  time step for times, to its own magnitude for weights; cell tallies within 1e-9 relative.
+
+(`test_gpu_accuracy.py` states the tolerance against the reference's libm arithmetic.)"""
+import numpy as np
+import pytest
+
+from helpers import load_deck, make_oracle, run_oracle_cycles
+from test_gpu_parity import SMR_OVERRIDES, _gpu_problem
+
+pytestmark = [pytest.mark.gpu, pytest.mark.lean]
+
+C_LIGHT = 2.99792458e10
+
+CASES = [
+    ("stepdiff", {"jaybenne/num_particles": 4000}, 2),                       # 1-D, 2 blocks (as shipped)
+    ("stepdiff", {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128,
+                  "jaybenne/num_particles": 4000}, 2),                        # the reference's test shape
+    ("stepdiff_smr", dict(SMR_OVERRIDES, **{"jaybenne/num_particles": 6000}), 1),      # 2-D SMR IMC
+    ("stepdiff", {"parthenon/mesh/nx2": 8, "parthenon/mesh/nx3": 8, "parthenon/mesh/nx1": 16,
+                  "parthenon/meshblock/nx1": 8, "parthenon/meshblock/nx2": 4,
+                  "parthenon/meshblock/nx3": 4, "jaybenne/num_particles": 3000}, 1),   # 3-D, 8 blocks
+    ("stepdiff", {"mcblock/opacity_model": "constant", "mcblock/opacity_constant_value": 40.0,
+                  "mcblock/scattering_constant_value": 20.0, "mcblock/initial_temperature": 1.0e6,
+                  "parthenon/mesh/nx1": 16, "parthenon/meshblock/nx1": 8,
+                  "jaybenne/num_particles": 20000}, 1),                        # absorbing (GRAY = 1)
+]
+
+
+def _close(a, b, scale, what, tol=1e-9):
+    bad = np.abs(a - b) > tol * scale
+    assert not bad.any(), (what, int(bad.sum()), a[bad][:3], b[bad][:3])
+
+
+def _compare_within_tolerance(g, ref, n, mesh, dt, by_id=False):
+    og = np.argsort(g["id"]) if by_id else slice(None)
+    orf = np.argsort(ref["id"][:n]) if by_id else slice(None)
+    for k in ("id", "rng", "ip", "jp", "kp", "blk", "status"):
+        assert np.array_equal(g[k][og], ref[k][:n][orf]), k
+    size = float(np.max(np.asarray(mesh.gmax) - np.asarray(mesh.gmin)))
+    for k in ("x", "y", "z"):
+        _close(g[k][og], ref[k][:n][orf], size, k)
+    for k in ("vx", "vy", "vz"):
+        _close(g[k][og], ref[k][:n][orf], C_LIGHT, k)
+    _close(g["t"][og], ref["t"][:n][orf], dt, "t")
+    for k in ("w", "e"):
+        _close(g[k][og], ref[k][:n][orf], np.abs(ref[k][:n][orf]), k)
+
+
+@pytest.mark.parametrize("deck,overrides,cycles", CASES)
+def test_lean_arithmetic_within_stated_tolerance_of_the_oracle(gpu_device, deck, overrides, cycles):
+    from oracle import orc
+    pin = load_deck(deck, overrides)
+    drv = _gpu_problem(pin, gpu_device)
+    assert drv.pkg.arithmetic() == "lean"                  # the library's default
+    O, mesh, _ = make_oracle(load_deck(deck, overrides), orc.MATH_PORTABLE)
+    for _ in range(cycles):
+        drv.Step()
+    run_oracle_cycles(O, pin, cycles)
+    variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
+    assert variant.endswith("true>"), variant              # <..., LEAN = true>
+    assert drv.md.n == O.n and drv.md.events == O.events
+    absorbing = "mcblock/opacity_constant_value" in overrides
+    _compare_within_tolerance(drv.md.get_swarm(), O.sw, O.n, mesh, pin.GetReal("jaybenne", "dt"),
+                              by_id=absorbing)
+    sl = mesh.interior()
+    a, b = drv.md.get_field("tally")[sl], O.fields["tally"][drv.md.gids][sl]
+    assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max()
+
+
+def test_lean_and_exact_variants_agree_on_a_million_histories(gpu_device):
+    """3-D, 8 blocks of 16^3, 1e6 photons, one cycle (1.4e9 events): the two variants of the kernel
+    leave every photon in the same cell with the same stream state, attributes within the stated
+    tolerance -- and are not the same arithmetic (some last bits differ)."""
+    ov = {"parthenon/mesh/nx1": 32, "parthenon/mesh/nx2": 32, "parthenon/mesh/nx3": 32,
+          "parthenon/meshblock/nx1": 16, "parthenon/meshblock/nx2": 16, "parthenon/meshblock/nx3": 16,
+          "jaybenne/num_particles": 1000000}
+    out = {}
+    for mode in ("lean", "exact"):
+        drv = _gpu_problem(load_deck("stepdiff", ov), gpu_device)
+        drv.pkg.set_arithmetic(mode)
+        drv.Step()
+        assert drv.md.lib.jb_last_transport_variant(drv.md.handle).decode().endswith(
+            "true>" if mode == "lean" else "false>")
+        out[mode] = (drv.md.get_swarm(), drv.md.n, drv.md.events, drv.mesh, drv.md.get_field("tally"))
+        del drv
+    (g, n, ev, mesh, tl), (h, m, ev2, _, te) = out["lean"], out["exact"]
+    assert n == m and ev == ev2
+    _compare_within_tolerance(g, h, n, mesh, 3.335641e-11)
+    assert np.any(g["x"] != h["x"])
+    sl = mesh.interior()
+    assert np.abs(tl[sl] - te[sl]).max() <= 1e-9 * np.abs(te[sl]).max()
