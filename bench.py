@@ -191,6 +191,8 @@ def main() -> None:
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c3-1d", "c4", "c5"],
                     help="c2 = headline (BASELINE configs[1]); c3* = DDMC side measurements")
     ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--no-other-variant", action="store_true",
+                    help="skip the one extra step in the other arithmetic variant (profiling runs)")
     ap.add_argument("--arithmetic", choices=("lean", "exact"), default=None,
                     help="arithmetic of the gray IMC tracking step (default: the library's, lean)")
     args = ap.parse_args()
@@ -262,7 +264,7 @@ def main() -> None:
     other = None
     main_variant = md.lib.jb_last_transport_variant(md.handle).decode()
     main_stats = md.stats()
-    if args.gpus == 1 and not md.pkg.Param("use_ddmc"):
+    if args.gpus == 1 and not md.pkg.Param("use_ddmc") and not args.no_other_variant:
         kept = list(md.kernel_events)
         mode = md.pkg.arithmetic()
         md.pkg.set_arithmetic("exact" if mode == "lean" else "lean")
@@ -304,8 +306,10 @@ def main() -> None:
             f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{args.workload}.json")
             try:
                 tr = json.load(open(f))
+                same_arith = tr.get("kernel", "").rstrip().endswith("true>") == variant.endswith("true>") \
+                    or "k_ddmc_all" in tr.get("kernel", "")
                 if (tr["workload"] == args.workload and tr["particles_per_gpu"] == args.particles_per_gpu
-                        and args.block_nx == 64 and args.gpus == 1):
+                        and args.block_nx == 64 and args.gpus == 1 and same_arith):
                     pmc, pmc_file = tr, os.path.relpath(f, ROOT)
                     break
             except (OSError, KeyError, ValueError):

@@ -66,7 +66,7 @@ for wl, particles in (("c2", 10_000_000), ("c3", 100_000_000)):
         "workload": wl, "particles_per_gpu": particles, "kernel": kernel,
         "command": "rocprofv3 --kernel-trace --pmc <one group per pass> --output-format csv -- python3 bench.py "
                    + ("" if wl == "c2" else "--workload c3 --particles-per-gpu 100000000 ")
-                   + "--steps 1 --warmup 0 --no-cpu-baseline",
+                   + "--steps 1 --warmup 0 --no-cpu-baseline" + (" --no-other-variant" if wl == "c2" else ""),
         "launch_ms_by_pass": ms_by_pass, "events_per_launch": ev, "wave_passes": passes,
         "service_phases": services,
         "hbm_bytes_per_launch": hbm,

@@ -4,7 +4,7 @@
 set -e
 O=gpurun_out/r02prof
 mkdir -p $O && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-C2="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+C2="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
 C3="python3 bench.py --workload c3 --particles-per-gpu 100000000 --steps 1 --warmup 0 --no-cpu-baseline"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o runc -- python3 bench.py > $O/bench_c2_under_rocprof.json 2> $O/stats_c2.err
 echo "stats c2 done"
