@@ -126,6 +126,44 @@ def _ranks_equal_the_oracle(case, world, tmp_path):
     assert sum(int(p["events"][0]) for p in parts) == O.events
 
 
+@pytest.mark.lean
+@pytest.mark.parametrize("case", [4, 6])
+def test_lean_arithmetic_does_not_depend_on_the_partition(gpu_device, case, tmp_path):
+    """The library's default arithmetic (lean) across ranks: the union of two ranks' particles
+    equals the single-process run of the same library bit for bit -- the operations a history
+    sees do not depend on which rank tracks it -- and both are within the stated tolerance of the
+    oracle (tests/test_gpu_lean.py)."""
+    from oracle import orc
+    from jaybenne_amd import mcblock
+    from test_gpu_lean import _compare_within_tolerance
+    sys.path.insert(0, os.path.dirname(__file__))
+    deck, ov, cycles = CASES[case]
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    drv = mcblock.McblockDriver(load_deck(deck, ov), device=gpu_device)
+    assert drv.pkg.arithmetic() == "lean"
+    for _ in range(cycles):
+        drv.Step()
+    one = drv.md.get_swarm()
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    assert sum(int(p["outgoing"][0]) for p in parts) > 0
+    ids = np.concatenate([p["id"] for p in parts])
+    order, o1 = np.argsort(ids), np.argsort(one["id"])
+    assert np.array_equal(ids[order], one["id"][o1])
+    for k in ("x", "y", "z", "vx", "vy", "vz", "t", "w", "e", "ip", "jp", "kp", "rng"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts])[order], one[k][o1]), k
+    pin = load_deck(deck, ov)
+    O, mesh, _ = make_oracle(pin, orc.MATH_PORTABLE)
+    run_oracle_cycles(O, pin, cycles)
+    _compare_within_tolerance(one, O.sw, O.n, mesh, pin.GetReal("jaybenne", "dt"), by_id=True)
+
+
 FEEDBACK = dict(SMR, **{"jaybenne/num_particles": 30000, "jaybenne/do_emission": "true",
                         "jaybenne/do_feedback": "true", "mcblock/opacity_model": "constant",
                         "mcblock/opacity_constant_value": 20.0})
