@@ -315,6 +315,25 @@ def test_all_ddmc_mesh_runs_the_lean_kernel(gpu_device):
         assert want in drv.md.lib.jb_last_transport_variant(drv.md.handle).decode(), deck
 
 
+def test_more_resident_blocks_than_the_lds_table_holds(gpu_device):
+    """The DDMC kernels keep the per-block tables of up to 128 resident blocks in LDS; a mesh
+    with more (here 160 blocks of 4 cells, all DDMC) runs the general kernel with the tables in
+    global memory -- same bits."""
+    from oracle import orc
+    ov = {"parthenon/mesh/nx1": 640, "parthenon/meshblock/nx1": 4, "jaybenne/num_particles": 20000}
+    pin = load_deck("stepdiff_ddmc", ov)
+    drv = _gpu_problem(pin, gpu_device)
+    assert drv.mesh.nblocks == 160
+    O, mesh, _ = make_oracle(load_deck("stepdiff_ddmc", ov), orc.MATH_PORTABLE)
+    for _ in range(2):
+        drv.Step()
+    run_oracle_cycles(O, pin, 2)
+    assert "k_transport<1" in drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
+    _compare_swarm(drv.md, O)
+    _compare_fields(drv.md, O)
+    assert drv.md.events == O.events
+
+
 @pytest.mark.parametrize("deck,overrides", [
     ("stepdiff", {"jaybenne/num_particles": 3000}),
     ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 20000}),

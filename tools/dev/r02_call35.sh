@@ -1,2 +1,2 @@
 set -e
-python -m pytest tests/test_gpu_multirank.py -x -q -k "lean" 2>&1 | tail -5
+python -m pytest tests/test_gpu_parity.py -x -q -k "more_resident" 2>&1 | tail -15
