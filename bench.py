@@ -402,7 +402,7 @@ def main() -> None:
                                    "log, each within 2 ulp of 'exact', whose results equal the CPU "
                                    "oracle's bit for bit; stated tolerance of lean: every particle "
                                    "attribute within 1e-9 after full cycles, integer attributes "
-                                   "equal (tests/test_gpu_lean.py); DDMC / hybrid kernels: exact only",
+                                   "equal (tests/test_gpu_lean.py); DDMC steps: exact only",
                            "other_variant": other},
         }
         if md.phase_times is not None:

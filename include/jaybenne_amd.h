@@ -220,7 +220,8 @@ jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swa
  *     ~8 % fewer instructions.  Stated tolerance (tests/test_gpu_lean.py): after full cycles
  *     every particle attribute within 1e-9 (relative; positions relative to the domain size) of
  *     the exact variant's and of the oracle's, integer attributes equal.
- * The DDMC / hybrid / per-event-opacity kernels have the exact arithmetic only.  JB_EXACT_ARITH=1
+ * The IMC steps of a hybrid (IMC / DDMC) deck follow the same switch; DDMC steps and the
+ * per-event-opacity kernels have the exact arithmetic only.  JB_EXACT_ARITH=1
  * in the environment makes exact the default of jb_initialize. */
 enum { JB_ARITH_EXACT = 0, JB_ARITH_LEAN = 1 };
 jb_status jb_set_arithmetic(jb_context *ctx, int mode);

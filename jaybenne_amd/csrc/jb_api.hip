@@ -143,7 +143,7 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   ctx->dp.kappa_s = scattering->kappa_s;
   ctx->dp.apm = scattering->apm;
   ctx->dp.opac_model = opacity->model;
-  ctx->dp.pad_ = 0;
+  ctx->dp.lean = ctx->lean_arith ? 1 : 0;
   ctx->dp.ep_A = ctx->dp.ep_B = ctx->dp.ep_E = 0.0;
   {
     // CGS constants (CODATA 2018): electron charge (esu), electron / proton mass, Planck,
@@ -735,6 +735,7 @@ extern "C" int jb_mesh_exact_geometry(const jb_mesh *mesh) { return mesh && mesh
 extern "C" jb_status jb_set_arithmetic(jb_context *ctx, int mode) {
   if (!ctx || (mode != JB_ARITH_EXACT && mode != JB_ARITH_LEAN)) return fail(JB_ERR_INVALID, "bad argument");
   ctx->lean_arith = mode == JB_ARITH_LEAN;
+  ctx->dp.lean = ctx->lean_arith ? 1 : 0;
   return JB_COMPLETE;
 }
 extern "C" int jb_get_arithmetic(const jb_context *ctx) {

@@ -67,7 +67,8 @@ struct DevParams {
   double kappa_a;     // Gray
   double kappa_s, apm;  // GrayS (ThomsonS: kappa_s = sigma_T / length_scale^2)
   // EPBremss (opac_model 1): sigma_a = A rho^2 T^-1/2 (1 - e^(-B nu / T)) nu^-3, j = E rho^2 T^1/2
-  int opac_model, pad_;
+  int opac_model;
+  int lean;           // 1: lean arithmetic in the IMC steps of the hybrid kernel (jb_set_arithmetic)
   double ep_A, ep_B, ep_E;
 };
 

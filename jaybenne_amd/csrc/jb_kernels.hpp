@@ -809,9 +809,14 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
               c.fdx = kEpsImc * (s.xu - s.xl); c.fdy = kEpsImc * (s.yu - s.yl);
               c.fdz = kEpsImc * (s.zu - s.zl);
             }
-            imc_step_fast<NDIM, kNoAbs>(c, vv, P.rc, t_end, Bp.dx_push, kNoAbs ? 0.0 : f1[q], lam,
-                                        rng, s.t, s.x, s.y, s.z, s.vx, s.vy, s.vz, s.ip, s.jp, s.kp,
-                                        s.is_absorbed, s.is_scattered);
+            if (P.lean)  // (uniform) jb_set_arithmetic
+              imc_step_fast<NDIM, kNoAbs, true>(c, vv, P.rc, t_end, Bp.dx_push, kNoAbs ? 0.0 : f1[q],
+                                                lam, rng, s.t, s.x, s.y, s.z, s.vx, s.vy, s.vz,
+                                                s.ip, s.jp, s.kp, s.is_absorbed, s.is_scattered);
+            else
+              imc_step_fast<NDIM, kNoAbs, false>(c, vv, P.rc, t_end, Bp.dx_push, kNoAbs ? 0.0 : f1[q],
+                                                 lam, rng, s.t, s.x, s.y, s.z, s.vx, s.vy, s.vz,
+                                                 s.ip, s.jp, s.kp, s.is_absorbed, s.is_scattered);
           }
         } else {
           const double rho = f0[q];

@@ -37,6 +37,7 @@ CASES = [
                   "mcblock/scattering_constant_value": 20.0, "mcblock/initial_temperature": 1.0e6,
                   "parthenon/mesh/nx1": 16, "parthenon/meshblock/nx1": 8,
                   "jaybenne/num_particles": 20000}, 1),                        # absorbing (GRAY = 1)
+    ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 30000}, 1),            # hybrid: IMC steps lean
 ]
 
 
@@ -71,7 +72,8 @@ def test_lean_arithmetic_within_stated_tolerance_of_the_oracle(gpu_device, deck,
         drv.Step()
     run_oracle_cycles(O, pin, cycles)
     variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
-    assert variant.endswith("true>"), variant              # <..., LEAN = true>
+    if "hybrid" not in deck:     # (the hybrid kernel takes the arithmetic as a run-time flag)
+        assert variant.endswith("true>"), variant          # <..., LEAN = true>
     assert drv.md.n == O.n and drv.md.events == O.events
     absorbing = "mcblock/opacity_constant_value" in overrides
     _compare_within_tolerance(drv.md.get_swarm(), O.sw, O.n, mesh, pin.GetReal("jaybenne", "dt"),
