@@ -667,12 +667,14 @@ def test_c_abi_error_paths(gpu_device):
 
 
 # ------------------------------------------------------------------------------------------------
-def test_full_size_invariants_c2(gpu_device):
+@pytest.mark.parametrize("arithmetic", [pytest.param("lean", marks=pytest.mark.lean), "exact"])
+def test_full_size_invariants_c2(gpu_device, arithmetic):
     """BASELINE config C2 at full size (64 blocks of 64^3, 1e7 photons, pure IMC): too large for the
     oracle, so checked through size-independent properties -- conservation of particles and
     energy (no absorption, reflecting / periodic walls), every history ends exactly at census,
     |v| = c, tally integral = radiation energy, and bitwise run-to-run determinism of the
-    particle states."""
+    particle states.  In both arithmetic variants of the kernel (the library's default and the
+    exact one)."""
     import torch
     sys_path = __import__("sys").path
     root = __import__("os").path.dirname(__import__("os").path.dirname(__file__))
@@ -683,6 +685,7 @@ def test_full_size_invariants_c2(gpu_device):
 
     def run():
         drv = mcblock.McblockDriver(bench.make_deck(1, 10_000_000), device=gpu_device, capacity_factor=1.2)
+        assert drv.pkg.arithmetic() == arithmetic
         n0 = drv.md.n
         e0 = float(drv.md.swarm["w"][:n0].sum())
         drv.Step()
