@@ -39,7 +39,12 @@ FLOPS_PER_EVENT = 200.0      # FP64 flop-equivalents per IMC event
 
 
 def block_grid(ngpus: int):
-    return {1: (4, 4, 4), 2: (8, 4, 4), 4: (8, 8, 4), 8: (8, 8, 8)}.get(ngpus) or (4 * ngpus, 4, 4)
+    """Blocks of the weak-scaled headline mesh.  The stepdiff initial condition puts the photons
+    into the hot half x < 0, so the domain keeps its four block columns in x and grows in the
+    periodic directions y and z: every rank's contiguous Z-order range is then a 4 x 4 x 4 cube of
+    blocks with 32 hot and 32 cold ones -- the one-GPU problem, coupled to its neighbours through
+    the particle hand-off (growing in x instead would leave every other rank without photons)."""
+    return {1: (4, 4, 4), 2: (4, 8, 4), 4: (4, 8, 8), 8: (4, 16, 8)}.get(ngpus) or (4, 4 * ngpus, 4)
 
 
 def make_deck(ngpus: int, particles_per_gpu: int, block_nx: int = 64, workload: str = "c2"):
