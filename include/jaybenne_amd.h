@@ -184,7 +184,8 @@ jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh *mesh, dou
  *           block b writes slots slot_base[b].. and stream ids id_base[b]..  (host arrays
  *           [nblocks]; the slot assignment is Parthenon's AddEmptyParticles step).
  * Returns JB_COMPLETE without doing anything for emission when do_emission is false
- * (sourcing.cpp:41-43); JB_ERR_INVALID for the `energy` strategy (sourcing.cpp:38). */
+ * (sourcing.cpp:41-43); JB_ERR_INVALID for the `energy` strategy (sourcing.cpp:38) and for
+ * epoch >= 2^20 (the per-cell rounding streams are keyed by 20 bits of it). */
 jb_status jb_source_photons_count(jb_context *ctx, jb_mesh *mesh, int source_type, double dt,
                                   int blocks_in_call, uint32_t epoch, int32_t *nper_block_host,
                                   int32_t *prefix_dev);

@@ -534,6 +534,8 @@ extern "C" jb_status jb_source_photons_count(jb_context *ctx, jb_mesh *mesh, int
   JB_HIP(hipSetDevice(ctx->device));
   if (ctx->params.source_strategy == JB_STRATEGY_ENERGY)
     return fail(JB_ERR_INVALID, "Energy source strategy not implemented!");  // sourcing.cpp:38
+  if (epoch >= (1u << 20))  // cell_stream_id keeps the source-call counter in 20 bits
+    return fail(JB_ERR_INVALID, "more than 2^20 source calls: the per-cell rounding streams would repeat");
   const DevMesh &M = mesh->dm;
   if (source_type == JB_SOURCE_EMISSION && !ctx->params.do_emission) {  // sourcing.cpp:41-43
     for (int b = 0; b < M.nblocks; ++b) nper_block_host[b] = 0;
