@@ -307,8 +307,9 @@ def main() -> None:
         # counters of this very command under rocprofv3 (separate --pmc passes), if a committed
         # summary matches workload and size: labelled as read from that file, not measured now
         pmc, pmc_file = None, None
-        for rnd in ("r02", "r01_g"):
-            f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{args.workload}.json")
+        for rnd in ("r02", "r02_exact", "r01_g"):
+            f = os.path.join(ROOT, "profiles", f"{rnd.split('_exact')[0]}_pmc_summary_{args.workload}"
+                                               f"{'_exact' if rnd.endswith('_exact') else ''}.json")
             try:
                 tr = json.load(open(f))
                 same_arith = tr.get("kernel", "").rstrip().endswith("true>") == variant.endswith("true>") \
