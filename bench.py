@@ -312,8 +312,11 @@ def main() -> None:
                                                f"{'_exact' if rnd.endswith('_exact') else ''}.json")
             try:
                 tr = json.load(open(f))
-                same_arith = tr.get("kernel", "").rstrip().endswith("true>") == variant.endswith("true>") \
-                    or "k_ddmc_all" in tr.get("kernel", "")
+                # (kernel names of the summaries carry NDIM, DDMC, TALLY, GRAY, EXACT[, LEAN]: five
+                # arguments = a kernel from before the lean variant existed, i.e. exact arithmetic)
+                kargs = tr.get("kernel", "").split("<")[-1].rstrip("> ").split(",")
+                tr_lean = len(kargs) == 6 and kargs[-1].strip() == "true"
+                same_arith = tr_lean == variant.endswith("true>") or "k_ddmc_all" in tr.get("kernel", "")
                 if (tr["workload"] == args.workload and tr["particles_per_gpu"] == args.particles_per_gpu
                         and args.block_nx == 64 and args.gpus == 1 and same_arith):
                     pmc, pmc_file = tr, os.path.relpath(f, ROOT)
