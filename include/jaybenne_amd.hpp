@@ -59,6 +59,9 @@ class StateDescriptor {
   jb_context *ctx() const { return ctx_; }
   const jb_params &params() const { return params_; }
   int seed() const { return jb_param_seed(ctx_); }  // Param<int>("seed"), jaybenne.cpp:187-190
+  // arithmetic of the gray IMC tracking step: JB_ARITH_LEAN (default) or JB_ARITH_EXACT
+  void SetArithmetic(int mode) { Check(jb_set_arithmetic(ctx_, mode)); }
+  int Arithmetic() const { return jb_get_arithmetic(ctx_); }
 
  private:
   jb_context *ctx_ = nullptr;
