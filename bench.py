@@ -150,7 +150,7 @@ def accuracy(device, threads: int):
             "max_cell_difference_in_sigma": float(z.max()),
             "rms_cell_difference_in_sigma": float(np.sqrt((z * z).mean())),
             "note": "same random streams; the HIP path evaluates log / sincos by table and (lean "
-                    "arithmetic, the default) face distances / position updates within 2 ulp of "
+                    "arithmetic, the default) face distances / position updates within 4e-15 (relative) of "
                     "the CPU path's libm / IEEE operations: a history parts ways with its twin "
                     "only where a last-bit difference flips a branch, and the tally moves only if "
                     "that photon ends the cycle in another cell.  Stated tolerance "
@@ -408,7 +408,7 @@ def main() -> None:
             "arithmetic": {"mode": md.pkg.arithmetic(),
                            "note": "gray IMC tracking step: 'lean' (default) = face distance by a "
                                    "once-refined reciprocal, fused position update, uncompensated "
-                                   "log, each within 2 ulp of 'exact', whose results equal the CPU "
+                                   "log, each within 4e-15 (relative) of 'exact', whose results equal the CPU "
                                    "oracle's bit for bit; stated tolerance of lean: every particle "
                                    "attribute within 1e-9 after full cycles, integer attributes "
                                    "equal (tests/test_gpu_lean.py); DDMC steps: exact only",

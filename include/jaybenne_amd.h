@@ -217,8 +217,9 @@ jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swa
  *     come out bit-identical to it.
  *   JB_ARITH_LEAN (default): distance to a face as numerator times a once-refined reciprocal,
  *     time step as distance times 1/c, position update as one fused multiply-add per axis,
- *     logarithm without its compensated sum: each within 2 ulp of the exact variant's result,
- *     ~8 % fewer instructions.  Stated tolerance (tests/test_gpu_lean.py): after full cycles
+ *     logarithm without its compensated sum: the quotient within 2^-48 (relative, ~20 ulp) of
+ *     the exact variant's, the logarithm within 1 ulp, the fused update the more accurate of
+ *     the two forms; ~8 % fewer instructions.  Stated tolerance (tests/test_gpu_lean.py): after full cycles
  *     every particle attribute within 1e-9 (relative; positions relative to the domain size) of
  *     the exact variant's and of the oracle's, integer attributes equal.
  * The IMC steps of a hybrid (IMC / DDMC) deck follow the same switch; DDMC steps and the
@@ -318,7 +319,8 @@ jb_status jb_debug_stream_start(jb_context *ctx, uint32_t seed, uint64_t id, uin
 jb_status jb_debug_draw_stream(jb_context *ctx, uint64_t state, int n, double *out_host,
                                uint64_t *final_state);
 /* which: 0 log, 1 sin, 2 cos, 3 acos, 4 sqrt, 5 reciprocal, 6 lean sqrt, 7 lean x[i] / x[i+1],
- * 8 lean x[i] / c, 9 sin(2 pi x), 10 cos(2 pi x), 11 1 - exp(-x) */
+ * 8 lean x[i] / c, 9 sin(2 pi x), 10 cos(2 pi x), 11 1 - exp(-x), 12 x[i] / x[i+1] as the lean
+ * arithmetic forms it (numerator times once-refined reciprocal), 13 lean log */
 jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n, double *out_host);
 /* the opacity / scattering models as the kernels evaluate them: out[0..3] = EPBremss A, B, E
  * (sigma_a = A rho^2 T^-1/2 (1 - e^(-B nu / T)) nu^-3, j = E rho^2 T^1/2, code units) and the

@@ -1113,7 +1113,9 @@ __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
     case 8: out[i] = m_div_r(x[i], 2.99792458e10, m_rcp_refined(2.99792458e10)); break;
     case 9: m_sincos2pi(x[i], s, c); out[i] = s; break;
     case 10: m_sincos2pi(x[i], s, c); out[i] = c; break;
-    default: out[i] = m_one_minus_exp_neg(x[i]); break;
+    case 11: out[i] = m_one_minus_exp_neg(x[i]); break;
+    case 12: out[i] = x[i] * m_rcp_once(x[(i + 1) % n]); break;   // lean quotient
+    default: out[i] = m_log_lean(x[i]); break;
     }
   }
 }

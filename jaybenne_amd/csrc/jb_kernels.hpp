@@ -357,8 +357,8 @@ enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
 // decks).  Then x0 + (i + 0.5) dx -+ 0.5 dx and upper - lower are exact, so the cell faces are
 // formed as fma(i, dx, x0) and + dx, and the nudge width as eps dx: the same doubles as the
 // general formulas (transport.cpp:114-119), in 3 instead of 8 operations per axis.
-// LEAN (gray IMC kernels only): lean arithmetic in the tracking step (imc_step_fast): within 2 ulp
-// per operation of the exact variant, ~8 % fewer instructions; jb_set_arithmetic picks.
+// LEAN (gray IMC kernels only): lean arithmetic in the tracking step (imc_step_fast): within 2^-48
+// (relative) per operation of the exact variant, ~8 % fewer instructions; jb_set_arithmetic picks.
 template <int NDIM, bool DDMC, bool TALLY, int GRAY, bool EXACT = false, bool LEAN = false>
 __global__ void
 __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER_SIMD)

@@ -191,9 +191,9 @@ struct ImcCell {
 };
 //  * LEAN: the same step in lean arithmetic -- distance to a face as (c (face - x)) times a
 //    once-refined reciprocal of the velocity component, time step as distance times 1/c, position
-//    update as one fused multiply-add per axis, logarithm without its compensated sum.  Every
-//    operation is within 2 ulp of the exact variant's (whose quotients are correctly rounded and
-//    whose position update rounds twice); a history parts ways with its exact twin only where
+//    update as one fused multiply-add per axis, logarithm without its compensated sum.  The
+//    quotient is within 2^-48 (relative; ~20 ulp) of the exact variant's correctly rounded one,
+//    the logarithm within 1 ulp, the fused update the more accurate of the two forms; a history parts ways with its exact twin only where
 //    such a difference flips a comparison.  A zero velocity component still yields NaN in the
 //    reciprocal's Newton step and v_min_f64 ignores it.
 template <int NDIM, bool NOABS, bool LEAN = false, class Rng>
