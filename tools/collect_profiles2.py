@@ -42,7 +42,7 @@ def pmc_pass(d):
     return tot, sum(dur[main]) / len(dur[main]), main.split("(")[0]
 
 
-for wl, particles in (("c2", 10_000_000), ("c3", 100_000_000)):
+for wl, particles in (("c2", 10_000_000), ("c3", 100_000_000), ("c4", 10_000_000), ("c5", 10_000_000)):
     counters, ms_by_pass, kernel = {}, {}, None
     for p in "ABCDEFG":
         d = os.path.join(src, f"pmc_{wl}_{p}")
@@ -65,8 +65,8 @@ for wl, particles in (("c2", 10_000_000), ("c3", 100_000_000)):
     summary = {
         "workload": wl, "particles_per_gpu": particles, "kernel": kernel,
         "command": "rocprofv3 --kernel-trace --pmc <one group per pass> --output-format csv -- python3 bench.py "
-                   + ("" if wl == "c2" else "--workload c3 --particles-per-gpu 100000000 ")
-                   + "--steps 1 --warmup 0 --no-cpu-baseline" + (" --no-other-variant" if wl == "c2" else ""),
+                   + ("" if wl == "c2" else f"--workload {wl} --particles-per-gpu {particles} ")
+                   + "--steps 1 --warmup 0 --no-cpu-baseline" + ("" if wl == "c3" else " --no-other-variant"),
         "launch_ms_by_pass": ms_by_pass, "events_per_launch": ev, "wave_passes": passes,
         "service_phases": services,
         "hbm_bytes_per_launch": hbm,
