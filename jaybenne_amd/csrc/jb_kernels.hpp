@@ -336,6 +336,10 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 #ifndef JB_TRANSPORT_WAVES_PER_SIMD
 #define JB_TRANSPORT_WAVES_PER_SIMD 1
 #endif
+#ifndef JB_LEAN_WAVES_PER_SIMD   // the lean kernels of a non-absorbing material (the stepdiff decks) are
+                                 // held to three waves per SIMD: 168 registers, no spill (tests/test_cabi.py)
+#define JB_LEAN_WAVES_PER_SIMD 3
+#endif
 #ifndef JB_SERVICE_BUDGET        // idle lane-passes that buy a service phase: IMC kernels
 #define JB_SERVICE_BUDGET 96
 #endif
@@ -343,7 +347,8 @@ __global__ void __launch_bounds__(kBlock) k_source_edelta(DevMesh M, int source_
 #define JB_SERVICE_BUDGET_DDMC 128
 #endif
 
-enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
+// LS_DONE_RAW (lean kernels): finished without having been tracked -- t, v still hold what was loaded
+enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3, LS_DONE_RAW = 4 };
 
 #ifndef JB_DDMC_WAVES_PER_SIMD
 #define JB_DDMC_WAVES_PER_SIMD 3
@@ -361,7 +366,8 @@ enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3 };
 // (relative) per operation of the exact variant, ~8 % fewer instructions; jb_set_arithmetic picks.
 template <int NDIM, bool DDMC, bool TALLY, int GRAY, bool EXACT = false, bool LEAN = false>
 __global__ void
-__launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER_SIMD)
+__launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
+                            : (LEAN && GRAY == 2 ? JB_LEAN_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER_SIMD))
     k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
                 long long last, unsigned long long *counters, const int *skip_unless) {
   static_assert(!EXACT || (GRAY != 0 && !DDMC), "EXACT is a variant of the gray IMC kernels");
@@ -385,6 +391,9 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   constexpr bool kFastGray = GRAY != 0 && !DDMC;
   constexpr bool kNoAbs = GRAY == 2;
+  // lean arithmetic: a lane carries the unit direction v / c in (vx, vy, vz) and the distance
+  // left to census c (t_end - t) in t while it follows a photon (imc_step_dir)
+  constexpr bool kDir = LEAN;
   constexpr bool kPackedDdmc = GRAY != 0 && DDMC;
   // DDMC kernels re-read the block geometry (10 cached doubles) at the top of every event pass
   // instead of carrying it in 26 registers per lane across the whole loop: that is what lets
@@ -491,7 +500,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         if constexpr (DDMC && multi_d)
           sample_block_face<NDIM>(M, P, B, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
         xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // next launch's transport.cpp:96
-        ls = (t < t_end) ? LS_RUN : LS_DONE;
+        ls = (kDir ? t > 0.0 : t < t_end) ? LS_RUN : LS_DONE;
         if constexpr (kPackedDdmc) lam_cur = f2[cidx(M, kp, jp, ip)];
       }
     }
@@ -525,7 +534,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
     if constexpr (kFastGray) B.x0[AXIS] = nx0;
     idx = at_first ? first_i : last_i;
     bind_arrays(b);
-    ls = (t < t_end) ? LS_RUN : LS_DONE;
+    ls = (kDir ? t > 0.0 : t < t_end) ? LS_RUN : LS_DONE;
     if constexpr (kPackedDdmc) lam_cur = f2[cidx(M, kp, jp, ip)];
     return true;
   };
@@ -542,7 +551,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
     if constexpr (!kFastGray) {  // (the gray IMC kernels relocate inside their event loop)
       if (ls == LS_RELOC) relocate();
     }
-    if (ls == LS_DONE) {
+    if (ls == LS_DONE || (kDir && ls == LS_DONE_RAW)) {
       // (a particle relocated to a block that is not resident carries the GLOBAL id in b: the
       // geometry tables only cover resident blocks, and nothing below reads B for it)
       if constexpr (kReloadBlock) {
@@ -576,6 +585,12 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
         // or absorption deposit)
         if (status == ST_ACTIVE) status = ST_OUTGOING;
         b = M.gid[b];
+      }
+      if constexpr (kDir) {
+        if (ls == LS_DONE) {  // back to time and velocity (census: d_rem = 0 exactly, t = t_end)
+          t = fma(-t, P.rc, t_end);
+          vx *= vv; vy *= vv; vz *= vv;
+        }
       }
       S.blk[n] = b;
       S.t[n] = t;
@@ -631,7 +646,17 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
           status = ST_ACTIVE;
           resample = false;
           xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:96
-          ls = (t < t_end) ? LS_RUN : LS_DONE;      // already at census: nothing to track
+          if constexpr (kDir) {
+            if (t < t_end) {
+              t = vv * (t_end - t);
+              vx *= P.rc; vy *= P.rc; vz *= P.rc;
+              ls = LS_RUN;
+            } else {
+              ls = LS_DONE_RAW;
+            }
+          } else {
+            ls = (t < t_end) ? LS_RUN : LS_DONE;    // already at census: nothing to track
+          }
         }
       }
     } else {
@@ -711,26 +736,35 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
       c_ev += (unsigned int)nrun;
       if constexpr (kFastGray) {
         if (ls == LS_RUN) {
-          ImcCell c;
-          if constexpr (EXACT) {
-            c.xl = m_fma((double)ip, B.dx[0], B.x0[0]); c.xu = c.xl + B.dx[0];
-            c.yl = m_fma((double)jp, B.dx[1], B.x0[1]); c.yu = c.yl + B.dx[1];
-            c.zl = m_fma((double)kp, B.dx[2], B.x0[2]); c.zu = c.zl + B.dx[2];
-            c.fdx = fd[0]; c.fdy = fd[1]; c.fdz = fd[2];
-          } else {  // transport.cpp:114-119, transport_utils.hpp:151-153
-            c.xl = xc(B, 0, ip) - 0.5 * B.dx[0]; c.xu = xc(B, 0, ip) + 0.5 * B.dx[0];
-            c.yl = xc(B, 1, jp) - 0.5 * B.dx[1]; c.yu = xc(B, 1, jp) + 0.5 * B.dx[1];
-            c.zl = xc(B, 2, kp) - 0.5 * B.dx[2]; c.zu = xc(B, 2, kp) + 0.5 * B.dx[2];
-            c.fdx = kEpsImc * (c.xu - c.xl); c.fdy = kEpsImc * (c.yu - c.yl);
-            c.fdz = kEpsImc * (c.zu - c.zl);
-          }
           // per-cell mean free paths precomputed by k_fleck: two gathers instead of three, and
           // no division (same values: same operations on the same operands)
           const int q = cidx(M, kp, jp, ip);
           bool is_absorbed, is_scattered;
-          imc_step_fast<NDIM, kNoAbs, LEAN>(c, vv, P.rc, t_end, B.dx_push, kNoAbs ? 0.0 : f0[q], f1[q],
-                                      rng, t, x, y, z, vx, vy, vz, ip, jp, kp, is_absorbed,
-                                      is_scattered);
+          if constexpr (kDir) {
+            DirGeom g;
+            g.x0[0] = B.x0[0]; g.x0[1] = B.x0[1]; g.x0[2] = B.x0[2];
+            g.dx[0] = B.dx[0]; g.dx[1] = B.dx[1]; g.dx[2] = B.dx[2];
+            g.fd[0] = fd[0]; g.fd[1] = fd[1]; g.fd[2] = fd[2];
+            imc_step_dir<NDIM, kNoAbs, EXACT>(g, B.dx_push, kNoAbs ? 0.0 : f0[q], f1[q], rng, t, x, y, z,
+                                              vx, vy, vz, ip, jp, kp, is_absorbed, is_scattered);
+          } else {
+            ImcCell c;
+            if constexpr (EXACT) {
+              c.xl = m_fma((double)ip, B.dx[0], B.x0[0]); c.xu = c.xl + B.dx[0];
+              c.yl = m_fma((double)jp, B.dx[1], B.x0[1]); c.yu = c.yl + B.dx[1];
+              c.zl = m_fma((double)kp, B.dx[2], B.x0[2]); c.zu = c.zl + B.dx[2];
+              c.fdx = fd[0]; c.fdy = fd[1]; c.fdz = fd[2];
+            } else {  // transport.cpp:114-119, transport_utils.hpp:151-153
+              c.xl = xc(B, 0, ip) - 0.5 * B.dx[0]; c.xu = xc(B, 0, ip) + 0.5 * B.dx[0];
+              c.yl = xc(B, 1, jp) - 0.5 * B.dx[1]; c.yu = xc(B, 1, jp) + 0.5 * B.dx[1];
+              c.zl = xc(B, 2, kp) - 0.5 * B.dx[2]; c.zu = xc(B, 2, kp) + 0.5 * B.dx[2];
+              c.fdx = kEpsImc * (c.xu - c.xl); c.fdy = kEpsImc * (c.yu - c.yl);
+              c.fdz = kEpsImc * (c.zu - c.zl);
+            }
+            imc_step_fast<NDIM, kNoAbs, false>(c, vv, P.rc, t_end, B.dx_push, kNoAbs ? 0.0 : f0[q],
+                                               f1[q], rng, t, x, y, z, vx, vy, vz, ip, jp, kp,
+                                               is_absorbed, is_scattered);
+          }
           if (!on_block(M, ip, jp, kp)) {
             ls = LS_RELOC;  // comm phase: below, for the lanes that need it
           } else if (is_absorbed) {  // transport.cpp:157-163
@@ -742,8 +776,13 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER
             }
             ls = LS_DONE;
           } else {
-            if (is_scattered) scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
-            if (!(t < t_end)) ls = LS_DONE;                  // census
+            if constexpr (kDir) {
+              if (is_scattered) scatter_dir(rng, vx, vy, vz);
+              if (!(t > 0.0)) ls = LS_DONE;
+            } else {
+              if (is_scattered) scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
+              if (!(t < t_end)) ls = LS_DONE;                  // census
+            }
           }
         }
         // A particle that left its block is relocated at once (in the reference: end of the

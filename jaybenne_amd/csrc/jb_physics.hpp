@@ -255,6 +255,103 @@ __device__ __forceinline__ void imc_step_fast(const ImcCell &c, double vv, doubl
   }
 }
 
+// The lean tracking step of the gray IMC kernels (jb_set_arithmetic: the library's default), in
+// "direction space": while a lane follows a photon it carries the unit direction omega = v / c
+// and the distance left to census d_rem = c (t_end - t) instead of v and t (converted when the
+// photon is loaded and written back).  The step of transport_utils.hpp:118-159 then reads
+//   d_face = (face - x) / omega   (the reference: c (face - x) / v -- the same number),
+//   x += omega d   (x += v (d / c)),   d_rem -= d   (t += d / c),
+// with the quotient formed by a once-refined reciprocal (m_rcp_once: <= 2^-48 relative), the
+// position update fused, and the logarithm without its compensated sum (m_log_lean: <= 2 ulp) --
+// every operation within 4e-15 (relative) of the exact variant's.  One more difference, of another
+// kind: per axis only the face the photon is MOVING TOWARDS is tested for the nudge of
+// transport_utils.hpp:151-159.  The face behind it is at least eps_imc dx away -- the photon was
+// put that far beyond it when it entered the cell -- unless the photon has moved less than the
+// rounding error of its own position since (a flight of < 1e-16 cm: probability ~1e-13 per event)
+// or was sourced within eps_imc dx = 2e-9 dx of a face; the exact variant tests both faces as the
+// reference does.  A history parts ways with its exact twin only where such a difference flips a
+// comparison (include/jaybenne_amd.h states the tolerance, tests/test_gpu_lean.py tests it).
+// The block geometry the lean step reads: coordinate of cell index 0 and cell width per axis,
+// nudge widths eps_imc dx.  EXACTG: power-of-two cell widths and block corners that are whole
+// numbers of them (jb_mesh_exact_geometry), so that x0 + i dx is exact for every face i.
+struct DirGeom {
+  double x0[3], dx[3], fd[3];
+};
+// "moving up": the sign bit of the direction component is clear (+0.0 counts as up, -0.0 as down;
+// either way a zero component reaches no face: see below)
+__device__ __forceinline__ bool dir_up(double o) { return __double2hiint(o) >= 0; }
+// the face the photon moves towards is face idx + up of its block (iu); EXACTG: one exact fma
+template <bool EXACTG>
+__device__ __forceinline__ double dir_face(const DirGeom &g, int d, int idx, bool up, int &iu) {
+  iu = idx + (int)up;
+  if constexpr (EXACTG) {
+    return m_fma((double)iu, g.dx[d], g.x0[d]);
+  } else {  // transport.cpp:114-119
+    const double xcd = g.x0[d] + ((double)idx + 0.5) * g.dx[d];
+    return up ? xcd + 0.5 * g.dx[d] : xcd - 0.5 * g.dx[d];
+  }
+}
+// nudge (transport_utils.hpp:151-159) at the face ahead, and Xtoijk after it (transport.cpp:146):
+// the cell index moves by one exactly when the nudge fires -- to iu when moving up, to iu - 1
+// (= idx - 1) when moving down -- and is idx = iu - up otherwise: iu - (hit != up) in all cases
+__device__ __forceinline__ void dir_nudge(double &x, int &idx, double o, double f, double fd, int iu,
+                                          bool up) {
+  const bool hit = fabs(x - f) < fd;
+  // fd with the sign of o (one v_bfi_b32 on the high word, into a register of its own)
+  int shi;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(shi) : "s"(0x7fffffff), "v"(__double2hiint(fd)), "v"(__double2hiint(o)));
+  x = hit ? f + __hiloint2double(shi, __double2loint(fd)) : x;
+  idx = iu - (int)(hit != up);
+}
+template <int NDIM, bool NOABS, bool EXACTG, class Rng>
+__device__ __forceinline__ void imc_step_dir(const DirGeom &g, double dx_push0, double lam_abs,
+                                             double lam_sc, Rng &rng, double &d_rem, double &x,
+                                             double &y, double &z, double ox, double oy, double oz,
+                                             int &ip, int &jp, int &kp, bool &is_absorbed,
+                                             bool &is_scattered) {
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  double dx_abs = 0.0;
+  if constexpr (NOABS) rng.skip();
+  else dx_abs = -lam_abs * m_log_lean(rng.drand());
+  const double dx_sc = -lam_sc * m_log_lean(rng.drand());
+  double dx_push = m_min(dx_push0, d_rem);
+  // (a direction component that is exactly zero: 0 x inf = NaN in the reciprocal's Newton step,
+  // and minNum ignores it -- the reference's third branch, as in imc_step_fast)
+  const bool upx = dir_up(ox), upy = dir_up(oy), upz = dir_up(oz);
+  int iux = 0, iuy = 0, iuz = 0;
+  const double fx = dir_face<EXACTG>(g, 0, ip, upx, iux);
+  const double fy = multi_d ? dir_face<EXACTG>(g, 1, jp, upy, iuy) : 0.0;
+  const double fz = three_d ? dir_face<EXACTG>(g, 2, kp, upz, iuz) : 0.0;
+  dx_push = m_min(dx_push, (fx - x) * m_rcp_once(ox));
+  if (multi_d) dx_push = m_min(dx_push, (fy - y) * m_rcp_once(oy));
+  if (three_d) dx_push = m_min(dx_push, (fz - z) * m_rcp_once(oz));
+  is_absorbed = NOABS ? false : (dx_abs < dx_push) && (dx_abs < dx_sc);
+  is_scattered = !is_absorbed && (dx_sc < dx_push);
+  const double dx_move =
+      NOABS ? m_min(dx_push, dx_sc) : (is_absorbed ? dx_abs : (is_scattered ? dx_sc : dx_push));
+  d_rem -= dx_move;  // (exactly zero when the step ends at census: dx_move = d_rem)
+  x = fma(ox, dx_move, x);
+  if (multi_d) y = fma(oy, dx_move, y);
+  if (three_d) z = fma(oz, dx_move, z);
+  dir_nudge(x, ip, ox, fx, EXACTG ? g.fd[0] : kEpsImc * g.dx[0], iux, upx);
+  if (multi_d) dir_nudge(y, jp, oy, fy, EXACTG ? g.fd[1] : kEpsImc * g.dx[1], iuy, upy);
+  if (three_d) dir_nudge(z, kp, oz, fz, EXACTG ? g.fd[2] : kEpsImc * g.dx[2], iuz, upz);
+}
+
+// scattering.hpp:21-29 in direction space: the new unit direction (2 draws)
+template <class Rng>
+__device__ __forceinline__ void scatter_dir(Rng &rng, double &ox, double &oy, double &oz) {
+  double xi1, xi2;
+  rng.drand2(xi1, xi2);
+  const double mu = fma(2.0, xi1, -1.0);
+  const double st = m_sqrt(1.0 - mu * mu);
+  double sn, cs;
+  m_sincos2pi(xi2, sn, cs);
+  ox = st * cs;
+  oy = st * sn;
+  oz = mu;
+}
+
 // reference transport_utils.hpp:111-160 -- one IMC tracking step, 2 draws
 template <int NDIM, class Rng>
 __device__ __forceinline__ void ptcl_transport_step(Step &s, Rng &rng) {
