@@ -310,8 +310,10 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
         exact = dx > 0.0 && std::frexp(dx, &e) == 0.5 && q == std::nearbyint(q) &&
                 std::fabs(q) < 1099511627776.0;  // 2^40: (q + i + 0.5) dx is exact
       }
-    m->exact_geom = exact;
     D.exact = exact ? 1 : 0;
+    // (the EXACT tracking kernels also address the mean-free-path arrays of all resident blocks
+    // with 32-bit byte offsets: 16 bytes per cell)
+    m->exact_geom = exact && 16ull * (unsigned long long)D.ntot * (unsigned long long)v->nblocks < (1ull << 32);
   }
   int maxrank = 0;
   for (int g = 0; g < v->nblocks_total; ++g) maxrank = v->owner[g] > maxrank ? v->owner[g] : maxrank;
@@ -1115,7 +1117,8 @@ __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
     case 10: m_sincos2pi(x[i], s, c); out[i] = c; break;
     case 11: out[i] = m_one_minus_exp_neg(x[i]); break;
     case 12: out[i] = x[i] * m_rcp_once(x[(i + 1) % n]); break;   // lean quotient
-    default: out[i] = m_log_lean(x[i]); break;
+    case 13: out[i] = m_log_lean(x[i]); break;
+    default: out[i] = m_sqrt_lean(x[i]); break;
     }
   }
 }

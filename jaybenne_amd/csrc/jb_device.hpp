@@ -231,8 +231,15 @@ __device__ __forceinline__ bool on_block(const DevMesh &M, int i, int j, int k) 
 // cell index inside one block's [nk][nj][ni] array.  jb_mesh_create checks ni < 2^23 and
 // nj nk < 2^23, so both products are 24-bit multiplications (v_mad_i32_i24, full rate; a
 // general 32-bit multiply-add is a quarter-rate 64-bit one on gfx950).
+// (through inline asm: left to itself the compiler forms k nj + j with v_mad_u64_u32, a
+// quarter-rate instruction, in the tracking loops)
+__device__ __forceinline__ int mad24(int a, int b_uniform, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+  return d;
+}
 __device__ __forceinline__ int cidx(const DevMesh &M, int k, int j, int i) {
-  return __mul24(__mul24(k, M.nj) + j, M.ni) + i;
+  return mad24(mad24(k, M.nj, j), M.ni, i);
 }
 
 // ---- comm phase applied to one particle in flight ----------------------------------------------

@@ -434,6 +434,13 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
   double t = 0, x = 0, y = 0, z = 0, vx = 0, vy = 0, vz = 0, ee = 0;
   Blk B;
   gcptr f0 = nullptr, f1 = nullptr, f2 = nullptr;  // this block's cell arrays
+  // EXACT gray IMC kernels: the mean-free-path arrays of all resident blocks span < 4 GiB
+  // (jb_mesh_create), so a lane keeps the byte offset of its block's pair of arrays (32 bits)
+  // instead of two pointers and gathers through scalar base + 32-bit vector offset
+  constexpr bool kOff32 = GRAY != 0 && !DDMC && EXACT;
+  unsigned lam_off = 0u;
+  const char *const lam_abs0 = (const char *)M.lam_base;
+  const char *const lam_sc0 = (const char *)(M.lam_base + M.ntot);
   double fd[3] = {0.0, 0.0, 0.0};                  // EXACT: the block's nudge widths
   // deferred direction of the last DDMC leak (packed-record DDMC kernels; see ddmc_step_event)
   int pend = -1;
@@ -444,7 +451,9 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
   double lam_cur = 0.0;
 
   auto bind_arrays = [&](int blk) {
-    if constexpr (kFastGray) {  // (library-owned, contiguous: no pointer-table load)
+    if constexpr (kOff32) {
+      lam_off = (unsigned)(2 * blk) * ((unsigned)M.ntot * 8u);
+    } else if constexpr (kFastGray) {  // (library-owned, contiguous: no pointer-table load)
       f0 = (gcptr)(M.lam_base + (long long)(2 * blk) * M.ntot);
       f1 = (gcptr)(M.lam_base + (long long)(2 * blk + 1) * M.ntot);
     } else if constexpr (kPackedDdmc) {
@@ -455,6 +464,25 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
       f0 = (gcptr)M.rho[blk];
       f1 = (gcptr)M.sie[blk];
       f2 = (gcptr)M.fleck[blk];
+    }
+  };
+  // gray IMC kernels: the mean free paths of the lane's cell, requested as soon as the cell is
+  // known (when a photon is loaded or relocated, and at the end of a pass for the next one) so
+  // that the step at the top of a pass does not wait for the gather
+#ifndef JB_PREFETCH_LAM
+#define JB_PREFETCH_LAM 1
+#endif
+  constexpr bool kPrefetch = kFastGray && JB_PREFETCH_LAM;
+  double lam_a_cur = 0.0, lam_s_cur = 0.0;
+  auto fetch_lam = [&]() {
+    const int q = cidx(M, kp, jp, ip);
+    if constexpr (kOff32) {
+      const unsigned off = ((unsigned)q << 3) + lam_off;
+      if constexpr (!kNoAbs) lam_a_cur = *(gcptr)(lam_abs0 + off);
+      lam_s_cur = *(gcptr)(lam_sc0 + off);
+    } else {
+      if constexpr (!kNoAbs) lam_a_cur = f0[q];
+      lam_s_cur = f1[q];
     }
   };
   auto bind_block = [&](int blk) {
@@ -502,6 +530,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
         xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // next launch's transport.cpp:96
         ls = (kDir ? t > 0.0 : t < t_end) ? LS_RUN : LS_DONE;
         if constexpr (kPackedDdmc) lam_cur = f2[cidx(M, kp, jp, ip)];
+        if constexpr (kPrefetch) fetch_lam();
       }
     }
   };
@@ -536,6 +565,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
     bind_arrays(b);
     ls = (kDir ? t > 0.0 : t < t_end) ? LS_RUN : LS_DONE;
     if constexpr (kPackedDdmc) lam_cur = f2[cidx(M, kp, jp, ip)];
+    if constexpr (kPrefetch) fetch_lam();
     return true;
   };
 
@@ -657,6 +687,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
           } else {
             ls = (t < t_end) ? LS_RUN : LS_DONE;    // already at census: nothing to track
           }
+          if constexpr (kPrefetch) fetch_lam();
         }
       }
     } else {
@@ -738,14 +769,27 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
         if (ls == LS_RUN) {
           // per-cell mean free paths precomputed by k_fleck: two gathers instead of three, and
           // no division (same values: same operations on the same operands)
-          const int q = cidx(M, kp, jp, ip);
+          double lam_a = 0.0, lam_s;
+          if constexpr (kPrefetch) {
+            lam_a = lam_a_cur; lam_s = lam_s_cur;
+          } else {
+            const int q = cidx(M, kp, jp, ip);
+            if constexpr (kOff32) {
+              const unsigned off = ((unsigned)q << 3) + lam_off;
+              if constexpr (!kNoAbs) lam_a = *(gcptr)(lam_abs0 + off);
+              lam_s = *(gcptr)(lam_sc0 + off);
+            } else {
+              if constexpr (!kNoAbs) lam_a = f0[q];
+              lam_s = f1[q];
+            }
+          }
           bool is_absorbed, is_scattered;
           if constexpr (kDir) {
             DirGeom g;
             g.x0[0] = B.x0[0]; g.x0[1] = B.x0[1]; g.x0[2] = B.x0[2];
             g.dx[0] = B.dx[0]; g.dx[1] = B.dx[1]; g.dx[2] = B.dx[2];
             g.fd[0] = fd[0]; g.fd[1] = fd[1]; g.fd[2] = fd[2];
-            imc_step_dir<NDIM, kNoAbs, EXACT>(g, B.dx_push, kNoAbs ? 0.0 : f0[q], f1[q], rng, t, x, y, z,
+            imc_step_dir<NDIM, kNoAbs, EXACT>(g, B.dx_push, lam_a, lam_s, rng, t, x, y, z,
                                               vx, vy, vz, ip, jp, kp, is_absorbed, is_scattered);
           } else {
             ImcCell c;
@@ -761,8 +805,8 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
               c.fdx = kEpsImc * (c.xu - c.xl); c.fdy = kEpsImc * (c.yu - c.yl);
               c.fdz = kEpsImc * (c.zu - c.zl);
             }
-            imc_step_fast<NDIM, kNoAbs, false>(c, vv, P.rc, t_end, B.dx_push, kNoAbs ? 0.0 : f0[q],
-                                               f1[q], rng, t, x, y, z, vx, vy, vz, ip, jp, kp,
+            imc_step_fast<NDIM, kNoAbs, false>(c, vv, P.rc, t_end, B.dx_push, lam_a,
+                                               lam_s, rng, t, x, y, z, vx, vy, vz, ip, jp, kp,
                                                is_absorbed, is_scattered);
           }
           if (!on_block(M, ip, jp, kp)) {
@@ -776,6 +820,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
             }
             ls = LS_DONE;
           } else {
+            if constexpr (kPrefetch) fetch_lam();  // (for the next pass, ahead of the scatter)
             if constexpr (kDir) {
               if (is_scattered) scatter_dir(rng, vx, vy, vz);
               if (!(t > 0.0)) ls = LS_DONE;

@@ -69,8 +69,13 @@ __shared__ double lds_sc2_tab[JB_SC2_N + 1][2];
 
 // Copies the three tables into this workgroup's LDS (8.2 KB); ends with a barrier.
 __device__ __forceinline__ void load_math_tables() {
-  for (int q = threadIdx.x; q < JB_LOG_N * 3; q += blockDim.x)
-    lds_log_tab[q / 3][q % 3] = (&jb_log_tab[0][0])[q];
+  // LDS row: {1/c, log c (one double: the lean logarithm), log c in two parts (hi, lo)}
+  for (int q = threadIdx.x; q < JB_LOG_N; q += blockDim.x) {
+    lds_log_tab[q][0] = jb_log_tab[q][0];
+    lds_log_tab[q][1] = jb_log_tab[q][1] + jb_log_tab[q][2];
+    lds_log_tab[q][2] = jb_log_tab[q][1];
+    lds_log_tab[q][3] = jb_log_tab[q][2];
+  }
   for (int q = threadIdx.x; q < (JB_SC_N + 1) * 2; q += blockDim.x)
     (&lds_sc_tab[0][0])[q] = (&jb_sc_tab[0][0])[q];
   for (int q = threadIdx.x; q < (JB_SC2_N + 1) * 2; q += blockDim.x)
@@ -135,7 +140,7 @@ __device__ __forceinline__ double m_log(double x) {  // x positive, finite, norm
   const int i = (int)((th >> 13) & (JB_LOG_N - 1));
   const int k = (int)th >> 20;
   const double z = __hiloint2double((int)(hx - (th & 0xfff00000u)), __double2loint(x));
-  const double invc = lds_log_tab[i][0], lc_hi = lds_log_tab[i][1], lc_lo = lds_log_tab[i][2];
+  const double invc = lds_log_tab[i][0], lc_hi = lds_log_tab[i][2], lc_lo = lds_log_tab[i][3];
   const double r = fma(z, invc, -1.0);
   const double kd = (double)k;
   const double w = fma(kd, ln2_hi, lc_hi);  // exact: both terms are short
@@ -151,21 +156,20 @@ __device__ __forceinline__ double m_log(double x) {  // x positive, finite, norm
   return fma(r2, p, lo) + hi;
 }
 
-// ... and the logarithm without the compensated low-order sum: k ln2 + log c + (r + r^2 P(r))
-// added in plain double (error <= 2 ulp of the result for the arguments in (0, 1) the kernels
-// feed it; next to x = 1 the table row is {1, 0, 0} and the result is r + r^2 P(r) itself).
+// ... the logarithm without the compensated low-order sum: k ln2 + log c in one fused
+// multiply-add on the rounded constants, plus r + r^2 P(r), added in plain double (<= 3 ulp of the
+// result for the arguments in (0, 1) the kernels feed it, measured <= 2; next to x = 1 the table
+// row is {1, 0} and the result is r + r^2 P(r) itself) ...
 __device__ __forceinline__ double m_log_lean(double x) {
-  constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  constexpr double ln2 = 6.93147180559945286227e-01;
   const uint32_t hx = (uint32_t)__double2hiint(x);
   const uint32_t th = hx - (uint32_t)(JB_LOG_OFF >> 32);
   const int i = (int)((th >> 13) & (JB_LOG_N - 1));
   const int k = (int)th >> 20;
   const double z = __hiloint2double((int)(hx - (th & 0xfff00000u)), __double2loint(x));
-  const double invc = lds_log_tab[i][0], lc_hi = lds_log_tab[i][1], lc_lo = lds_log_tab[i][2];
+  const double invc = lds_log_tab[i][0], lc = lds_log_tab[i][1];
   const double r = fma(z, invc, -1.0);
-  const double kd = (double)k;
-  const double w = fma(kd, ln2_hi, lc_hi);
-  const double wl = fma(kd, ln2_lo, lc_lo);
+  const double w = fma((double)k, ln2, lc);
   const double r2 = r * r;
   double p = m_fma(r, -0.125, 1.0 / 7.0);
   p = m_fma(r, p, -1.0 / 6.0);
@@ -173,7 +177,19 @@ __device__ __forceinline__ double m_log_lean(double x) {
   p = m_fma(r, p, -0.25);
   p = m_fma(r, p, 1.0 / 3.0);
   p = m_fma(r, p, -0.5);
-  return w + (wl + fma(r2, p, r));
+  return w + fma(r2, p, r);
+}
+
+// ... and the square root of 1 - mu^2 (in [2^-52, 1]) from the hardware's reciprocal square root
+// with one coupled refinement step and one residual correction (m_sqrt: two, and a refined
+// half-reciprocal); <= 2 ulp, measured in tests/test_gpu_lean.py.
+__device__ __forceinline__ double m_sqrt_lean(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  const double h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  return fma(fma(-g, g, x), h, g);
 }
 
 __device__ __forceinline__ void m_sincos(double x, double &sn, double &cs) {  // 0 <= x <= 2 pi

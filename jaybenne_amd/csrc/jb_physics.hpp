@@ -344,7 +344,7 @@ __device__ __forceinline__ void scatter_dir(Rng &rng, double &ox, double &oy, do
   double xi1, xi2;
   rng.drand2(xi1, xi2);
   const double mu = fma(2.0, xi1, -1.0);
-  const double st = m_sqrt(1.0 - mu * mu);
+  const double st = m_sqrt_lean(1.0 - mu * mu);
   double sn, cs;
   m_sincos2pi(xi2, sn, cs);
   ox = st * cs;

@@ -17,7 +17,7 @@ for item in "$@"; do
   for p in A B C; do
     eval "CN=\$P$p"
     timeout -k 10 240 rocprofv3 --kernel-trace --pmc $CN --output-format csv -d gpurun_out/pmc2_${w}_${name}_$p -o runc -- \
-        python3 bench.py --workload $w --particles-per-gpu $n --steps 1 --warmup 0 --no-cpu-baseline \
+        python3 bench.py --workload $w --particles-per-gpu $n --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant \
         > gpurun_out/pmc2_${w}_${name}_$p.json 2> gpurun_out/pmc2_err.txt
     echo "pmc pass $p of $item done"
   done

@@ -3,20 +3,24 @@
 and prints the derived per-pass / per-event figures (see profiles/README.md for the formulas)."""
 import csv, glob, json, os, sys
 w, name = sys.argv[1], sys.argv[2]
-tot, dur = {}, []
+tot, dur, per_pass = {}, [], {}
 for p in "ABC":
     d = f"gpurun_out/pmc2_{w}_{name}_{p}"
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if "k_transport" not in r["Kernel_Name"] and "k_ddmc_all" not in r["Kernel_Name"]:
                 continue
-            tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            per_pass.setdefault(r["Counter_Name"], {}).setdefault(p, 0.0)
+            per_pass[r["Counter_Name"]][p] += float(r["Counter_Value"])
             tot["_vgpr"] = r.get("VGPR_Count") or r.get("Arch_VGPR_Count")
             tot["_kernel"] = r["Kernel_Name"][:60]
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if "k_transport" in r["Kernel_Name"] or "k_ddmc_all" in r["Kernel_Name"]:
                 dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+# a counter collected in several passes (SQ_INSTS_VALU): the mean over those passes
+for c, by_pass in per_pass.items():
+    tot[c] = sum(by_pass.values()) / len(by_pass)
 b = json.load(open(f"gpurun_out/pmc2_{w}_{name}_A.json"))
 k = b["kernel_diagnostics"]
 ev, passes = k["n_events"], k["n_wave_passes"]
