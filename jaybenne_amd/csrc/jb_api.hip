@@ -16,6 +16,7 @@
 
 #include "../../include/jaybenne_amd.h"
 #include "jb_kernels.hpp"
+#include "jb_kernel_hybrid.hpp"
 
 using namespace jb;
 
@@ -623,7 +624,7 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
                                                      kBlock, 0) != hipSuccess || occ < 1)          \
       occ = 3;                                                                                     \
     const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
-    const int *pair_flag = (DDMC && G != 0 && M.nblocks <= kLdsBlocks) ? M.not_all_ddmc : nullptr; \
+    const int *pair_flag = nullptr;                                                                \
     hipLaunchKernelGGL((k_transport<NDIM, DDMC, T, G, X, L>), dim3(g), dim3(kBlock), 0,            \
                        ctx->stream, M, ctx->dp, S, t_start, dt, first, last, ctx->counters_d,      \
                        pair_flag);                                                                 \
@@ -649,24 +650,59 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
   } while (0)
   mesh->last_pair = "";
   if constexpr (DDMC) {
-    // every cell a DDMC cell: the lean kernel (else it returns at once); it keeps the per-block
-    // tables in LDS, so meshes with more resident blocks than fit there stay with k_transport
+    // Gray opacities: UpdateDerivedTransportFields has packed the cell records and left a flag on
+    // the device saying whether every cell takes DDMC steps.  Every cell: k_ddmc_all; a mix of IMC
+    // and DDMC cells: k_hybrid.  Both keep the per-block tables in LDS, so meshes with more resident
+    // blocks than fit there stay with the general kernel below.
     if (gray && M.ddmc_cell && M.nblocks <= kLdsBlocks) {
-      mesh->last_pair = NDIM == 1 ? (tally ? "k_ddmc_all<1, true>" : "k_ddmc_all<1, false>")
-                        : NDIM == 2 ? (tally ? "k_ddmc_all<2, true>" : "k_ddmc_all<2, false>")
-                                    : (tally ? "k_ddmc_all<3, true>" : "k_ddmc_all<3, false>");
-      int occ = 0;
-      if (tally) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, true>, kBlock, 0) != hipSuccess || occ < 1) occ = 4;
-        const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
-        hipLaunchKernelGGL((k_ddmc_all<NDIM, true>), dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, S,
-                           t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
-      } else {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, false>, kBlock, 0) != hipSuccess || occ < 1) occ = 4;
-        const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
-        hipLaunchKernelGGL((k_ddmc_all<NDIM, false>), dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, S,
-                           t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
+      int *flag_h = (int *)(ctx->counters_h + kCounterWords - 1);
+      *flag_h = 1;
+      (void)hipMemcpyAsync(flag_h, M.not_all_ddmc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+      (void)hipStreamSynchronize(ctx->stream);
+      const bool noabs_h = ctx->dp.kappa_a == 0.0;
+      if (*flag_h == 0) {
+        mesh->last_variant = NDIM == 1 ? (tally ? "k_ddmc_all<1, true>" : "k_ddmc_all<1, false>")
+                             : NDIM == 2 ? (tally ? "k_ddmc_all<2, true>" : "k_ddmc_all<2, false>")
+                                         : (tally ? "k_ddmc_all<3, true>" : "k_ddmc_all<3, false>");
+        int occ = 0;
+        if (tally) {
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, true>, kBlock, 0) != hipSuccess || occ < 1) occ = 3;
+          const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
+          hipLaunchKernelGGL((k_ddmc_all<NDIM, true>), dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, S,
+                             t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
+        } else {
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, false>, kBlock, 0) != hipSuccess || occ < 1) occ = 3;
+          const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
+          hipLaunchKernelGGL((k_ddmc_all<NDIM, false>), dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, S,
+                             t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
+        }
+        return;
       }
+      // (variant string: NDIM, TALLY, NOABS, MODE: 0 exact arithmetic, 1 lean, 2 lean on exact geometry)
+#define JB_LAUNCH_H(T, NA, MD)                                                                     \
+  do {                                                                                             \
+    int occ = 0;                                                                                   \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_hybrid<NDIM, T, NA, MD>, kBlock, 0)   \
+            != hipSuccess || occ < 1)                                                              \
+      occ = 3;                                                                                     \
+    const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
+    hipLaunchKernelGGL((k_hybrid<NDIM, T, NA, MD>), dim3(g), dim3(kBlock), 0, ctx->stream, M,      \
+                       ctx->dp, S, t_start, dt, first, last, ctx->counters_d);                     \
+    mesh->last_variant = NDIM == 1 ? "k_hybrid<1, " #T ", " #NA ", " #MD ">"                       \
+                         : NDIM == 2 ? "k_hybrid<2, " #T ", " #NA ", " #MD ">"                     \
+                                     : "k_hybrid<3, " #T ", " #NA ", " #MD ">";                    \
+  } while (0)
+#define JB_LAUNCH_HM(T, NA)                                                                        \
+  do {                                                                                             \
+    if (!ctx->lean_arith) JB_LAUNCH_H(T, NA, 0);                                                   \
+    else if (M.exact) JB_LAUNCH_H(T, NA, 2);                                                       \
+    else JB_LAUNCH_H(T, NA, 1);                                                                    \
+  } while (0)
+      if (tally) { if (noabs_h) JB_LAUNCH_HM(true, true); else JB_LAUNCH_HM(true, false); }
+      else { if (noabs_h) JB_LAUNCH_HM(false, true); else JB_LAUNCH_HM(false, false); }
+#undef JB_LAUNCH_HM
+#undef JB_LAUNCH_H
+      return;
     }
   }
   // gray opacity with kappa = 0 (opacity_model = none): sigma_a = rho * 0 in every cell
@@ -724,16 +760,7 @@ extern "C" jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh,
 }
 
 extern "C" const char *jb_last_transport_variant(const jb_mesh *mesh) {
-  if (!mesh) return "";
-  if (mesh->last_pair[0]) {  // a gray DDMC launch is a pair: the device-side flag says which one ran
-    int flag = 1;
-    if (hipSetDevice(mesh->ctx->device) != hipSuccess ||
-        hipStreamSynchronize(mesh->ctx->stream) != hipSuccess ||
-        hipMemcpy(&flag, mesh->dm.not_all_ddmc, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-      return "";
-    return flag == 0 ? mesh->last_pair : mesh->last_variant;
-  }
-  return mesh->last_variant;
+  return mesh ? mesh->last_variant : "";
 }
 extern "C" int jb_mesh_exact_geometry(const jb_mesh *mesh) { return mesh && mesh->exact_geom; }
 extern "C" jb_status jb_set_arithmetic(jb_context *ctx, int mode) {

@@ -139,6 +139,7 @@ __device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
 constexpr int kLdsBlocks = 128;
 struct LdsBlockTable {
   double xmin[kLdsBlocks][3], dx[kLdsBlocks][3], inv_dx[kLdsBlocks][3];
+  double x0[kLdsBlocks][3];  // coordinate of cell index 0: xmin - first * dx
   double *tally[kLdsBlocks];
   int owned[kLdsBlocks];
   int nbr_ent[kLdsBlocks][6];
@@ -149,6 +150,8 @@ __device__ __forceinline__ void fill_block_table(const DevMesh &M, LdsBlockTable
     (&T.xmin[0][0])[q] = M.blk_xmin[q];
     (&T.dx[0][0])[q] = M.blk_dx[q];
     (&T.inv_dx[0][0])[q] = M.blk_inv_dx[q];
+    const int first = (q % 3 == 0) ? M.is : (q % 3 == 1 ? M.js : M.ks);
+    (&T.x0[0][0])[q] = M.blk_xmin[q] - (double)first * M.blk_dx[q];
   }
   for (int q = threadIdx.x; q < M.nblocks; q += blockDim.x) {
     T.tally[q] = M.tally[q];
@@ -170,12 +173,11 @@ __device__ __forceinline__ void load_block(const DevMesh &M, const LdsBlockTable
     load_block(M, b, B);
     return;
   }
-  const int first[3] = {M.is, M.js, M.ks};
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     B.xmin[d] = T.xmin[b][d];
     B.dx[d] = T.dx[b][d];
-    B.x0[d] = B.xmin[d] - (double)first[d] * B.dx[d];
+    B.x0[d] = T.x0[b][d];
     B.inv_dx[d] = T.inv_dx[b][d];
   }
   B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));
@@ -184,12 +186,11 @@ __device__ __forceinline__ void load_block(const DevMesh &M, const LdsBlockTable
 // ... and without the fallback to the global tables (k_ddmc_all: the host only launches it when
 // the resident blocks fit the LDS table)
 __device__ __forceinline__ void load_block_lds(const DevMesh &M, const LdsBlockTable &T, int b, Blk &B) {
-  const int first[3] = {M.is, M.js, M.ks};
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     B.xmin[d] = T.xmin[b][d];
     B.dx[d] = T.dx[b][d];
-    B.x0[d] = B.xmin[d] - (double)first[d] * B.dx[d];
+    B.x0[d] = T.x0[b][d];
     B.inv_dx[d] = T.inv_dx[b][d];
   }
   B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));

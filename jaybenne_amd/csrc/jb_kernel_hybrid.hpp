@@ -1,0 +1,634 @@
+// jb_kernel_hybrid.hpp -- TransportPhotons_DDMC for gray opacities on meshes where some cells take
+// IMC steps and others DDMC steps (transport_ddmc.cpp:135: dx_push (sigma_s + sigma_a) > tau_ddmc
+// decides per cell and per step): the reference's stepdiff_smr_hybrid deck, BASELINE configs[4].
+//
+// Why a kernel of its own.  On such a deck ~99 % of the events are IMC steps of photons in the
+// optically thin (refined) cells, and about half of the photons live in DDMC cells and take a few
+// tens of steps each.  One loop body that can do either step (k_transport<.., DDMC = true>, which
+// still serves per-event opacities) makes every IMC pass carry the DDMC step's registers: it
+// spilled, and ran 50 % slower than the pure-IMC kernel on the same IMC work.  Here a wave runs TWO
+// event loops and a lane is in one of them at a time:
+//   * the IMC loop of the gray IMC kernels (imc_step_dir / imc_step_fast: cell index from the
+//     nudge predicates, block crossings from the face table, next cell's mean free path requested
+//     ahead), for lanes whose photon is in an IMC cell;
+//   * the DDMC loop of k_ddmc_all ("virtual" state: cell, time, stream, pending leak), for lanes
+//     whose photon is in a DDMC cell;
+//   * a service phase for everything that happens once per history or once per change of regime:
+//     loading / writing back, general relocation (level changes, other ranks), the albedo step
+//     of a photon that arrives in a DDMC cell with a real position (from an IMC cell, from
+//     another block, or freshly loaded next to a face: transport_utils.hpp:279-397), and the
+//     re-materialisation of a DDMC photon that leaked into an IMC cell.
+// Neither loop carries the other's temporaries; what a lane keeps across both is the IMC state
+// (position, direction, time, stream, cell, block geometry) plus the pending leak.  A lane learns
+// the regime of a cell it has just entered from the data it gathers for the next step anyway: the
+// sign of lam_hyb (IMC loop) or of the record's sigma (DDMC loop), both written by k_ddmc_pack.
+// Lanes of the other regime wait (parked) while a loop runs; the IMC loop is left when parked
+// DDMC lanes have waited long enough (kParkBudget lane-passes) and the DDMC loop is cut short when
+// IMC lanes wait (kDdmcMaxPasses).
+//
+// Same draws, same arithmetic, same bits as the reference's per-step choice (tests/test_gpu_parity.py
+// holds it to the oracle on the 2-D / 3-D SMR hybrid decks, one rank and several); MODE picks the
+// arithmetic of the IMC steps exactly as in the gray IMC kernels: 0 = exact (bit-identical to the
+// oracle), 1 = lean, 2 = lean on exact geometry.  DDMC steps have the exact arithmetic only.
+#pragma once
+
+#include "jb_device.hpp"
+
+namespace jb {
+
+#ifndef JB_HYBRID_WAVES_PER_SIMD
+#define JB_HYBRID_WAVES_PER_SIMD 3
+#endif
+#ifndef JB_HYBRID_IMC_BUDGET      // idle lane-passes (lanes that left the IMC loop) that buy a service phase
+#define JB_HYBRID_IMC_BUDGET 96
+#endif
+#ifndef JB_HYBRID_PARK_BUDGET     // lane-passes parked DDMC lanes wait before the DDMC loop is run
+#define JB_HYBRID_PARK_BUDGET 256
+#endif
+#ifndef JB_HYBRID_DDMC_BUDGET     // idle lane-passes in the DDMC loop that buy a service phase
+#define JB_HYBRID_DDMC_BUDGET 256
+#endif
+#ifndef JB_HYBRID_DDMC_MAX_PASSES  // ... and its length while IMC lanes wait
+#define JB_HYBRID_DDMC_MAX_PASSES 24
+#endif
+#ifndef JB_HYBRID_CHUNK
+#define JB_HYBRID_CHUNK 128
+#endif
+
+enum { HS_IDLE = 0, HS_IMC = 1, HS_VIRT = 2, HS_REAL = 3, HS_DONE = 4, HS_RELOC = 5, HS_EMERGE = 6,
+       HS_NEW = 7 };
+
+template <int NDIM, bool TALLY, bool NOABS, int MODE>
+__global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
+    k_hybrid(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
+             long long last, unsigned long long *counters) {
+  __shared__ double lds_tally[TALLY ? kLdsTally : 1];
+  const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
+  if constexpr (TALLY) {
+    if (tally_in_lds)
+      for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) lds_tally[q] = 0.0;
+  }
+  __shared__ LdsBlockTable lds_blocks;
+  fill_block_table(M, lds_blocks);
+  load_math_tables();  // (ends with a barrier)
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  constexpr bool kLean = MODE != 0, kExactG = MODE == 2;
+  constexpr long long kChunk = JB_HYBRID_CHUNK;
+  const double vv = P.c;
+  const double t_end = t_start + dt;
+  const int lane = threadIdx.x & 63;
+  unsigned long long *queue = counters + CNT_QUEUE;
+  const long long per_q = (last - first + kQueues - 1) / kQueues;
+  int cur = blockIdx.x % kQueues, tried = 0;
+  bool more = true;
+  long long chunk_pos = 0, chunk_end = 0;
+
+  unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0;
+  unsigned long long c_ev = 0;   // wave-level: stepping lanes summed over the passes of both loops
+  unsigned int c_ev_real = 0;    // per lane: steps taken in the service phase
+  unsigned int c_pass = 0, c_service = 0;
+
+  // ---- lane state
+  int ls = HS_IDLE;
+  long long n = 0;
+  LcgRng rng(0);
+  int b = 0, ip = 0, jp = 0, kp = 0, status = ST_ACTIVE;
+  // time; for an HS_IMC lane of a lean kernel: the distance left to census c (t_end - t), and
+  // (vx, vy, vz) the unit direction (in_dir)
+  double t = 0.0;
+  double x = 0.0, y = 0.0, z = 0.0, vx = 0.0, vy = 0.0, vz = 0.0;
+  bool in_dir = false;
+  bool real_pos = false;  // x, y, z hold the photon's position (not so for a virtual DDMC lane)
+  // channel of the last DDMC leak (0..5) while its direction is deferred: its two uniforms then
+  // live in (vx, vy) -- the direction they stand for replaces a stale one; -1: the direction is
+  // the one in vx, vy, vz
+  int pend = -1;
+  bool resample = false;  // reached census in a DDMC step: position / direction to be resampled
+  // IMC lanes: geometry of the lane's block (index-0 coordinate, cell width, nudge width per axis)
+  // and the mean free paths of its cell (lam_cur < 0: the cell takes DDMC steps)
+  // (bound when the IMC loop is entered: nothing of it is live in the service phase or the DDMC loop)
+  DirGeom g;
+  double dxp = 0.0, lam_cur = 0.0, lam_a_cur = 0.0;
+
+  const unsigned ntot_u = sgpr_copy((unsigned)M.ntot);
+  const double *rec_base = sgpr_copy_ptr(M.ddmc_base);
+  const double *hyb_base = sgpr_copy_ptr(M.lam_hyb);
+  const int l_ni = (int)sgpr_copy((unsigned)M.ni), l_nj = (int)sgpr_copy((unsigned)M.nj);
+  const int l_is = (int)sgpr_copy((unsigned)M.is), l_ie = (int)sgpr_copy((unsigned)M.ie);
+  const int l_js = (int)sgpr_copy((unsigned)M.js), l_je = (int)sgpr_copy((unsigned)M.je);
+  const int l_ks = (int)sgpr_copy((unsigned)M.ks), l_ke = (int)sgpr_copy((unsigned)M.ke);
+  auto cidx_l = [&](int k, int j, int i) { return mad24(mad24(k, l_nj, j), l_ni, i); };
+  auto on_block_l = [&](int i, int j, int k) {
+    return i >= l_is && i <= l_ie && j >= l_js && j <= l_je && k >= l_ks && k <= l_ke;
+  };
+  auto cell_word = [&](int blk, int q) {  // index of cell q of block blk in the per-cell arrays
+    return (unsigned long long)(unsigned)blk * ntot_u + (unsigned)q;
+  };
+  auto faces_of = [&](Step &s, const Blk &Bq, int i, int j, int k) {  // transport.cpp:114-119
+    s.xl = xc(Bq, 0, i) - 0.5 * Bq.dx[0]; s.xu = xc(Bq, 0, i) + 0.5 * Bq.dx[0];
+    s.yl = xc(Bq, 1, j) - 0.5 * Bq.dx[1]; s.yu = xc(Bq, 1, j) + 0.5 * Bq.dx[1];
+    s.zl = xc(Bq, 2, k) - 0.5 * Bq.dx[2]; s.zu = xc(Bq, 2, k) + 0.5 * Bq.dx[2];
+  };
+  // the 64-byte record of a cell {f sigma_a, +-(sigma_a + sigma_s), six leak opacities}; the sign
+  // of the second entry is negative in a cell that takes IMC steps (k_ddmc_pack)
+  auto load_record = [&](Step &s, int blk, int q) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    typedef const v4d __attribute__((address_space(1))) *grec;
+    const grec rec = (grec)((gcptr)rec_base + 8 * cell_word(blk, q));
+    const v4d r0 = rec[0];
+    const v4d r1 = rec[1];
+    s.ffaa = r0.x; s.sig = r0.y;
+    s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
+  };
+  auto fetch_lam = [&]() {  // the IMC loop's gather for the lane's cell
+    const unsigned long long w = cell_word(b, cidx_l(kp, jp, ip));
+    lam_cur = ((gcptr)hyb_base)[w];
+    if constexpr (!NOABS) lam_a_cur = ((gcptr)M.lam_base)[2ull * (unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip)];
+  };
+  // a photon with a real position in a DDMC cell enters the DDMC loop unless the albedo step
+  // would find it at a face of its cell (k_ddmc_all)
+  auto enter_ddmc = [&](const Blk &Bq) {
+    Step s;
+    faces_of(s, Bq, ip, jp, kp);
+    s.x = x; s.y = y; s.z = z;
+    if (at_cell_face<NDIM>(s)) {
+      ls = HS_REAL;
+    } else {
+      real_pos = false;
+      ls = HS_VIRT;
+    }
+  };
+  // ... and one in an IMC cell enters the IMC loop: lean units
+  auto bind_geometry = [&]() {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      g.dx[d] = lds_blocks.dx[b][d];
+      g.x0[d] = lds_blocks.x0[b][d];
+      g.fd[d] = kEpsImc * g.dx[d];
+    }
+    dxp = dmin(g.dx[0], dmin(g.dx[1], g.dx[2]));
+  };
+  auto enter_imc = [&]() {
+    if constexpr (kLean) {
+      t = vv * (t_end - t);
+      vx *= P.rc; vy *= P.rc; vz *= P.rc;
+      in_dir = true;
+    }
+    ls = HS_IMC;
+  };
+  // one face of the lane's block crossed by an IMC step into a resident block of the same size, a
+  // periodic wrap or a reflection: served from the face table (k_transport's cross_face)
+  auto cross_face = [&](auto axis_c, bool up, double &pos, double &vel, int &idx, int first_i,
+                        int last_i) -> bool {
+    constexpr int AXIS = decltype(axis_c)::value;
+    const int ent = lds_blocks.nbr_ent[b][2 * AXIS + (int)up];
+    if (ent < 0) return false;
+    const int kind = ent >> 28;
+    bool at_first = up;
+    if (kind != 0) {
+      const double lo = M.gmin[AXIS], hi = M.gmax[AXIS];
+      if (kind == 1) {  // periodic
+        pos = up ? lo + (pos - hi) : hi - (lo - pos);
+      } else {  // reflecting (boundaries.hpp:46-82): back into the same block
+        pos = up ? hi - (pos - hi) : lo + (lo - pos);
+        vel = -vel;
+        at_first = !up;
+      }
+    }
+    b = ent & 0x0fffffff;
+    g.x0[AXIS] = lds_blocks.x0[b][AXIS];
+    idx = at_first ? first_i : last_i;
+    if (!((kLean ? t > 0.0 : t < t_end))) ls = HS_DONE;
+    else fetch_lam();
+    return true;
+  };
+
+  int park_waste = 0;  // wave-level: lane-passes parked DDMC lanes have waited since the last DDMC loop
+
+  for (;;) {
+    // ================================ SERVICE ================================
+    ++c_service;
+    // lanes that left the IMC loop of a lean kernel: back to time and velocity (census: the
+    // distance left is exactly 0, t = t_end)
+    if constexpr (kLean) {
+      if (in_dir && ls != HS_IMC) {
+        t = fma(-t, P.rc, t_end);
+        vx *= vv; vy *= vv; vz *= vv;
+        in_dir = false;
+      }
+    }
+    // -- 1. block crossings: the comm phase of the reference for one particle in flight
+    if (ls == HS_RELOC) {
+      Blk Bo;
+      load_block_lds(M, lds_blocks, b, Bo);
+      Step s;
+      s.vv = vv; s.pend = pend; s.pz1 = vx; s.pz2 = vy;
+      if (!real_pos) {
+        // leak out of the block from the virtual state: the position the step function gave the
+        // particle (transport_utils.hpp:209-263), from the cell it left and the channel
+        const int axis = pend >> 1;
+        const bool up = (pend & 1) != 0;
+        const int step = up ? 1 : -1;
+        faces_of(s, Bo, ip - (axis == 0 ? step : 0), jp - (axis == 1 ? step : 0),
+                 kp - (axis == 2 ? step : 0));
+        const double dx = s.xu - s.xl, dy = s.yu - s.yl, dz = s.zu - s.zl;
+        const double eps = kEpsDdmc;
+        x = (axis == 0) ? (up ? s.xu + eps * dx : s.xl - eps * dx) : s.xl + 0.5 * dx;
+        y = (axis == 1) ? (up ? s.yu + eps * dy : s.yl - eps * dy) : s.yl + 0.5 * dy;
+        z = (axis == 2) ? (up ? s.zu + eps * dz : s.zl - eps * dz) : s.zl + 0.5 * dz;
+      }
+      // transport_ddmc.cpp:203-211: zero velocity flags a DDMC leak for SampleDDMCBlockFace
+      // (multi-D); in 1-D the direction travels with the particle
+      if (pend >= 0) {
+        if constexpr (multi_d) {
+          vx = 0.0; vy = 0.0; vz = 0.0;
+        } else {
+          s.vx = vx; s.vy = vy; s.vz = vz;
+          materialise_dir(s);
+          vx = s.vx; vy = s.vy; vz = s.vz;
+        }
+        pend = -1;
+      }
+      real_pos = true;
+      if (!apply_swarm_bcs<NDIM>(M, x, y, z, vx, vy, vz)) {
+        status = ST_ESCAPED;
+        ls = HS_DONE;
+      } else {
+        const int gb = find_block<NDIM>(M, x, y, z);
+        const int li = M.local_index[gb];
+        if (li < 0) {  // not resident here: hand the particle to the block's owner
+          status = ST_OUTGOING;
+          b = gb;  // global id travels in blk
+          ls = HS_DONE;
+        } else {
+          b = li;
+          Blk Bn;
+          load_block_lds(M, lds_blocks, b, Bn);
+          if constexpr (multi_d)
+            sample_block_face<NDIM>(M, P, Bn, b, rng, x, y, z, vx, vy, vz, ip, jp, kp);
+          xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);
+          ls = HS_NEW;
+        }
+      }
+    }
+    // -- 2. a DDMC photon that leaked into an IMC cell of its block: position and direction as
+    //       the step function gave them (transport_utils.hpp:209-263), from the cell it left
+    if (ls == HS_EMERGE) {
+      Blk Bo;
+      load_block_lds(M, lds_blocks, b, Bo);
+      Step s;
+      s.vv = vv; s.pend = pend; s.pz1 = vx; s.pz2 = vy;
+      const int axis = pend >> 1;
+      const bool up = (pend & 1) != 0;
+      const int step = up ? 1 : -1;
+      faces_of(s, Bo, ip - (axis == 0 ? step : 0), jp - (axis == 1 ? step : 0),
+               kp - (axis == 2 ? step : 0));
+      const double dx = s.xu - s.xl, dy = s.yu - s.yl, dz = s.zu - s.zl;
+      const double eps = kEpsDdmc;
+      x = (axis == 0) ? (up ? s.xu + eps * dx : s.xl - eps * dx) : s.xl + 0.5 * dx;
+      y = (axis == 1) ? (up ? s.yu + eps * dy : s.yl - eps * dy) : s.yl + 0.5 * dy;
+      z = (axis == 2) ? (up ? s.zu + eps * dz : s.zl - eps * dz) : s.zl + 0.5 * dz;
+      s.vx = vx; s.vy = vy; s.vz = vz;
+      materialise_dir(s);  // (an IMC step reads the direction)
+      vx = s.vx; vy = s.vy; vz = s.vz;
+      pend = -1;
+      real_pos = true;
+      ls = HS_NEW;
+    }
+    // -- 3a. finished particles: census resampling, write-back, tally
+    if (ls == HS_DONE) {
+      if (status != ST_OUTGOING && status != ST_ESCAPED) {
+        Blk Bd;
+        load_block_lds(M, lds_blocks, b, Bd);
+        Step s;
+        s.vv = vv;
+        faces_of(s, Bd, ip, jp, kp);
+        if (resample) {  // transport_utils.hpp:265-276, once per history
+          ddmc_census_resample(s, rng);
+          x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
+          pend = -1;
+        } else if (!real_pos) {
+          // absorbed in the virtual state: the albedo step left it at the cell centre
+          // (transport_utils.hpp:392-396), with the direction of its last leak
+          x = 0.5 * (s.xl + s.xu); y = 0.5 * (s.yl + s.yu); z = 0.5 * (s.zl + s.zu);
+        }
+        if (pend >= 0) {
+          s.pend = pend; s.pz1 = vx; s.pz2 = vy;
+          s.vx = vx; s.vy = vy; s.vz = vz;
+          materialise_dir(s);
+          vx = s.vx; vy = s.vy; vz = s.vz;
+          pend = -1;
+        }
+        if ((status == ST_ACTIVE || status == ST_OUTGOING_ABSORBED) && lds_blocks.owned[b] == 0) {
+          if (status == ST_ACTIVE) status = ST_OUTGOING;  // the owner of the block tallies it
+          b = M.gid[b];
+        } else if (status == ST_ACTIVE) {
+          if constexpr (TALLY) {  // jaybenne.cpp:547-561
+            const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
+            if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], S.w[n] / dv);
+            else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
+          }
+        }
+      }
+      S.blk[n] = b;
+      S.t[n] = t;
+      S.x[n] = x; S.y[n] = y; S.z[n] = z;
+      S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+      S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
+      S.status[n] = status;
+      S.rng[n] = rng.s;
+      if (status == ST_ACTIVE) ++c_census;
+      else if (status == ST_ABSORBED) ++c_abs;
+      else if (status == ST_ESCAPED) ++c_esc;
+      else ++c_out;
+      resample = false;
+      ls = HS_IDLE;
+    }
+    // -- 3b. every idle lane claims the next slot of the wave's chunk (chunks of consecutive slots,
+    //        one atomic per chunk)
+    long long cand = -1;
+    int st_in = ST_ABSORBED, b_in = 0;
+    unsigned long long rng_in = 0ull;
+    double t_in = 0.0, x_in = 0.0, y_in = 0.0, z_in = 0.0, vx_in = 0.0, vy_in = 0.0, vz_in = 0.0;
+    {
+      unsigned long long need = __ballot(ls == HS_IDLE);
+      while (need != 0ull && more) {
+        if (chunk_pos >= chunk_end) {
+          const long long q_first = first + (long long)cur * per_q;
+          long long q_last = q_first + per_q;
+          if (q_last > last) q_last = last;
+          unsigned long long base = 0;
+          if (lane == 0) base = atomicAdd(&queue[cur], (unsigned long long)kChunk);
+          chunk_pos = q_first + (long long)uniform_u64(base);
+          chunk_end = chunk_pos + kChunk < q_last ? chunk_pos + kChunk : q_last;
+          if (chunk_pos >= q_last) {  // this queue is drained: move on
+            chunk_pos = chunk_end = 0;
+            cur = (cur + 1) % kQueues;
+            if (++tried == kQueues) more = false;
+            continue;
+          }
+        }
+        const int want = __popcll(need);
+        const long long avail = chunk_end - chunk_pos;
+        const int give = (long long)want < avail ? want : (int)avail;
+        const int rank = __popcll(need & ((1ull << lane) - 1ull));
+        const bool mine = ((need >> lane) & 1ull) != 0ull && rank < give;
+        if (mine) {
+          cand = chunk_pos + rank;
+          st_in = S.status[cand];
+          rng_in = S.rng[cand];
+          b_in = S.blk[cand];
+          t_in = S.t[cand]; x_in = S.x[cand]; y_in = S.y[cand]; z_in = S.z[cand];
+          vx_in = S.vx[cand]; vy_in = S.vy[cand]; vz_in = S.vz[cand];
+        }
+        chunk_pos += give;
+        need &= ~__ballot(mine);
+      }
+    }
+    // -- 3c. the lanes that claimed a slot in 3a take their new particle
+    if (ls == HS_IDLE && cand >= 0 && st_in == ST_ACTIVE) {
+      n = cand;
+      rng.s = rng_in;
+      b = b_in;
+      t = t_in;
+      x = x_in; y = y_in; z = z_in; vx = vx_in; vy = vy_in; vz = vz_in;
+      status = ST_ACTIVE;
+      resample = false;
+      pend = -1;
+      real_pos = true;
+      in_dir = false;
+      Blk Bn;
+      load_block_lds(M, lds_blocks, b, Bn);
+      xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);  // transport.cpp:96
+      ls = HS_NEW;
+    }
+    // -- 4. one step with the real position in a DDMC cell (arrival from an IMC cell or another
+    //       block, a particle loaded next to a face, the steps after an albedo rejection): the
+    //       general step functions (transport_ddmc.cpp:137-179)
+    if (ls == HS_REAL) {
+      ++c_ev_real;
+      Blk Br;
+      load_block_lds(M, lds_blocks, b, Br);
+      Step s;
+      s.t_start = t_start; s.dt = dt; s.vv = vv; s.rvv = P.rc; s.dx_push = Br.dx_push;
+      faces_of(s, Br, ip, jp, kp);
+      s.t = t; s.x = x; s.y = y; s.z = z; s.vx = vx; s.vy = vy; s.vz = vz;
+      s.ip = ip; s.jp = jp; s.kp = kp;
+      s.is_absorbed = false; s.is_scattered = false; s.is_rejected = false;
+      s.pend = pend; s.pz1 = vx; s.pz2 = vy;
+      load_record(s, b, cidx_l(kp, jp, ip));
+      ptcl_ddmc_albedo<NDIM, true>(s, rng);
+      bool census = false;
+      if (!s.is_rejected) census = ddmc_step_event<NDIM, true, true>(s, rng);
+      t = s.t; x = s.x; y = s.y; z = s.z; vz = s.vz;
+      pend = s.pend;
+      vx = pend >= 0 ? s.pz1 : s.vx;  // (a deferred leak: its uniforms instead of a direction)
+      vy = pend >= 0 ? s.pz2 : s.vy;
+      xtoijk<NDIM>(M, Br, x, y, z, ip, jp, kp);  // transport.cpp:146
+      if (!s.is_rejected) resample = census;  // (the flag of the last DDMC step)
+      real_pos = true;
+      if (!on_block_l(ip, jp, kp)) {
+        // (a rejected particle keeps its direction: pend < 0; a leak is flagged in step 1)
+        ls = HS_RELOC;
+      } else if (s.is_absorbed) {  // transport.cpp:157-163
+        if (lds_blocks.owned[b] != 0) {
+          atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], S.w[n]);
+          status = ST_ABSORBED;
+        } else {
+          status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
+        }
+        ls = HS_DONE;
+      } else if (!(t < t_end)) {  // census
+        ls = HS_DONE;
+      } else if (!s.is_rejected) {
+        real_pos = false;  // leaked into a neighbouring cell of this block: virtual from here on
+        ls = HS_VIRT;      // (the DDMC loop finds out whether that cell takes DDMC steps)
+      } else {
+        ls = HS_NEW;       // rejected: a real position in the cell on the other side of the face
+      }
+    }
+    // -- 5. a real position in a cell of a resident block: which loop?
+    if (ls == HS_NEW) {
+      if (!(t < t_end)) {
+        ls = HS_DONE;  // already at census: nothing to track
+      } else {
+        const double lam = ((gcptr)hyb_base)[cell_word(b, cidx_l(kp, jp, ip))];
+        if (__double2hiint(lam) < 0) {
+          Blk Bn;
+          load_block_lds(M, lds_blocks, b, Bn);
+          enter_ddmc(Bn);
+        } else {
+          enter_imc();
+        }
+      }
+    }
+    // lanes that still need the service phase are served before a loop is entered
+    if (__ballot(ls == HS_REAL || ls == HS_DONE || ls == HS_RELOC || ls == HS_EMERGE || ls == HS_NEW) != 0ull)
+      continue;
+    const int n_imc = __popcll(__ballot(ls == HS_IMC));
+    const int n_virt = __popcll(__ballot(ls == HS_VIRT));
+    if (n_imc == 0 && n_virt == 0) {
+      if (more) continue;
+      break;
+    }
+
+    // ================================ DDMC EVENTS =============================
+    // (run when the parked lanes have waited long enough, or nothing else can run)
+    if (n_virt > 0 && (n_imc == 0 || park_waste >= JB_HYBRID_PARK_BUDGET)) {
+      park_waste = 0;
+      int waste = 0, passes = 0;
+      int nrun = n_virt;
+      int thresh = 1;
+      while (nrun >= thresh) {
+        Step s;
+        if (ls == HS_VIRT) {
+          s.t_start = t_start; s.dt = dt; s.vv = vv;
+          s.t = t;
+          s.ip = ip; s.jp = jp; s.kp = kp;
+          s.is_absorbed = false;
+          s.pend = pend; s.pz1 = vx; s.pz2 = vy;
+          s.xl = s.yl = s.zl = 0.0; s.xu = s.yu = s.zu = 1.0;
+          load_record(s, b, cidx_l(kp, jp, ip));
+          // the cell the last leak led into takes IMC steps: out of this loop
+          if (__double2hiint(s.sig) < 0) ls = HS_EMERGE;
+        }
+        const int stepping = __popcll(__ballot(ls == HS_VIRT));
+        ++c_pass;
+        c_ev += (unsigned int)stepping;
+        if (ls == HS_VIRT) {
+          const bool census = ddmc_step_event<NDIM, true, true>(s, rng);
+          t = s.t;
+          ip = s.ip; jp = s.jp; kp = s.kp;  // = Xtoijk of the position the step gives
+          pend = s.pend;
+          if (pend >= 0) { vx = s.pz1; vy = s.pz2; }
+          resample = census;
+          if (!on_block_l(ip, jp, kp)) {
+            ls = HS_RELOC;  // a leak through a block face: the service phase
+          } else if (s.is_absorbed) {  // transport.cpp:157-163
+            if (lds_blocks.owned[b] != 0) {
+              atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], S.w[n]);
+              status = ST_ABSORBED;
+            } else {
+              status = ST_OUTGOING_ABSORBED;
+            }
+            ls = HS_DONE;
+          } else if (!(t < t_end)) {  // census
+            ls = HS_DONE;
+          }
+        }
+        nrun = __popcll(__ballot(ls == HS_VIRT));
+        waste += n_virt - nrun;
+        ++passes;
+        if (waste >= JB_HYBRID_DDMC_BUDGET || (n_imc > 0 && passes >= JB_HYBRID_DDMC_MAX_PASSES)) thresh = 65;
+      }
+      continue;  // (service: the lanes that left the loop)
+    }
+
+    // ================================ IMC EVENTS ==============================
+    {
+      if (ls == HS_IMC) {
+        bind_geometry();
+        fetch_lam();
+      }
+      int waste = 0;
+      int nrun = n_imc;
+      int thresh = 1;
+      while (nrun >= thresh) {
+        // the cell entered in the last pass takes DDMC steps: out of this loop (albedo: service)
+        if (ls == HS_IMC && __double2hiint(lam_cur) < 0) ls = HS_REAL;
+        const int stepping = __popcll(__ballot(ls == HS_IMC));
+        ++c_pass;
+        c_ev += (unsigned int)stepping;
+        bool crossing = false;  // left its block in this pass
+        if (ls == HS_IMC) {
+          bool is_absorbed, is_scattered;
+          if constexpr (kLean) {
+            imc_step_dir<NDIM, NOABS, kExactG>(g, dxp, lam_a_cur, lam_cur, rng, t, x, y, z, vx, vy, vz,
+                                               ip, jp, kp, is_absorbed, is_scattered);
+          } else {
+            ImcCell c;
+            if (M.exact) {  // (uniform) the same doubles in 3 instead of 8 operations per axis
+              c.xl = m_fma((double)ip, g.dx[0], g.x0[0]); c.xu = c.xl + g.dx[0];
+              c.yl = m_fma((double)jp, g.dx[1], g.x0[1]); c.yu = c.yl + g.dx[1];
+              c.zl = m_fma((double)kp, g.dx[2], g.x0[2]); c.zu = c.zl + g.dx[2];
+              c.fdx = g.fd[0]; c.fdy = g.fd[1]; c.fdz = g.fd[2];
+            } else {  // transport.cpp:114-119, transport_utils.hpp:151-153
+              const double xcx = g.x0[0] + ((double)ip + 0.5) * g.dx[0];
+              const double xcy = g.x0[1] + ((double)jp + 0.5) * g.dx[1];
+              const double xcz = g.x0[2] + ((double)kp + 0.5) * g.dx[2];
+              c.xl = xcx - 0.5 * g.dx[0]; c.xu = xcx + 0.5 * g.dx[0];
+              c.yl = xcy - 0.5 * g.dx[1]; c.yu = xcy + 0.5 * g.dx[1];
+              c.zl = xcz - 0.5 * g.dx[2]; c.zu = xcz + 0.5 * g.dx[2];
+              c.fdx = kEpsImc * (c.xu - c.xl); c.fdy = kEpsImc * (c.yu - c.yl);
+              c.fdz = kEpsImc * (c.zu - c.zl);
+            }
+            imc_step_fast<NDIM, NOABS, false>(c, vv, P.rc, t_end, dxp, lam_a_cur, lam_cur, rng, t, x, y,
+                                              z, vx, vy, vz, ip, jp, kp, is_absorbed, is_scattered);
+          }
+          if (!on_block_l(ip, jp, kp)) {
+            crossing = true;
+          } else if (is_absorbed) {  // transport.cpp:157-163
+            if (lds_blocks.owned[b] != 0) {
+              atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], S.w[n]);
+              status = ST_ABSORBED;
+            } else {
+              status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
+            }
+            ls = HS_DONE;
+          } else {
+            fetch_lam();  // (for the next pass, ahead of the scatter)
+            if constexpr (kLean) {
+              if (is_scattered) scatter_dir(rng, vx, vy, vz);
+              if (!(t > 0.0)) ls = HS_DONE;
+            } else {
+              if (is_scattered) scatter(rng, vv, vx, vy, vz);  // transport.cpp:165-170
+              if (!(t < t_end)) ls = HS_DONE;                  // census
+            }
+          }
+        }
+        // one face crossed into a resident block of the same size, a periodic wrap, a reflection:
+        // from the face table, at once; everything else: the service phase (HS_RELOC stays)
+        if (__ballot(crossing) != 0ull) {
+          if (crossing) {
+            const bool xo = ip < l_is || ip > l_ie;
+            const bool yo = multi_d && (jp < l_js || jp > l_je);
+            const bool zo = three_d && (kp < l_ks || kp > l_ke);
+            bool done = false;
+            if (xo && !yo && !zo) done = cross_face(std::integral_constant<int, 0>{}, ip > l_ie, x, vx, ip, l_is, l_ie);
+            else if (yo && !xo && !zo) done = cross_face(std::integral_constant<int, 1>{}, jp > l_je, y, vy, jp, l_js, l_je);
+            else if (zo && !xo && !yo) done = cross_face(std::integral_constant<int, 2>{}, kp > l_ke, z, vz, kp, l_ks, l_ke);
+            if (!done) ls = HS_RELOC;
+          }
+        }
+        nrun = __popcll(__ballot(ls == HS_IMC));
+        waste += n_imc - nrun;
+        park_waste += n_virt;
+        if (waste >= JB_HYBRID_IMC_BUDGET || (n_virt > 0 && park_waste >= JB_HYBRID_PARK_BUDGET)) thresh = 65;
+      }
+    }
+  }
+
+  if constexpr (TALLY) {
+    if (tally_in_lds) {
+      __syncthreads();
+      for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) {
+        const double v = lds_tally[q];
+        if (v != 0.0) atomicAdd(&M.tally[q / (int)M.ntot][q % (int)M.ntot], v);
+      }
+    }
+  }
+  unsigned long long r_census = wave_sum(c_census), r_abs = wave_sum(c_abs), r_esc = wave_sum(c_esc),
+                     r_out = wave_sum(c_out);
+  const unsigned long long r_ev = c_ev + wave_sum(c_ev_real);
+  if (lane == 0) {
+    if (r_census) atomicAdd(&counters[CNT_CENSUS], r_census);
+    if (r_abs) atomicAdd(&counters[CNT_ABSORBED], r_abs);
+    if (r_esc) atomicAdd(&counters[CNT_ESCAPED], r_esc);
+    if (r_out) atomicAdd(&counters[CNT_OUTGOING], r_out);
+    if (r_ev) atomicAdd(&counters[CNT_EVENTS], r_ev);
+    atomicAdd(&counters[CNT_PASSES], (unsigned long long)c_pass);
+    atomicAdd(&counters[CNT_SERVICE], (unsigned long long)c_service);
+  }
+}
+
+}  // namespace jb

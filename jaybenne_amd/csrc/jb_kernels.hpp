@@ -151,8 +151,11 @@ __global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P) {
     const double dz = (xc(B, 2, k) + 0.5 * B.dx[2]) - (xc(B, 2, k) - 0.5 * B.dx[2]);
     double *o = M.ddmc_cell[b] + 8 * q;
     o[0] = ff * aa;
-    o[1] = aa + ss;
-    const bool ddmc_cell = B.dx_push * o[1] > P.tau_ddmc;  // transport_ddmc.cpp:135
+    const double sig = aa + ss;
+    const bool ddmc_cell = B.dx_push * sig > P.tau_ddmc;  // transport_ddmc.cpp:135
+    // (the sign of the record's sigma tells k_hybrid's DDMC loop that a photon has leaked into a
+    // cell that takes IMC steps; only DDMC cells' records are read for their values)
+    o[1] = ddmc_cell ? sig : -sig;
     if (!ddmc_cell) atomicOr(M.not_all_ddmc, 1);
     const double ls = M.lam_sc[b][q];  // (k_fleck, this cycle)
     M.lam_hyb[(long long)b * M.ntot + q] = ddmc_cell ? -ls : ls;

@@ -291,8 +291,8 @@ def test_history_loop_bit_exact(gpu_device, deck, overrides, cycles):
 
 @pytest.mark.parametrize("deck,overrides,cycles", [c for c in CASES if c[0].endswith("_ddmc")])
 def test_general_kernel_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, monkeypatch):
-    """All-DDMC meshes are tracked by k_ddmc_all (test_history_loop_bit_exact runs it); the general
-    k_transport<.., DDMC> kernel, which a hybrid deck runs, must give the same bits on them."""
+    """All-DDMC meshes are tracked by k_ddmc_all (test_history_loop_bit_exact runs it); k_hybrid,
+    the kernel of a mesh that mixes IMC and DDMC cells, must give the same bits on them."""
     from oracle import orc
     monkeypatch.setenv("JB_NO_DDMC_ALL", "1")
     pin = load_deck(deck, overrides)
@@ -301,14 +301,14 @@ def test_general_kernel_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, 
     for _ in range(cycles):
         drv.Step()
     run_oracle_cycles(O, pin, cycles)
-    assert "k_transport<" in drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
+    assert "k_hybrid<" in drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
     _compare_swarm(drv.md, O)
     _compare_fields(drv.md, O)
     assert drv.md.events == O.events
 
 
 def test_all_ddmc_mesh_runs_the_lean_kernel(gpu_device):
-    for deck, want in (("stepdiff_ddmc", "k_ddmc_all<1"), ("stepdiff_smr_hybrid", "k_transport<2"),
+    for deck, want in (("stepdiff_ddmc", "k_ddmc_all<1"), ("stepdiff_smr_hybrid", "k_hybrid<2"),
                        ("stepdiff_smr_ddmc", "k_ddmc_all<2"), ("stepdiff", "k_transport<1")):
         drv = _gpu_problem(load_deck(deck, {"jaybenne/num_particles": 3000}), gpu_device)
         drv.Step()
