@@ -145,6 +145,10 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   ctx->dp.apm = scattering->apm;
   ctx->dp.opac_model = opacity->model;
   ctx->dp.lean = ctx->lean_arith ? 1 : 0;
+  ctx->dp.hyb_imc_budget = JB_HYBRID_IMC_BUDGET;    // (tuning aids: environment overrides)
+  ctx->dp.hyb_park_budget = JB_HYBRID_PARK_BUDGET;
+  if (const char *e = getenv("JB_HYBRID_IMC_BUDGET")) ctx->dp.hyb_imc_budget = atoi(e) > 0 ? atoi(e) : JB_HYBRID_IMC_BUDGET;
+  if (const char *e = getenv("JB_HYBRID_PARK_BUDGET")) ctx->dp.hyb_park_budget = atoi(e) > 0 ? atoi(e) : JB_HYBRID_PARK_BUDGET;
   ctx->dp.ep_A = ctx->dp.ep_B = ctx->dp.ep_E = 0.0;
   {
     // CGS constants (CODATA 2018): electron charge (esu), electron / proton mass, Planck,
@@ -678,29 +682,66 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
         }
         return;
       }
+      // A mix of IMC and DDMC cells, three launches: k_hybrid<.., PHASE 1> follows the photons in
+      // IMC cells (its service phase also takes the albedo step of a photon that enters a DDMC
+      // cell) and parks those that settle in DDMC cells; <.., PHASE 2> follows these and parks the
+      // ones that leak back into IMC cells; <.., PHASE 0>, which runs both event loops, finishes
+      // that remainder -- the photons that keep changing regime at the interface (alternating
+      // phases 1 and 2 until nothing is left costs one launch per change of regime of the most
+      // persistent photon: measured ~80 rounds of ~0.5 ms on BASELINE configs[4]).  The lists of
+      // parked photons (slot numbers, 4 bytes each) live in the context's scratch buffer.
       // (variant string: NDIM, TALLY, NOABS, MODE: 0 exact arithmetic, 1 lean, 2 lean on exact geometry)
-#define JB_LAUNCH_H(T, NA, MD)                                                                     \
+      const long long nrange = last - first;
+      if (ensure_scratch(ctx, (size_t)nrange + 16) != JB_COMPLETE) return;  // 2 lists x 4 bytes x n
+      unsigned *list_d = (unsigned *)ctx->scratch_d;          // parked by phase 1, read by phase 2
+      unsigned *list_i = list_d + nrange;                     // parked by phase 2, read by phase 1
+      unsigned long long *cnt = ctx->counters_d + kCursorBase;  // [0] |list_d|, [1] |list_i|
+      volatile unsigned long long *cnt_h = ctx->counters_h + kCursorBase;
+#define JB_LAUNCH_H(T, NA, MD, PH, F, L, LIN, LOUT, COUT)                                          \
   do {                                                                                             \
     int occ = 0;                                                                                   \
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_hybrid<NDIM, T, NA, MD>, kBlock, 0)   \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_hybrid<NDIM, T, NA, MD, PH>, kBlock, 0) \
             != hipSuccess || occ < 1)                                                              \
       occ = 3;                                                                                     \
-    const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
-    hipLaunchKernelGGL((k_hybrid<NDIM, T, NA, MD>), dim3(g), dim3(kBlock), 0, ctx->stream, M,      \
-                       ctx->dp, S, t_start, dt, first, last, ctx->counters_d);                     \
-    mesh->last_variant = NDIM == 1 ? "k_hybrid<1, " #T ", " #NA ", " #MD ">"                       \
-                         : NDIM == 2 ? "k_hybrid<2, " #T ", " #NA ", " #MD ">"                     \
-                                     : "k_hybrid<3, " #T ", " #NA ", " #MD ">";                    \
+    const int g = grid_for(ctx, (L) - (F), per_cu_env > 0 ? per_cu_env : occ);                     \
+    (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream); \
+    hipLaunchKernelGGL((k_hybrid<NDIM, T, NA, MD, PH>), dim3(g), dim3(kBlock), 0, ctx->stream, M,  \
+                       ctx->dp, S, t_start, dt, (long long)(F), (long long)(L), ctx->counters_d,   \
+                       (const unsigned *)(LIN), (unsigned *)(LOUT), (unsigned long long *)(COUT)); \
   } while (0)
-#define JB_LAUNCH_HM(T, NA)                                                                        \
+#define JB_PHASE1(T, NA, F, L, LIN)                                                                \
   do {                                                                                             \
-    if (!ctx->lean_arith) JB_LAUNCH_H(T, NA, 0);                                                   \
-    else if (M.exact) JB_LAUNCH_H(T, NA, 2);                                                       \
-    else JB_LAUNCH_H(T, NA, 1);                                                                    \
+    if (!ctx->lean_arith) JB_LAUNCH_H(T, NA, 0, 1, F, L, LIN, list_d, cnt);                        \
+    else if (mesh->exact_geom) JB_LAUNCH_H(T, NA, 2, 1, F, L, LIN, list_d, cnt);                            \
+    else JB_LAUNCH_H(T, NA, 1, 1, F, L, LIN, list_d, cnt);                                         \
   } while (0)
-      if (tally) { if (noabs_h) JB_LAUNCH_HM(true, true); else JB_LAUNCH_HM(true, false); }
-      else { if (noabs_h) JB_LAUNCH_HM(false, true); else JB_LAUNCH_HM(false, false); }
-#undef JB_LAUNCH_HM
+      mesh->last_variant =
+          NDIM == 1 ? (ctx->lean_arith ? (mesh->exact_geom ? "k_hybrid<1, lean, exact geometry>" : "k_hybrid<1, lean>") : "k_hybrid<1, exact>")
+          : NDIM == 2 ? (ctx->lean_arith ? (mesh->exact_geom ? "k_hybrid<2, lean, exact geometry>" : "k_hybrid<2, lean>") : "k_hybrid<2, exact>")
+                      : (ctx->lean_arith ? (mesh->exact_geom ? "k_hybrid<3, lean, exact geometry>" : "k_hybrid<3, lean>") : "k_hybrid<3, exact>");
+#define JB_PHASE0(T, NA, L, LIN)                                                                   \
+  do {                                                                                             \
+    if (!ctx->lean_arith) JB_LAUNCH_H(T, NA, 0, 0, 0, L, LIN, nullptr, nullptr);                   \
+    else if (mesh->exact_geom) JB_LAUNCH_H(T, NA, 2, 0, 0, L, LIN, nullptr, nullptr);                       \
+    else JB_LAUNCH_H(T, NA, 1, 0, 0, L, LIN, nullptr, nullptr);                                    \
+  } while (0)
+      (void)hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), ctx->stream);
+      if (tally) { if (noabs_h) JB_PHASE1(true, true, first, last, nullptr); else JB_PHASE1(true, false, first, last, nullptr); }
+      else { if (noabs_h) JB_PHASE1(false, true, first, last, nullptr); else JB_PHASE1(false, false, first, last, nullptr); }
+      (void)hipMemcpyAsync((void *)cnt_h, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess) return;
+      const long long n_d = (long long)cnt_h[0];
+      if (n_d == 0) return;
+      if (tally) JB_LAUNCH_H(true, true, 0, 2, 0, n_d, list_d, list_i, cnt + 1);
+      else JB_LAUNCH_H(false, true, 0, 2, 0, n_d, list_d, list_i, cnt + 1);
+      (void)hipMemcpyAsync((void *)(cnt_h + 1), cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess) return;
+      const long long n_i = (long long)cnt_h[1];
+      if (n_i == 0) return;
+      if (tally) { if (noabs_h) JB_PHASE0(true, true, n_i, list_i); else JB_PHASE0(true, false, n_i, list_i); }
+      else { if (noabs_h) JB_PHASE0(false, true, n_i, list_i); else JB_PHASE0(false, false, n_i, list_i); }
+#undef JB_PHASE0
+#undef JB_PHASE1
 #undef JB_LAUNCH_H
       return;
     }

@@ -69,6 +69,8 @@ struct DevParams {
   // EPBremss (opac_model 1): sigma_a = A rho^2 T^-1/2 (1 - e^(-B nu / T)) nu^-3, j = E rho^2 T^1/2
   int opac_model;
   int lean;           // 1: lean arithmetic in the IMC steps of the hybrid kernel (jb_set_arithmetic)
+  int hyb_imc_budget;   // k_hybrid: idle lane-passes that buy a service phase (JB_HYBRID_IMC_BUDGET)
+  int hyb_park_budget;  // ... lane-passes parked DDMC lanes wait for their loop (JB_HYBRID_PARK_BUDGET)
   double ep_A, ep_B, ep_E;
 };
 

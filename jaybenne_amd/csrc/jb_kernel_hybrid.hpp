@@ -56,12 +56,20 @@ namespace jb {
 #endif
 
 enum { HS_IDLE = 0, HS_IMC = 1, HS_VIRT = 2, HS_REAL = 3, HS_DONE = 4, HS_RELOC = 5, HS_EMERGE = 6,
-       HS_NEW = 7 };
+       HS_NEW = 7, HS_PARK = 8 };
 
-template <int NDIM, bool TALLY, bool NOABS, int MODE>
+// PHASE 0: both event loops in one launch (lanes of the other regime wait in their registers).
+// PHASE 1 / 2: the IMC loop only / the DDMC loop only -- a photon that turns out to belong to the
+// other regime is PARKED: written back as it stands (position and direction materialised: the
+// state the reference's swarm holds between two transport iterations) and its slot appended to
+// park_list, which the other phase's launch then works through (list_in), until both lists stay
+// empty (launch_hybrid in jb_api.hip).  Each phase is a kernel of its own to the register
+// allocator, and every loop runs with full waves.
+template <int NDIM, bool TALLY, bool NOABS, int MODE, int PHASE>
 __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
     k_hybrid(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
-             long long last, unsigned long long *counters) {
+             long long last, unsigned long long *counters, const unsigned *list_in,
+             unsigned *park_list, unsigned long long *park_count) {
   __shared__ double lds_tally[TALLY ? kLdsTally : 1];
   const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
   if constexpr (TALLY) {
@@ -83,9 +91,10 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
   bool more = true;
   long long chunk_pos = 0, chunk_end = 0;
 
+  // wave-level counters (scalar registers): finished histories by outcome; events = stepping lanes
+  // summed over the passes of both loops + steps taken in the service phase
   unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0;
-  unsigned long long c_ev = 0;   // wave-level: stepping lanes summed over the passes of both loops
-  unsigned int c_ev_real = 0;    // per lane: steps taken in the service phase
+  unsigned long long c_ev = 0;
   unsigned int c_pass = 0, c_service = 0;
 
   // ---- lane state
@@ -140,10 +149,19 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
     s.ffaa = r0.x; s.sig = r0.y;
     s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
   };
+  // (MODE 2: the per-cell arrays of all resident blocks span < 4 GiB -- jb_mesh_create -- and a
+  // lane keeps the byte offset of its block's part, as the EXACT gray IMC kernels do)
+  unsigned hyb_off = 0u;
   auto fetch_lam = [&]() {  // the IMC loop's gather for the lane's cell
-    const unsigned long long w = cell_word(b, cidx_l(kp, jp, ip));
-    lam_cur = ((gcptr)hyb_base)[w];
-    if constexpr (!NOABS) lam_a_cur = ((gcptr)M.lam_base)[2ull * (unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip)];
+    if constexpr (kExactG) {
+      const unsigned off = ((unsigned)cidx_l(kp, jp, ip) << 3) + hyb_off;
+      lam_cur = *(gcptr)((const char *)hyb_base + off);
+      if constexpr (!NOABS) lam_a_cur = *(gcptr)((const char *)M.lam_base + (off + hyb_off));
+    } else {
+      const unsigned long long w = cell_word(b, cidx_l(kp, jp, ip));
+      lam_cur = ((gcptr)hyb_base)[w];
+      if constexpr (!NOABS) lam_a_cur = ((gcptr)M.lam_base)[2ull * (unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip)];
+    }
   };
   // a photon with a real position in a DDMC cell enters the DDMC loop unless the albedo step
   // would find it at a face of its cell (k_ddmc_all)
@@ -167,6 +185,7 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
       g.fd[d] = kEpsImc * g.dx[d];
     }
     dxp = dmin(g.dx[0], dmin(g.dx[1], g.dx[2]));
+    hyb_off = (unsigned)b * (ntot_u * 8u);
   };
   auto enter_imc = [&]() {
     if constexpr (kLean) {
@@ -197,6 +216,7 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
     }
     b = ent & 0x0fffffff;
     g.x0[AXIS] = lds_blocks.x0[b][AXIS];
+    hyb_off = (unsigned)b * (ntot_u * 8u);
     idx = at_first ? first_i : last_i;
     if (!((kLean ? t > 0.0 : t < t_end))) ls = HS_DONE;
     else fetch_lam();
@@ -296,6 +316,7 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
       ls = HS_NEW;
     }
     // -- 3a. finished particles: census resampling, write-back, tally
+    const bool was_done = ls == HS_DONE;
     if (ls == HS_DONE) {
       if (status != ST_OUTGOING && status != ST_ESCAPED) {
         Blk Bd;
@@ -337,12 +358,16 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
       S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
       S.status[n] = status;
       S.rng[n] = rng.s;
-      if (status == ST_ACTIVE) ++c_census;
-      else if (status == ST_ABSORBED) ++c_abs;
-      else if (status == ST_ESCAPED) ++c_esc;
-      else ++c_out;
       resample = false;
       ls = HS_IDLE;
+    }
+    {  // (wave-level counters are updated outside divergent branches)
+      const int n_done = __popcll(__ballot(was_done));
+      const int n_census = __popcll(__ballot(was_done && status == ST_ACTIVE));
+      const int n_abs = __popcll(__ballot(was_done && status == ST_ABSORBED));
+      const int n_esc = __popcll(__ballot(was_done && status == ST_ESCAPED));
+      c_census += n_census; c_abs += n_abs; c_esc += n_esc;
+      c_out += n_done - n_census - n_abs - n_esc;
     }
     // -- 3b. every idle lane claims the next slot of the wave's chunk (chunks of consecutive slots,
     //        one atomic per chunk)
@@ -375,6 +400,7 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
         const bool mine = ((need >> lane) & 1ull) != 0ull && rank < give;
         if (mine) {
           cand = chunk_pos + rank;
+          if (list_in != nullptr) cand = (long long)list_in[cand];  // (uniform)
           st_in = S.status[cand];
           rng_in = S.rng[cand];
           b_in = S.blk[cand];
@@ -405,8 +431,8 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
     // -- 4. one step with the real position in a DDMC cell (arrival from an IMC cell or another
     //       block, a particle loaded next to a face, the steps after an albedo rejection): the
     //       general step functions (transport_ddmc.cpp:137-179)
+    c_ev += (unsigned)__popcll(__ballot(ls == HS_REAL));
     if (ls == HS_REAL) {
-      ++c_ev_real;
       Blk Br;
       load_block_lds(M, lds_blocks, b, Br);
       Step s;
@@ -441,8 +467,12 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
       } else if (!(t < t_end)) {  // census
         ls = HS_DONE;
       } else if (!s.is_rejected) {
-        real_pos = false;  // leaked into a neighbouring cell of this block: virtual from here on
-        ls = HS_VIRT;      // (the DDMC loop finds out whether that cell takes DDMC steps)
+        if constexpr (PHASE == 1) {
+          ls = HS_NEW;       // leaked into a neighbouring cell of this block (x, y, z: where to)
+        } else {
+          real_pos = false;  // ... : virtual from here on
+          ls = HS_VIRT;      // (the DDMC loop finds out whether that cell takes DDMC steps)
+        }
       } else {
         ls = HS_NEW;       // rejected: a real position in the cell on the other side of the face
       }
@@ -454,12 +484,55 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
       } else {
         const double lam = ((gcptr)hyb_base)[cell_word(b, cidx_l(kp, jp, ip))];
         if (__double2hiint(lam) < 0) {
-          Blk Bn;
-          load_block_lds(M, lds_blocks, b, Bn);
-          enter_ddmc(Bn);
+          if constexpr (PHASE == 1) {
+            ls = HS_PARK;
+          } else {
+            Blk Bn;
+            load_block_lds(M, lds_blocks, b, Bn);
+            enter_ddmc(Bn);
+          }
         } else {
-          enter_imc();
+          if constexpr (PHASE == 2) {
+            ls = HS_PARK;
+          } else {
+            if (pend >= 0) {  // (a DDMC step of the service phase leaked straight into this cell)
+              Step s;
+              s.vv = vv; s.pend = pend; s.pz1 = vx; s.pz2 = vy;
+              s.vx = vx; s.vy = vy; s.vz = vz;
+              materialise_dir(s);
+              vx = s.vx; vy = s.vy; vz = s.vz;
+              pend = -1;
+            }
+            enter_imc();
+          }
         }
+      }
+    }
+    // -- 6. a photon of the other phase's regime: written back as it stands, its slot appended
+    //       to the list the other phase works through
+    if constexpr (PHASE != 0) {
+      if (ls == HS_PARK) {
+        if (pend >= 0) {
+          Step s;
+          s.vv = vv; s.pend = pend; s.pz1 = vx; s.pz2 = vy;
+          s.vx = vx; s.vy = vy; s.vz = vz;
+          materialise_dir(s);
+          vx = s.vx; vy = s.vy; vz = s.vz;
+          pend = -1;
+        }
+        S.blk[n] = b;
+        S.t[n] = t;
+        S.x[n] = x; S.y[n] = y; S.z[n] = z;
+        S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+        S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
+        S.rng[n] = rng.s;
+        const unsigned long long pm = __ballot(true);
+        const int leader = __ffsll((long long)pm) - 1;
+        unsigned long long base = 0ull;
+        if (lane == leader) base = atomicAdd(park_count, (unsigned long long)__popcll(pm));
+        base = __shfl(base, leader, 64);
+        park_list[base + (unsigned long long)__popcll(pm & ((1ull << lane) - 1ull))] = (unsigned)n;
+        ls = HS_IDLE;
       }
     }
     // lanes that still need the service phase are served before a loop is entered
@@ -474,7 +547,7 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
 
     // ================================ DDMC EVENTS =============================
     // (run when the parked lanes have waited long enough, or nothing else can run)
-    if (n_virt > 0 && (n_imc == 0 || park_waste >= JB_HYBRID_PARK_BUDGET)) {
+    if (PHASE != 1 && n_virt > 0 && (n_imc == 0 || park_waste >= P.hyb_park_budget)) {
       park_waste = 0;
       int waste = 0, passes = 0;
       int nrun = n_virt;
@@ -525,7 +598,7 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
     }
 
     // ================================ IMC EVENTS ==============================
-    {
+    if constexpr (PHASE != 2) {
       if (ls == HS_IMC) {
         bind_geometry();
         fetch_lam();
@@ -603,7 +676,7 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
         nrun = __popcll(__ballot(ls == HS_IMC));
         waste += n_imc - nrun;
         park_waste += n_virt;
-        if (waste >= JB_HYBRID_IMC_BUDGET || (n_virt > 0 && park_waste >= JB_HYBRID_PARK_BUDGET)) thresh = 65;
+        if (waste >= P.hyb_imc_budget || (n_virt > 0 && park_waste >= P.hyb_park_budget)) thresh = 65;
       }
     }
   }
@@ -617,9 +690,7 @@ __global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
       }
     }
   }
-  unsigned long long r_census = wave_sum(c_census), r_abs = wave_sum(c_abs), r_esc = wave_sum(c_esc),
-                     r_out = wave_sum(c_out);
-  const unsigned long long r_ev = c_ev + wave_sum(c_ev_real);
+  const unsigned long long r_census = c_census, r_abs = c_abs, r_esc = c_esc, r_out = c_out, r_ev = c_ev;
   if (lane == 0) {
     if (r_census) atomicAdd(&counters[CNT_CENSUS], r_census);
     if (r_abs) atomicAdd(&counters[CNT_ABSORBED], r_abs);
