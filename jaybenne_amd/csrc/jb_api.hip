@@ -70,6 +70,7 @@ struct jb_mesh {
   bool exact_geom = false;
   const char *last_variant = "";  // the k_transport instantiation launched last
   const char *last_pair = "";     // ... and the k_ddmc_all launched beside it (gray DDMC), or ""
+  const DevMesh *dm_dev = nullptr;  // copy of dm in device memory (k_hybrid reads the view through it)
 };
 
 __global__ void k_rcp_refined(double b, double *out) { *out = m_rcp_refined(b); }
@@ -478,6 +479,11 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
       D.lam_hyb = hyb;
     }
   }
+  {
+    const DevMesh *copy = nullptr;
+    if ((st = upload(m, &D, 1, &copy)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
+    m->dm_dev = copy;
+  }
   *out = m;
   return JB_COMPLETE;
 }
@@ -705,8 +711,8 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
       occ = 3;                                                                                     \
     const int g = grid_for(ctx, (L) - (F), per_cu_env > 0 ? per_cu_env : occ);                     \
     (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream); \
-    hipLaunchKernelGGL((k_hybrid<NDIM, T, NA, MD, PH>), dim3(g), dim3(kBlock), 0, ctx->stream, M,  \
-                       ctx->dp, S, t_start, dt, (long long)(F), (long long)(L), ctx->counters_d,   \
+    hipLaunchKernelGGL((k_hybrid<NDIM, T, NA, MD, PH>), dim3(g), dim3(kBlock), 0, ctx->stream,     \
+                       mesh->dm_dev, ctx->dp, S, t_start, dt, (long long)(F), (long long)(L), ctx->counters_d,   \
                        (const unsigned *)(LIN), (unsigned *)(LOUT), (unsigned long long *)(COUT)); \
   } while (0)
 #define JB_PHASE1(T, NA, F, L, LIN)                                                                \

@@ -66,10 +66,19 @@ enum { HS_IDLE = 0, HS_IMC = 1, HS_VIRT = 2, HS_REAL = 3, HS_DONE = 4, HS_RELOC 
 // empty (launch_hybrid in jb_api.hip).  Each phase is a kernel of its own to the register
 // allocator, and every loop runs with full waves.
 template <int NDIM, bool TALLY, bool NOABS, int MODE, int PHASE>
-__global__ void __launch_bounds__(kBlock, JB_HYBRID_WAVES_PER_SIMD)
-    k_hybrid(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
-             long long last, unsigned long long *counters, const unsigned *list_in,
+// (PHASE 0 keeps the state of both loops: two waves per SIMD, 256 registers; it only ever sees the
+// remainder.  PHASES 1 and 2 are held to three waves per SIMD, 168 registers, without spills.)
+// The exact-arithmetic IMC phase in 3-D or with an absorption opacity, and the lean one in 3-D with
+// an absorption opacity, do not fit 168 registers either (parity-test and absorbing-material
+// configurations; the stepdiff decks run none of them).
+__global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 0 && (NDIM == 3 || !NOABS)) ||
+                                           (PHASE == 1 && NDIM == 3 && !NOABS)) ? 2 : JB_HYBRID_WAVES_PER_SIMD)
+    k_hybrid(const DevMesh *__restrict__ Mp, DevParams P, DevSwarm S, double t_start, double dt,
+             long long first, long long last, unsigned long long *counters, const unsigned *list_in,
              unsigned *park_list, unsigned long long *park_count) {
+  // (the mesh view is read through a pointer to its copy in device memory: as a by-value argument
+  // its ~120 dwords compete for the scalar registers with everything else that is uniform here)
+  const DevMesh &M = *Mp;
   __shared__ double lds_tally[TALLY ? kLdsTally : 1];
   const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
   if constexpr (TALLY) {

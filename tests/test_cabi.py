@@ -139,6 +139,10 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         "IMC, 1-D, exact geometry, lean arithmetic (configs[0])": "k_transportILi1ELb0ELb1ELi2ELb1ELb1E",
         "all-DDMC, 3-D (configs[2])": "k_ddmc_allILi3ELb1E",
         "all-DDMC, 1-D": "k_ddmc_allILi1ELb1E",
+        "hybrid, 2-D, IMC phase, lean on exact geometry (configs[4])": "k_hybridILi2ELb1ELb1ELi2ELi1E",
+        "hybrid, 2-D, DDMC phase (configs[4])": "k_hybridILi2ELb1ELb1ELi0ELi2E",
+        "hybrid, 3-D, IMC phase, lean on exact geometry": "k_hybridILi3ELb1ELb1ELi2ELi1E",
+        "hybrid, 3-D, DDMC phase": "k_hybridILi3ELb1ELb1ELi0ELi2E",
     }
     for what, key in hot.items():
         names = [n for n in found if key in n]
@@ -146,3 +150,9 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         vgpr, scratch = found[names[0]]
         assert vgpr <= 168, f"{what}: {vgpr} vector registers (> 168: two waves per SIMD)"
         assert scratch == 0, f"{what}: {scratch} bytes of scratch per lane (register spills)"
+    # no launch of the hybrid IMC/DDMC path touches scratch memory (the remainder kernel, PHASE 0,
+    # and the exact / absorbing 3-D variants of the IMC phase take two waves per SIMD instead)
+    hybrid = {n: v for n, v in found.items() if "k_hybrid" in n}
+    assert len(hybrid) == 78
+    spilling = {n: v for n, v in hybrid.items() if v[1] != 0}
+    assert not spilling, spilling
