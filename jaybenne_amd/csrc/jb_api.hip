@@ -55,6 +55,8 @@ struct jb_context {
   // arithmetic of the gray IMC tracking step: lean (default) or exact (JB_EXACT_ARITH=1 in the
   // environment at jb_initialize, or jb_set_arithmetic)
   bool lean_arith = true;
+  int blocks_per_cu_env = 0;  // JB_TRANSPORT_BLOCKS_PER_CU at jb_initialize (tuning aid), 0 = occupancy query
+  bool no_ddmc_all = false;   // JB_NO_DDMC_ALL=1 at jb_initialize (tests: k_hybrid on all-DDMC meshes)
 };
 constexpr int kCounterWords = 1024;  // CNT_N.. | 16..17 cursors | 32.. per-rank counts (<= 480 ranks)
 constexpr int kCursorBase = 16;
@@ -134,6 +136,8 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
     const char *ex = getenv("JB_EXACT_ARITH");
     ctx->lean_arith = !(ex && ex[0] == '1');
   }
+  if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) ctx->blocks_per_cu_env = atoi(e);
+  if (const char *e = getenv("JB_NO_DDMC_ALL")) ctx->no_ddmc_all = e[0] == '1';
   ctx->dp.key0 = (uint32_t)params->seed;  // RngPool rng_pool(seed): unadjusted (quirk 1)
   ctx->dp.use_ddmc = params->use_ddmc;
   ctx->dp.do_feedback = params->do_feedback;
@@ -520,7 +524,8 @@ extern "C" jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh
   JB_HIP(hipSetDevice(ctx->device));
   const DevMesh &M = mesh->dm;
   const long long cells = (long long)M.nblocks * M.ncell;
-  hipLaunchKernelGGL(k_fleck, dim3(grid_for(ctx, cells)), dim3(kBlock), 0, ctx->stream, M, ctx->dp, dt);
+  hipLaunchKernelGGL(k_fleck, dim3(grid_for(ctx, 64ll * M.nblocks * M.nx[1] * M.nx[2])), dim3(kBlock), 0,
+                     ctx->stream, M, ctx->dp, dt);
   if (ctx->params.use_ddmc) {
     const int g = grid_for(ctx, cells * 2);
     hipLaunchKernelGGL(k_face_prob<0>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
@@ -528,8 +533,7 @@ extern "C" jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh
     if (M.ndim > 2) hipLaunchKernelGGL(k_face_prob<2>, dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
     if (M.ddmc_cell) {
       // JB_NO_DDMC_ALL=1 keeps the general kernel also on all-DDMC meshes (tests, A/B)
-      const char *off = getenv("JB_NO_DDMC_ALL");
-      JB_HIP(hipMemsetAsync(M.not_all_ddmc, (off && off[0] == '1') ? 1 : 0, sizeof(int), ctx->stream));
+      JB_HIP(hipMemsetAsync(M.not_all_ddmc, ctx->no_ddmc_all ? 1 : 0, sizeof(int), ctx->stream));
       const int gp = grid_for(ctx, cells);
       if (M.ndim == 1) hipLaunchKernelGGL(k_ddmc_pack<1>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
       else if (M.ndim == 2) hipLaunchKernelGGL(k_ddmc_pack<2>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
@@ -623,15 +627,14 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
   // The kernel is persistent (waves draw particles from queues until they are empty), so the grid
   // is exactly what the chip holds at once: more workgroups would only start when the queues
   // are already drained.  JB_TRANSPORT_BLOCKS_PER_CU overrides the occupancy query (tuning aid).
-  int per_cu_env = 0;
-  if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) per_cu_env = atoi(e);
+  const int per_cu_env = ctx->blocks_per_cu_env;
   const bool gray = M.lam_abs != nullptr;
   (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream);
 #define JB_LAUNCH_X(T, G, X, L)                                                                    \
   do {                                                                                             \
-    int occ = 0;                                                                                   \
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_transport<NDIM, DDMC, T, G, X, L>,    \
-                                                     kBlock, 0) != hipSuccess || occ < 1)          \
+    static int occ = 0;  /* (one query per kernel instantiation and process) */                    \
+    if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(                                  \
+                        &occ, k_transport<NDIM, DDMC, T, G, X, L>, kBlock, 0) != hipSuccess || occ < 1)) \
       occ = 3;                                                                                     \
     const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
     const int *pair_flag = nullptr;                                                                \
@@ -674,14 +677,15 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
         mesh->last_variant = NDIM == 1 ? (tally ? "k_ddmc_all<1, true>" : "k_ddmc_all<1, false>")
                              : NDIM == 2 ? (tally ? "k_ddmc_all<2, true>" : "k_ddmc_all<2, false>")
                                          : (tally ? "k_ddmc_all<3, true>" : "k_ddmc_all<3, false>");
-        int occ = 0;
         if (tally) {
-          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, true>, kBlock, 0) != hipSuccess || occ < 1) occ = 3;
+          static int occ = 0;
+          if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, true>, kBlock, 0) != hipSuccess || occ < 1)) occ = 3;
           const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
           hipLaunchKernelGGL((k_ddmc_all<NDIM, true>), dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, S,
                              t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
         } else {
-          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, false>, kBlock, 0) != hipSuccess || occ < 1) occ = 3;
+          static int occ = 0;
+          if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, false>, kBlock, 0) != hipSuccess || occ < 1)) occ = 3;
           const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
           hipLaunchKernelGGL((k_ddmc_all<NDIM, false>), dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, S,
                              t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
@@ -705,9 +709,9 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
       volatile unsigned long long *cnt_h = ctx->counters_h + kCursorBase;
 #define JB_LAUNCH_H(T, NA, MD, PH, F, L, LIN, LOUT, COUT)                                          \
   do {                                                                                             \
-    int occ = 0;                                                                                   \
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_hybrid<NDIM, T, NA, MD, PH>, kBlock, 0) \
-            != hipSuccess || occ < 1)                                                              \
+    static int occ = 0;                                                                            \
+    if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_hybrid<NDIM, T, NA, MD, PH>, \
+                                                                 kBlock, 0) != hipSuccess || occ < 1)) \
       occ = 3;                                                                                     \
     const int g = grid_for(ctx, (L) - (F), per_cu_env > 0 ? per_cu_env : occ);                     \
     (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream); \

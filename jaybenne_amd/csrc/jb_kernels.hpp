@@ -59,24 +59,35 @@ __device__ __forceinline__ void decode_cell(const DevMesh &M, long long c, int &
 }
 
 // -------------------------------------------------------------------------------------------
+// (one wave per row of interior cells along x: the index arithmetic -- three integer divisions --
+// is done per row by scalar code, the lanes stream contiguous cells)
 __global__ void __launch_bounds__(kBlock) k_fleck(DevMesh M, DevParams P, double dt) {
-  const long long total = (long long)M.nblocks * M.ncell;
-  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
-       c += (long long)gridDim.x * blockDim.x) {
-    int b, k, j, i, cell;
-    decode_cell(M, c, b, k, j, i, cell);
-    const long long q = cidx(M, k, j, i);
-    const double rho = M.rho[b][q];
-    const double temp = eos_temperature(P, rho, M.sie[b][q]);
-    const double emis = opac_emissivity(P, rho, temp);
-    const double ff = 1.0 / (1.0 + (4.0 * emis / (rho * P.cv * temp)) * dt);
-    M.fleck[b][q] = ff;
-    if (M.lam_abs) {  // gray opacities: the IMC mean free paths are per-cell constants
-      double la, ls;
-      imc_cell_mfp(ff, opac_absorption(P, rho, temp, 1.0), opac_scattering(P, rho, temp, 1.0), la,
-                   ls);
-      M.lam_abs[b][q] = la;
-      M.lam_sc[b][q] = ls;
+  const long long rows = (long long)M.nblocks * M.nx[1] * M.nx[2];
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long r = wave0; r < rows; r += nwaves) {
+    const long long ru = (long long)uniform_u64((unsigned long long)r);
+    const int b = (int)(ru / (M.nx[1] * M.nx[2]));
+    const int rem = (int)(ru - (long long)b * (M.nx[1] * M.nx[2]));
+    const int k = rem / M.nx[1] + M.ks, j = rem % M.nx[1] + M.js;
+    const double *rho_b = M.rho[b], *sie_b = M.sie[b];
+    double *fleck_b = M.fleck[b];
+    double *la_b = M.lam_abs ? M.lam_abs[b] : nullptr, *ls_b = M.lam_abs ? M.lam_sc[b] : nullptr;
+    for (int i = M.is + lane; i <= M.ie; i += 64) {
+      const long long q = cidx(M, k, j, i);
+      const double rho = rho_b[q];
+      const double temp = eos_temperature(P, rho, sie_b[q]);
+      const double emis = opac_emissivity(P, rho, temp);
+      const double ff = 1.0 / (1.0 + (4.0 * emis / (rho * P.cv * temp)) * dt);
+      fleck_b[q] = ff;
+      if (la_b) {  // gray opacities: the IMC mean free paths are per-cell constants
+        double la, ls;
+        imc_cell_mfp(ff, opac_absorption(P, rho, temp, 1.0), opac_scattering(P, rho, temp, 1.0), la,
+                     ls);
+        la_b[q] = la;
+        ls_b[q] = ls;
+      }
     }
   }
 }

@@ -209,8 +209,14 @@ class MeshData:
         # hand-off accounting (bench.py): records this rank handed to others, wall time spent in
         # the exchange phase, transport iterations, since the caller last zeroed them
         self.handoff_records = 0
-        self.exchange_seconds = 0.0
+        self.exchange_seconds = 0.0        # hand-off proper: from the end of the transport launch on
+        self.transport_wait_seconds = 0.0  # host time spent waiting for the transport launch
+        self.collective_seconds = 0.0      # part of exchange_seconds inside the two collectives
         self.transport_iterations_total = 0
+        self._stats_cache = None           # counters as of the end of the last RadiationStep
+        # measurement aid (bench.py --force-exchange): run the hand-off phase of the iterate-sublist
+        # also when this rank holds the whole mesh (nothing moves; its fixed cost becomes visible)
+        self.force_exchange = False
         self._make_mesh_handle(owner)
 
     def reserve(self, nslots: int) -> None:
@@ -315,6 +321,7 @@ class MeshData:
     def stats(self, reset: bool = False) -> Dict[str, int]:
         st = _lib.TransportStats()
         _lib.check(self.lib.jb_get_transport_stats(self.pkg.ctx, C.byref(st), int(reset)))
+        self._stats_cache = None
         return {k: int(getattr(st, k)) for k, _ in st._fields_}
 
 
@@ -369,6 +376,7 @@ def SourcePhotons(md: MeshData, source_type: SourceType, t_start: float, dt: flo
 def _transport(md: MeshData, t_start: float, dt: float, first: int, last: Optional[int],
                fuse_census_tally: bool, ddmc: bool) -> TaskStatus:
     md._sync_stream()
+    md._stats_cache = None       # (a transport launch outside RadiationStep moves the counters)
     last = md.n if last is None else last
     fn = md.lib.jb_transport_photons_ddmc if ddmc else md.lib.jb_transport_photons
     timed = md.kernel_events is not None and last > first
@@ -482,14 +490,18 @@ def _exchange(md: MeshData, first: int, last: int):
         st = lib.jb_pack_outgoing(ctx, md.handle, C.byref(md.sv), first, last, md.nranks,
                                   md.records.data_ptr(), md.records.shape[0], counts.ctypes.data)
     _lib.check(st)
+    t_c = time.perf_counter()
     matrix = md.comm.gather_count_matrix(counts)
+    md.collective_seconds += time.perf_counter() - t_c
     total = int(matrix.sum())
     if total == 0:
         return 0, 0
     nsend = int(counts.sum())
     md.handoff_records += nsend
+    t_c = time.perf_counter()
     recv = md.comm.exchange_records(md.records[:nsend] if nsend else None, counts, md.device,
                                     recv_counts=matrix[:, md.rank].copy())
+    md.collective_seconds += time.perf_counter() - t_c
     nrecv = 0 if recv is None else int(recv.shape[0])
     if nrecv:
         if md.n + nrecv > md.capacity:
@@ -540,7 +552,9 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
         # the transport and resampling kernels read belongs to the block itself)
         md._sync_stream()
         _lib.check(md.lib.jb_zero_energy_tally(pkg.ctx, md.handle))
-        before = md.stats()
+        # (the counters are cumulative: the previous step's closing read is this step's opening one,
+        # one device synchronisation per step instead of two)
+        before = md._stats_cache if md._stats_cache is not None else md.stats()
     first = 0
     md.transport_iterations = 0
     for it in range(int(pkg.Param("max_transport_iterations"))):
@@ -549,10 +563,17 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
             transport(md, t_start, dt, first, last, fuse_census_tally=True)
         md.transport_iterations += 1
         md.transport_iterations_total += 1
-        if md.nranks == 1:
+        if md.nranks == 1 and not (md.force_exchange and md.comm is not None):
             break
         with _Phase(md, "exchange"):
+            # the hand-off clock starts when the transport launch has finished (its first device
+            # read-back would otherwise be charged with the whole kernel)
+            t_w = time.perf_counter()
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(md.device))
+            done.synchronize()
             t_x = time.perf_counter()
+            md.transport_wait_seconds += t_x - t_w
             nrecv, moved = _exchange(md, first, last)
             md.exchange_seconds += time.perf_counter() - t_x
         if moved == 0:
@@ -565,6 +586,7 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
         return TaskStatus.iterate
     with _Phase(md, "compaction+fluid"):
         after = md.stats()
+        md._stats_cache = after
         if md.nranks == 1 and after["n_outgoing"] != before["n_outgoing"]:
             raise RuntimeError("particles left for another rank in a single-rank step")
         if any(after[k] != before[k] for k in ("n_absorbed", "n_escaped", "n_outgoing")):

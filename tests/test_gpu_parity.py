@@ -247,6 +247,13 @@ def _gpu_problem(pin, gpu_device):
     return mcblock.McblockDriver(pin, device=gpu_device)
 
 
+# BASELINE configs[4]: the shipped hybrid deck plus a nested level-2 region (bench.make_deck "c5";
+# the block list is pinned by hand in tests/golden/smr_topology.json): 3 levels, 32 blocks
+C5_LEVEL2 = {"parthenon/static_refinement2/level": 2,
+             "parthenon/static_refinement2/x1min": -0.125, "parthenon/static_refinement2/x1max": 0.125,
+             "parthenon/static_refinement2/x2min": -0.125, "parthenon/static_refinement2/x2max": 0.125,
+             "parthenon/static_refinement2/x3min": -0.25, "parthenon/static_refinement2/x3max": 0.25}
+
 CASES = [
     # deck, overrides, cycles
     ("stepdiff", {"jaybenne/num_particles": 4000}, 2),                       # 1-D, 2 blocks (as shipped)
@@ -256,6 +263,8 @@ CASES = [
     ("stepdiff_smr", dict(SMR_OVERRIDES, **{"jaybenne/num_particles": 6000}), 1),      # 2-D SMR IMC
     ("stepdiff_smr_ddmc", dict(SMR_OVERRIDES, **{"jaybenne/num_particles": 40000}), 2),  # 2-D SMR DDMC
     ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 30000}, 1),            # true IMC/DDMC hybrid
+    ("stepdiff_smr_hybrid", dict(C5_LEVEL2, **{"jaybenne/num_particles": 30000}), 2),   # ... on the
+    # 3-level mesh of BASELINE configs[4] (level 0 DDMC, levels 1 and 2 IMC)
     ("stepdiff", {"parthenon/mesh/nx2": 8, "parthenon/mesh/nx3": 8, "parthenon/mesh/nx1": 16,
                   "parthenon/meshblock/nx1": 8, "parthenon/meshblock/nx2": 4,
                   "parthenon/meshblock/nx3": 4, "jaybenne/num_particles": 3000}, 1),   # 3-D, 8 blocks

@@ -1,0 +1,89 @@
+"""An independent check of the SMR topology the history loop runs on (the oracle
+and the product both take mesh, leaf map and neighbour levels from jaybenne_amd.mesh, so a wrong
+table would be common-mode).  tests/golden/smr_topology.json holds the leaf-block lists of
+reference inputs/stepdiff_smr.in (20 blocks, 2 levels) and of BASELINE configs[4]'s 3-level
+extension, written by hand from the decks; everything else -- bounds, neighbour levels across the
+faces, the finest-level leaf map -- is derived HERE by brute force over that list, without any code
+of jaybenne_amd.mesh, and Mesh.from_deck is held to it."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import load_deck
+from jaybenne_amd.mesh import Mesh
+
+FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "smr_topology.json")
+CASES = json.load(open(FIXTURE))
+
+
+def _expected(case):
+    blocks = case["blocks"]
+    ext = np.array(case["block_extent_level0"])
+    gmin = np.array(case["domain_min"])
+    nroot = np.array(case["root_blocks"])
+    gmax = gmin + nroot * ext
+    lo = np.array([gmin + np.array(b[1:]) * ext / 2 ** b[0] for b in blocks])
+    hi = np.array([gmin + (np.array(b[1:]) + 1) * ext / 2 ** b[0] for b in blocks])
+    level = np.array([b[0] for b in blocks])
+
+    def owner_of(p):            # the one block whose (half-open) box holds the point
+        inside = np.all((lo <= p) & (p < hi), axis=1)
+        assert inside.sum() == 1, (p, np.nonzero(inside)[0])
+        return int(np.nonzero(inside)[0][0])
+
+    # the blocks tile the domain exactly once
+    area = np.prod(hi - lo, axis=1).sum()
+    assert abs(area - np.prod(gmax - gmin)) < 1e-14
+    # neighbour level across each face: probe just outside the face, next to the block's lower corner
+    # (so that a finer neighbour is seen at its own level); x outflow: own level, y periodic
+    fine = ext / 2 ** level.max()
+    nbr = np.empty((len(blocks), 4), dtype=int)
+    for b in range(len(blocks)):
+        for d in range(2):
+            for side in range(2):
+                p = lo[b] + 0.25 * fine
+                p[d] = lo[b][d] - 0.25 * fine[d] if side == 0 else hi[b][d] + 0.25 * fine[d]
+                if d == 0 and (p[0] < gmin[0] or p[0] > gmax[0]):
+                    nbr[b, 2 * d + side] = level[b]
+                    continue
+                if d == 1:
+                    p[1] = gmin[1] + (p[1] - gmin[1]) % (gmax[1] - gmin[1])
+                nbr[b, 2 * d + side] = level[owner_of(p)]
+    nleaf = nroot * 2 ** level.max()
+    leaf = np.array([[owner_of(gmin + (np.array([i, j]) + 0.5) * fine) for i in range(nleaf[0])]
+                     for j in range(nleaf[1])])
+    return lo, hi, level, nbr, nleaf, leaf
+
+
+@pytest.mark.parametrize("name", ["stepdiff_smr", "three_level"])
+def test_smr_topology_matches_the_hand_written_block_list(name):
+    case = CASES[name]
+    pin = load_deck(case["deck"])
+    if case["extra"]:
+        pin.load_string(case["extra"])
+    mesh = Mesh.from_deck(pin)
+    lo, hi, level, nbr, nleaf, leaf = _expected(case)
+    assert mesh.nblocks == len(case["blocks"])
+    assert np.array_equal(mesh.blk_level, level)
+    assert np.array_equal(mesh.blk_lloc[:, :2], np.array([b[1:] for b in case["blocks"]]))
+    assert np.array_equal(mesh.blk_xmin[:, :2], lo) and np.array_equal(mesh.blk_xmax[:, :2], hi)
+    assert np.array_equal(mesh.blk_nbr_lev[:, :4], nbr)
+    assert np.all(mesh.blk_nbr_lev[:, 4:] == mesh.blk_level[:, None])       # inactive dimension
+    assert list(mesh.nleaf) == [int(nleaf[0]), int(nleaf[1]), 1]
+    assert np.array_equal(mesh.leaf_map[0], leaf)
+    # 2:1 balance across faces
+    assert np.abs(mesh.blk_nbr_lev[:, :4] - mesh.blk_level[:, None]).max() <= 1
+
+
+def test_three_level_deck_is_the_bench_workload():
+    """The hand-written 3-level list is the mesh bench.py --workload c5 runs."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    mesh = Mesh.from_deck(bench.make_deck(1, 1000, workload="c5"))
+    case = CASES["three_level"]
+    assert mesh.nblocks == len(case["blocks"]) == 32
+    assert np.array_equal(mesh.blk_level, np.array([b[0] for b in case["blocks"]]))
+    assert np.array_equal(mesh.blk_lloc[:, :2], np.array([b[1:] for b in case["blocks"]]))

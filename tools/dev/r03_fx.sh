@@ -1,0 +1,14 @@
+set -e
+mkdir -p gpurun_out
+for b in nccl gloo; do
+JB_BENCH_BACKEND=$b timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-variant --force-exchange > gpurun_out/fx_$b.json 2> gpurun_out/fx_err.txt || { tail -5 gpurun_out/fx_err.txt; }
+done
+timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-variant > gpurun_out/fx_none.json 2>> gpurun_out/fx_err.txt
+python - <<'P'
+import json
+for f in ("nccl", "gloo", "none"):
+    try: d = json.load(open(f"gpurun_out/fx_{f}.json"))
+    except Exception as e: print(f, "failed", e); continue
+    print(f, "ms/step", round(d["ms_per_step"], 3), "kernel", round(d["roofline"]["kernel_ms_avg"], 3), "iter/step", d["transport_iterations_per_step"],
+          "exchange ms", round(d["handoff"]["exchange_ms_per_step_max_rank"], 3), "coll ms", round(d["handoff"]["collectives_ms_per_step_max_rank"], 3))
+P
