@@ -265,11 +265,66 @@ static void Reserve(AmdState &st, std::int64_t nslots) {
 TaskStatus UpdateDerivedTransportFields(MeshData<Real> *md, const Real dt) {   // jaybenne.cpp:285-492
   EnsureMeshView(md);
   AmdState &st = State(md->GetParentPointer());
+  FlushInitialSource(md->GetParentPointer());   // (safeguard: normally done by the host after init)
+  st.cycle += 1;   // first task of RadiationStep: once per cycle on every rank (keys SourceEpoch)
   return Status(jb_update_derived_transport_fields(st.ctx, st.mesh, dt));
 }
 
 // sourcing.cpp:25-208.  T = MeshData<Real> (cycle loop) or MeshBlockData<Real> (initialisation,
 // one call per block: `nblocks` of sourcing.cpp:68-69 is then 1).
+//
+// Random-stream ids are global creation indices, so a source call needs every rank's per-block
+// counts: one MPI_Allreduce.  The MeshData form runs once per rank and cycle: every rank makes the
+// same collective calls.  The MeshBlockData form is called once per LOCAL block by the host's
+// problem generator (mcblock.cpp:202), a number that differs between ranks (20 SMR blocks on 8
+// ranks): it must not communicate.  It therefore only RECORDS the block; the source itself runs
+// for all recorded blocks of this rank in one collective step, FlushInitialSource -- called by
+// the host once after Parthenon has built the mesh and, as a
+// safeguard, at the top of the first UpdateDerivedTransportFields.  The per-cell rounding streams
+// are keyed by (cycle, source type) -- SourceEpoch of jaybenne_amd.hpp -- not by a per-call
+// counter, so they do not depend on how many blocks a rank holds either.
+static void SourceBlocks(Mesh *pm, AmdState &st, SourceType type, const Real t_start, const Real dt,
+                         const std::vector<char> &selected, bool per_block) {
+  auto *mesh_md = pm->mesh_data.Get().get();
+  EnsureMeshView(mesh_md);
+  const int nb = mesh_md->NumBlocks();
+  std::vector<int32_t> nper(nb), gid(nb);
+  const int src = type == SourceType::thermal ? JB_SOURCE_THERMAL : JB_SOURCE_EMISSION;
+  JB_REQUIRE(jb_source_photons_count(st.ctx, st.mesh, src, dt, per_block ? 1 : nb,
+                                     jaybenne_amd::SourceEpoch(st.cycle, type == SourceType::thermal
+                                                                             ? jaybenne_amd::SourceType::thermal
+                                                                             : jaybenne_amd::SourceType::emission),
+                                     nper.data(), st.prefix.data()));
+  std::vector<long long> counts(pm->nbtotal, 0), all(pm->nbtotal, 0);
+  for (int b = 0; b < nb; ++b) {
+    gid[b] = mesh_md->GetBlockData(b)->GetBlockPointer()->gid;
+    if (!selected[b]) nper[b] = 0;
+    counts[gid[b]] = nper[b];
+  }
+  MPI_Allreduce(counts.data(), all.data(), pm->nbtotal, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+  // (the index arithmetic is the tested one: include/jaybenne_amd.hpp, PlanSource)
+  const jaybenne_amd::SourcePlan pl = jaybenne_amd::PlanSource(nper, gid, all, st.next_id, st.sw.n);
+  Reserve(st, st.sw.n + pl.total_local);
+  JB_REQUIRE(jb_source_photons_fill(st.ctx, st.mesh, &st.sw, src, t_start, dt, nper.data(),
+                                    st.prefix.data(), pl.slot_base.data(), pl.id_base.data()));
+  st.sw.n += pl.total_local;
+  st.next_id = pl.next_id;
+}
+
+// One collective step for the blocks whose initial source was requested (every rank calls this
+// exactly once, with or without requests of its own).
+TaskStatus FlushInitialSource(Mesh *pm) {
+  AmdState &st = State(pm);
+  if (st.initial_source_done) return TaskStatus::complete;
+  auto *mesh_md = pm->mesh_data.Get().get();
+  std::vector<char> selected(mesh_md->NumBlocks(), 0);
+  for (int lid : st.pending_initial_blocks) selected[lid] = 1;
+  SourceBlocks(pm, st, SourceType::thermal, 0.0, 0.0, selected, /*per_block=*/true);
+  st.pending_initial_blocks.clear();
+  st.initial_source_done = true;
+  return Status(jb_evaluate_radiation_energy(st.ctx, st.mesh, &st.sw));   // jaybenne.cpp:577
+}
+
 template <typename T, SourceType ST>
 TaskStatus SourcePhotons(T *md, const Real t_start, const Real dt) {
   auto pm = md->GetParentPointer();
@@ -278,39 +333,14 @@ TaskStatus SourcePhotons(T *md, const Real t_start, const Real dt) {
   if constexpr (ST == SourceType::emission) {
     if (!jbn->template Param<bool>("do_emission")) return TaskStatus::complete;   // sourcing.cpp:41-43
   }
-  constexpr bool per_block = std::is_same_v<T, MeshBlockData<Real>>;
-  auto *mesh_md = pm->mesh_data.Get().get();
-  EnsureMeshView(mesh_md);
-  const int nb = mesh_md->NumBlocks();
-  std::vector<int32_t> nper(nb);
-  const int src = ST == SourceType::thermal ? JB_SOURCE_THERMAL : JB_SOURCE_EMISSION;
-  JB_REQUIRE(jb_source_photons_count(st.ctx, st.mesh, src, dt, per_block ? 1 : nb, st.epoch++,
-                                     nper.data(), st.prefix.data()));
-  if constexpr (per_block) {   // only the calling block sources in this call
-    const int mine = md->GetBlockPointer()->lid;
-    for (int b = 0; b < nb; ++b)
-      if (b != mine) nper[b] = 0;
+  if constexpr (std::is_same_v<T, MeshBlockData<Real>>) {
+    st.pending_initial_blocks.push_back(md->GetBlockPointer()->lid);   // no communication here
+    return TaskStatus::complete;
+  } else {
+    std::vector<char> all_blocks(md->NumBlocks(), 1);
+    SourceBlocks(pm, st, ST, t_start, dt, all_blocks, /*per_block=*/false);
+    return TaskStatus::complete;
   }
-  // stream ids are global creation indices: every rank learns every block's count
-  std::vector<long long> counts(pm->nbtotal, 0), all(pm->nbtotal, 0);
-  for (int b = 0; b < nb; ++b) counts[mesh_md->GetBlockData(b)->GetBlockPointer()->gid] = nper[b];
-  MPI_Allreduce(counts.data(), all.data(), pm->nbtotal, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
-  std::vector<std::int64_t> slot(nb);
-  std::vector<std::uint64_t> idb(nb);
-  std::vector<long long> excl(pm->nbtotal);
-  std::exclusive_scan(all.begin(), all.end(), excl.begin(), 0ll);
-  std::int64_t tot = 0;
-  for (int b = 0; b < nb; ++b) {
-    slot[b] = st.sw.n + tot;
-    idb[b] = st.next_id + (std::uint64_t)excl[mesh_md->GetBlockData(b)->GetBlockPointer()->gid];
-    tot += nper[b];
-  }
-  Reserve(st, st.sw.n + tot);
-  JB_REQUIRE(jb_source_photons_fill(st.ctx, st.mesh, &st.sw, src, t_start, dt, nper.data(),
-                                    st.prefix.data(), slot.data(), idb.data()));
-  st.sw.n += tot;
-  st.next_id += (std::uint64_t)std::accumulate(all.begin(), all.end(), 0ll);
-  return TaskStatus::complete;
 }
 template TaskStatus SourcePhotons<MeshBlockData<Real>, SourceType::thermal>(MeshBlockData<Real> *, const Real, const Real);
 template TaskStatus SourcePhotons<MeshBlockData<Real>, SourceType::emission>(MeshBlockData<Real> *, const Real, const Real);
@@ -397,8 +427,8 @@ Real EstimateTimestepMesh(MeshData<Real> *md) {   // jaybenne.cpp:271-275
 }
 
 void InitializeRadiation(MeshBlockData<Real> *mbd, const bool is_thermal) {   // jaybenne.cpp:570-578
+  // (records the block; the source and the initial tally run in FlushInitialSource, see above)
   if (is_thermal) SourcePhotons<MeshBlockData<Real>, SourceType::thermal>(mbd, 0.0, 0.0);
-  EvaluateRadiationEnergy<MeshBlockData<Real>>(mbd);
 }
 
 //----------------------------------------------------------------------------------------

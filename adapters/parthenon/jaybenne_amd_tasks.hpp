@@ -12,6 +12,7 @@
 #include <parthenon/package.hpp>
 
 #include "jaybenne_amd.h"
+#include "jaybenne_amd.hpp"   // PlanSource, SourceEpoch: the host-side arithmetic shared with the tested hosts
 #include "jaybenne_config.hpp"      // EOS / Opacity / Scattering aliases, HOST_* variables
 #include "jaybenne_variables.hpp"   // field::jaybenne::*, particle::photons::*, photons_swarm_name
 
@@ -35,7 +36,10 @@ struct AmdState {
   ParArray1D<int> prefix;            // per-cell exclusive source counts (SourcePhotons phase 1)
   ParArray1D<std::int64_t> records;  // hand-off records, JB_RECORD_WORDS words each
   std::uint64_t next_id = 0;         // first unused stream id (kept in step on every rank)
-  std::uint32_t epoch = 0;           // source-call counter
+  std::uint64_t cycle = 0;           // RadiationStep counter (keys the per-cell source streams:
+                                     // jaybenne_amd::SourceEpoch); 0 = initialisation
+  std::vector<int> pending_initial_blocks;   // local ids recorded by InitializeRadiation(mbd)
+  bool initial_source_done = false;
   int mesh_generation = -1;          // Mesh::nbtotal / block list stamp the view was built for
   ~AmdState();
 };
@@ -55,6 +59,11 @@ TaskStatus UpdateDerivedTransportFields(MeshData<Real> *md, const Real dt);
 template <typename T>
 TaskStatus EvaluateRadiationEnergy(T *md);
 TaskStatus UpdateFluid(MeshData<Real> *md);
+// The initial thermal source of every block recorded by InitializeRadiation(mbd, true), in ONE
+// collective step (an MPI_Allreduce): call once on every rank after ParthenonInitPackagesAndMesh
+// (reference main.cpp:42) -- ranks hold different numbers of blocks, so the per-block hook itself
+// must not communicate.
+TaskStatus FlushInitialSource(Mesh *pmesh);
 
 TaskCollection RadiationStep(Mesh *pmesh, const Real t_start, const Real dt);   // jaybenne.hpp:72
 Real EstimateTimestepMesh(MeshData<Real> *md);                                  // jaybenne.hpp:75

@@ -27,7 +27,7 @@
 #include <cstring>
 #include <vector>
 
-#include "jaybenne_amd.h"
+#include "jaybenne_amd.hpp"
 
 #define HIP_OK(call)                                                                         \
   do {                                                                                       \
@@ -172,16 +172,14 @@ int main(int argc, char **argv) {
   std::vector<long long> counts(nblocks_total, 0), all_counts(nblocks_total, 0);
   for (int l = 0; l < nb; ++l) counts[b0 + l] = nper[l];
   MPI_Allreduce(counts.data(), all_counts.data(), nblocks_total, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
-  std::vector<int64_t> slot(nb);
-  std::vector<uint64_t> idb(nb);
-  long long run = 0, mine = 0;
-  for (int g = 0; g < nblocks_total; ++g) {
-    if (g >= b0 && g < b1) { idb[g - b0] = (uint64_t)run; slot[g - b0] = mine; mine += all_counts[g]; }
-    run += all_counts[g];
-  }
-  const long long n_global0 = run;
-  JB_OK(jb_source_photons_fill(ctx, mesh, &sw, JB_SOURCE_THERMAL, 0.0, 0.0, nper.data(), prefix, slot.data(), idb.data()));
-  sw.n = mine;
+  // (the plan shared with the single-rank tasks and the Parthenon adapter: include/jaybenne_amd.hpp)
+  std::vector<int32_t> gids(nb);
+  for (int l = 0; l < nb; ++l) gids[l] = b0 + l;
+  const jaybenne_amd::SourcePlan plan = jaybenne_amd::PlanSource(nper, gids, all_counts, 0ull, 0);
+  const long long n_global0 = (long long)plan.next_id;
+  JB_OK(jb_source_photons_fill(ctx, mesh, &sw, JB_SOURCE_THERMAL, 0.0, 0.0, nper.data(), prefix,
+                               plan.slot_base.data(), plan.id_base.data()));
+  sw.n = plan.total_local;
 
   // total weight (host sum of this rank's photons), reduced over ranks
   auto total_weight = [&]() {

@@ -204,7 +204,11 @@ jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh, const jb_swarm_
  * a particle reaching census in an OWNED block adds weight / cell volume to energy_tally
  * (EvaluateRadiationEnergy fused; the caller zeroes the tally first with jb_zero_energy_tally).
  * A particle that reaches census or is absorbed in a HALO copy is marked OUTGOING /
- * OUTGOING_ABSORBED: its owner tallies it after the hand-off. */
+ * OUTGOING_ABSORBED: its owner tallies it after the hand-off.
+ * The calls return when the kernel is launched (jb_synchronize / jb_get_transport_stats wait
+ * for it), with one exception: jb_transport_photons_ddmc with gray opacities reads one flag back
+ * first (does every cell take DDMC steps?) and, on a mesh that mixes IMC and DDMC cells, runs
+ * three launches with the size of a work list read back before the second and the third. */
 jb_status jb_transport_photons(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
                                double t_start, double dt, int64_t first, int64_t last,
                                int fuse_census_tally);
@@ -215,25 +219,44 @@ jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swa
  *   JB_ARITH_EXACT: every operation is the one the CPU oracle's portable flavour performs --
  *     correctly rounded quotients, the reference's unfused position update -- and the particles
  *     come out bit-identical to it.
- *   JB_ARITH_LEAN (default): distance to a face as numerator times a once-refined reciprocal,
- *     time step as distance times 1/c, position update as one fused multiply-add per axis,
- *     logarithm without its compensated sum: the quotient within 2^-48 (relative, ~20 ulp) of
- *     the exact variant's, the logarithm within 1 ulp, the fused update the more accurate of
- *     the two forms; ~8 % fewer instructions.  Stated tolerance (tests/test_gpu_lean.py): after full cycles
- *     every particle attribute within 1e-9 (relative; positions relative to the domain size) of
- *     the exact variant's and of the oracle's, integer attributes equal.
+ *   JB_ARITH_LEAN (default): while a lane follows a photon it carries the unit direction v / c and
+ *     the distance left to census c (t_end - t) instead of v and t; distance to a face as
+ *     (face - x) times a once-refined reciprocal of the direction component (within 2^-48, ~20 ulp,
+ *     of the correctly rounded quotient), position update as one fused multiply-add per axis,
+ *     logarithm without its compensated sum (<= 3 ulp), square root of 1 - mu^2 with one residual
+ *     correction (<= 2 ulp) -- every operation within 4e-15 (relative) of the exact variant's; and,
+ *     per axis, only the face the photon moves TOWARDS is tested for the nudge of
+ *     transport_utils.hpp:151-159 (the face behind is >= eps_imc dx away unless the photon has
+ *     moved less than the rounding error of its position since it entered the cell: ~1e-13 per
+ *     event).  ~25 % fewer instructions per event than the exact variant.
+ *     Stated tolerance (tests/test_gpu_lean.py, tests/test_gpu_accuracy.py):
+ *       - after ONE or TWO full cycles every floating-point attribute of every photon is within
+ *         1e-9 of the exact variant's and of the oracle's (positions relative to the domain size,
+ *         velocities to c, times to dt), integer attributes and stream states equal;
+ *       - beyond that the two roundings of a history separate like nearby trajectories of any
+ *         chaotic system -- measured: largest position difference over 1e5 photons 5e-13 of the
+ *         domain after one cycle, 7e-11 after two, then about a decade per cycle, 2.5e-4 after ten
+ *         (the oracle's own libm / portable flavours, <= 1 ulp apart in log and sincos, separate
+ *         at the same rate) -- and a photon changes its sequence of events only where a
+ *         difference flips a comparison: 7 of 1e5 photons in ten cycles, ~1e-8 per history-event;
+ *       - at any length: the energy tally within 6 sigma of each cell's Monte Carlo noise of the
+ *         libm-arithmetic CPU path on the same streams (measured 3e-13 sigma on BASELINE
+ *         configs[0], 0.016 sigma per x-plane on configs[1]'s geometry) and the reference's error
+ *         metric against the analytic profile not worse than that path's + 0.01.
  * The IMC steps of a hybrid (IMC / DDMC) deck follow the same switch; DDMC steps and the
  * per-event-opacity kernels have the exact arithmetic only.  JB_EXACT_ARITH=1
  * in the environment makes exact the default of jb_initialize. */
 enum { JB_ARITH_EXACT = 0, JB_ARITH_LEAN = 1 };
 jb_status jb_set_arithmetic(jb_context *ctx, int mode);
 int jb_get_arithmetic(const jb_context *ctx);
-/* the k_transport instantiation the last transport call on this mesh launched, e.g.
- * "k_transport<3, true, 2, true, true>" = <NDIM, TALLY (census tally fused), GRAY (0 per-event
- * opacities, 1 gray, 2 gray without absorption), EXACT (exact cell-face arithmetic), LEAN (lean
- * arithmetic)>; "" before
- * the first launch.  jb_mesh_exact_geometry: 1 if every resident block has power-of-two cell
- * widths and a lower corner that is a whole number of them. */
+/* the kernel the last transport call on this mesh launched: "k_transport<3, true, 2, true, true>" =
+ * <NDIM, TALLY (census tally fused), GRAY (0 per-event opacities, 1 gray, 2 gray without
+ * absorption), EXACT (exact cell-face arithmetic, 32-bit cell offsets), LEAN (lean arithmetic)>;
+ * "k_ddmc_all<3, true>" = <NDIM, TALLY> on a mesh whose every cell takes DDMC steps;
+ * "k_hybrid<2, lean, exact geometry>" on a mesh that mixes IMC and DDMC cells (three launches: IMC
+ * phase, DDMC phase, remainder); "" before the first launch.  jb_mesh_exact_geometry: 1 if every
+ * resident block has power-of-two cell widths and a lower corner that is a whole number of them
+ * (and the per-cell arrays of the resident blocks span less than 4 GiB). */
 const char *jb_last_transport_variant(const jb_mesh *mesh);
 int jb_mesh_exact_geometry(const jb_mesh *mesh);
 /* counters accumulated by the transport tasks since the last reset (synchronises) */

@@ -114,6 +114,49 @@ class MeshData {
   std::function<void(jb_swarm_view &, int64_t)> reserve_;
 };
 
+// ---- host-side arithmetic of SourcePhotons shared by every host (this header's single-rank tasks,
+// examples/handoff_mpi.cpp across MPI ranks, adapters/parthenon/jaybenne_amd_tasks.cpp) ----------
+// Random-stream ids are GLOBAL creation indices -- block-major over the global block ids, then the
+// order within the block -- so that results do not depend on the block -> rank partition.
+//   nper_local[b]   new photons of resident block b of this rank (jb_source_photons_count)
+//   gid[b]          its global block id
+//   all_counts[g]   new photons of every global block g (the sum of the ranks' contributions;
+//                   one rank: its own counts scattered by gid)
+// Result: slot_base[b] (first swarm slot of block b's new photons, appended after the n_now live
+// ones), id_base[b] (stream id of its first new photon), total_local, and the first unused id
+// after this source call (identical on every rank).
+struct SourcePlan {
+  std::vector<int64_t> slot_base;
+  std::vector<uint64_t> id_base;
+  int64_t total_local = 0;
+  uint64_t next_id = 0;
+};
+inline SourcePlan PlanSource(const std::vector<int32_t> &nper_local, const std::vector<int32_t> &gid,
+                             const std::vector<long long> &all_counts, uint64_t next_id,
+                             int64_t n_now) {
+  SourcePlan pl;
+  const size_t nb = nper_local.size();
+  std::vector<uint64_t> excl(all_counts.size());
+  uint64_t run = 0;
+  for (size_t g = 0; g < all_counts.size(); ++g) { excl[g] = run; run += (uint64_t)all_counts[g]; }
+  pl.slot_base.resize(nb);
+  pl.id_base.resize(nb);
+  for (size_t b = 0; b < nb; ++b) {
+    pl.slot_base[b] = n_now + pl.total_local;
+    pl.id_base[b] = next_id + excl[(size_t)gid[b]];
+    pl.total_local += nper_local[b];
+  }
+  pl.next_id = next_id + run;
+  return pl;
+}
+// The key of the per-cell rounding streams (`epoch` of jb_source_photons_count) as a function of
+// the cycle and the source type, so that every rank -- whatever the number of blocks it calls the
+// source for -- uses the same one: 0 for the initial thermal source, then 2 cycle + type.
+// (jb_source_photons_count accepts epochs below 2^20: half a million cycles.)
+inline uint32_t SourceEpoch(uint64_t cycle, SourceType st) {
+  return (uint32_t)(2u * cycle + (st == SourceType::emission ? 1u : 0u));
+}
+
 // ---- tasks (jaybenne.hpp:59-76) ----------------------------------------------------------------
 inline TaskStatus UpdateDerivedTransportFields(MeshData *md, const Real dt) {
   return Check(jb_update_derived_transport_fields(md->ctx(), md->mesh(), dt));
@@ -133,19 +176,16 @@ inline TaskStatus SourcePhotons(MeshData *md, SourceType st, const Real t_start,
   Check(jb_source_photons_count(md->ctx(), md->mesh(), type, dt, per_block ? 1 : nb, md->epoch,
                                 nper.data(), md->prefix_dev()));
   md->epoch += 1;
-  std::vector<int64_t> slot_base(nb);
-  std::vector<uint64_t> id_base(nb);
-  int64_t tot = 0;
-  for (int b = 0; b < nb; ++b) {
-    slot_base[b] = md->swarm.n + tot;
-    id_base[b] = md->next_id + (uint64_t)tot;
-    tot += nper[b];
-  }
-  md->Reserve(md->swarm.n + tot);
+  // (this rank holds the whole mesh: global id = local index, global counts = local counts)
+  std::vector<int32_t> gid(nb);
+  std::vector<long long> all(nb);
+  for (int b = 0; b < nb; ++b) { gid[b] = b; all[b] = nper[b]; }
+  const SourcePlan pl = PlanSource(nper, gid, all, md->next_id, md->swarm.n);
+  md->Reserve(md->swarm.n + pl.total_local);
   Check(jb_source_photons_fill(md->ctx(), md->mesh(), &md->swarm, type, t_start, dt, nper.data(),
-                               md->prefix_dev(), slot_base.data(), id_base.data()));
-  md->swarm.n += tot;
-  md->next_id += (uint64_t)tot;
+                               md->prefix_dev(), pl.slot_base.data(), pl.id_base.data()));
+  md->swarm.n += pl.total_local;
+  md->next_id = pl.next_id;
   return TaskStatus::complete;
 }
 

@@ -64,8 +64,10 @@ class Opacity:
 
     @property
     def sb(self) -> float:   # erg cm^-2 s^-1 K^-4 = g s^-3 K^-4
-        return constants.STEFAN_BOLTZMANN * (self.time_scale ** 3 * self.temperature_scale ** 4 /
-                                             self.mass_scale)
+        # (products written out, in the order examples/mcblock_amd.cpp uses: `**` goes through pow(),
+        # whose last bit may differ from the repeated product for non-unit scales)
+        ts, tk = self.time_scale, self.temperature_scale
+        return constants.STEFAN_BOLTZMANN * (ts * ts * ts * (tk * tk) * (tk * tk) / self.mass_scale)
 
     def GetRuntimePhysicalConstants(self):
         return self

@@ -6,11 +6,17 @@ inputs/stepdiff_smr.in:86-94): ``Time``, ``NumBlocks``, ``NumDims``, ``MeshBlock
 ``BlockBounds`` (from the per-block node coordinates), ``Variables`` / ``Get(name)`` as
 ``[block, k, j, i]`` arrays of interior cells, and for swarms ``GetSwarm("photons")`` with
 ``x``, ``y``, ``z`` and ``Get("id")``.  Parthenon's reader (``phdf.py``) is not part of the
-reference tree; this module writes the layout its documentation describes --
+reference tree, so compatibility with it is UNVERIFIED; this module writes the layout with
+root-level ``/Levels`` and ``/LogicalLocations`` -- the one reference analysis/jhdf.py:91-101 names
+(its list of non-variable root entries: Blocks, Info, Input, Levels, Locations, LogicalLocations,
+Params, SparseInfo, VolumeLocations) -- and labels it ``OutputFormatVersion = 3`` (Parthenon's
+version 4 moved block metadata to ``/Blocks/loc.*``, which this writer does not produce) --
 
     /Info                attributes: Time, dt, NCycle, NumDims, NumMeshBlocks, MeshBlockSize[3],
                          MaxLevel, IncludesGhost, NGhost, Coordinates, OutputFormatVersion,
-                         OutputDatasetNames, RootGridDomain[9]
+                         OutputDatasetNames, NumComponents, ComponentNames, BlocksPerPE,
+                         RootGridDomain[9]
+    /Input  (attribute File: the deck)      /Params  (empty: the package parameters are not dumped)
     /Blocks/xmin         [nb, 3]        /Levels  [nb]        /LogicalLocations  [nb, 3]
     /Locations/x,y,z     [nb, n+1]   node coordinates      /VolumeLocations/x,y,z  [nb, n] centres
     /<variable>          [nb, nk, nj, ni]                   (e.g. field.jaybenne.energy_tally)
@@ -192,7 +198,7 @@ def write_dump(path: str, mesh, time: float, dt: float, ncycle: int,
     sl = mesh.interior()
     nx = [int(v) for v in mesh.nx]
     w.group("Info")
-    w.attr("Info", "OutputFormatVersion", 4)
+    w.attr("Info", "OutputFormatVersion", 3)   # root-level /Levels, /LogicalLocations (see above)
     w.attr("Info", "Time", float(time))
     w.attr("Info", "dt", float(dt))
     w.attr("Info", "NCycle", int(ncycle))
@@ -204,12 +210,15 @@ def write_dump(path: str, mesh, time: float, dt: float, ncycle: int,
     w.attr("Info", "NGhost", int(mesh.ng))
     w.attr("Info", "Coordinates", "UniformCartesian")
     w.attr("Info", "OutputDatasetNames", ",".join(variables))
+    w.attr("Info", "NumComponents", np.ones(max(len(variables), 1), dtype=np.int32))  # all scalars
+    w.attr("Info", "ComponentNames", ",".join(variables))
+    w.attr("Info", "BlocksPerPE", np.array([nb], dtype=np.int32))   # written by one process
     root = np.array([mesh.gmin[0], mesh.gmax[0], 1.0, mesh.gmin[1], mesh.gmax[1], 1.0,
                      mesh.gmin[2], mesh.gmax[2], 1.0])
     w.attr("Info", "RootGridDomain", root)
-    if input_text:
-        w.group("Input")
-        w.attr("Input", "File", input_text)
+    w.group("Input")
+    w.attr("Input", "File", input_text if input_text else "(no input deck recorded)")
+    w.group("Params")
     w.group("Blocks")
     w.dataset("Blocks/xmin", np.asarray(mesh.blk_xmin, dtype=np.float64))
     w.dataset("Levels", np.asarray(mesh.blk_level, dtype=np.int32))

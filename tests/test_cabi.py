@@ -100,6 +100,27 @@ def test_cpp_mirror_header_is_self_contained():
         assert f" {task}(" in text, task
 
 
+def test_shared_source_plan_is_partition_independent(tmp_path):
+    """include/jaybenne_amd.hpp: PlanSource / SourceEpoch, the host-side arithmetic of SourcePhotons
+    that the native hosts AND the (uncompiled) Parthenon adapter call -- compiled with the host
+    compiler and run (tests/plan_source_test.cpp)."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "plan_source_test"
+    res = subprocess.run([cxx, "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                          os.path.join(ROOT, "tests", "plan_source_test.cpp"), "-o", str(exe)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0 and "plan_source ok" in res.stdout, res.stdout + res.stderr
+    # the adapter really goes through it
+    text = open(os.path.join(ROOT, "adapters", "parthenon", "jaybenne_amd_tasks.cpp")).read()
+    assert "jaybenne_amd::PlanSource(" in text and "jaybenne_amd::SourceEpoch(" in text
+
+
 def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
     """The tracking kernels are tuned for three waves per SIMD (512 / 3 -> 168 vector registers,
     allocated in eights); a change that pushes one of them over the edge silently costs a wave

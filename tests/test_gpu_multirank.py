@@ -38,6 +38,26 @@ CASES = [
 ]
 
 
+
+def _run_workers(procs, timeout=300):
+    """Start the rank processes, wait for them and make sure none is left behind: a rank that hangs
+    would keep holding the GPU (the pool allows few processes per card) and fail later tests."""
+    try:
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout)
+        codes = [p.exitcode for p in procs]
+        assert all(c == 0 for c in codes), f"rank exit codes {codes} (None = still running after {timeout} s)"
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
+            if p.is_alive():
+                p.kill()
+                p.join(10)
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -98,11 +118,7 @@ def _ranks_equal_the_oracle(case, world, tmp_path):
     ctx = mp.get_context("spawn")
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, case, str(tmp_path))) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    _run_workers(procs)
     deck, ov, cycles = CASES[case]
     pin = load_deck(deck, ov)
     O, mesh, _ = make_oracle(pin, orc.MATH_PORTABLE)
@@ -141,11 +157,7 @@ def test_lean_arithmetic_does_not_depend_on_the_partition(gpu_device, case, tmp_
     ctx = mp.get_context("spawn")
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, case, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    _run_workers(procs)
     drv = mcblock.McblockDriver(load_deck(deck, ov), device=gpu_device)
     assert drv.pkg.arithmetic() == "lean"
     for _ in range(cycles):
@@ -202,11 +214,7 @@ def test_two_ranks_with_material_feedback(gpu_device, tmp_path):
     ctx = mp.get_context("spawn")
     port = _free_port()
     procs = [ctx.Process(target=_feedback_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    _run_workers(procs)
     pin = load_deck("stepdiff_smr_hybrid", FEEDBACK)
     O, mesh, _ = make_oracle(pin, orc.MATH_PORTABLE, capacity_factor=8.0)
     # the emission count per cell scales with 1 / (blocks in the calling rank's MeshData)

@@ -13,9 +13,15 @@ SMR = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "parthenon/meshblock/nx
        "parthenon/meshblock/nx2=16"]
 
 
+# (every deck in both arithmetic variants: "exact" -- JB_EXACT_ARITH=1, what the other tests run -- and
+# "lean", the library's shipped default; the `lean` marker makes tests/conftest.py leave the
+# default alone.  The all-DDMC decks take no lean step: one variant.)
 @pytest.mark.parametrize("deck,overrides,tol", [
     ("stepdiff", STEPDIFF, 0.05), ("stepdiff_ddmc", STEPDIFF, 0.05),
-    ("stepdiff_smr", SMR, 0.3), ("stepdiff_smr_ddmc", SMR, 0.3), ("stepdiff_smr_hybrid", SMR, 0.3)])
+    ("stepdiff_smr", SMR, 0.3), ("stepdiff_smr_ddmc", SMR, 0.3), ("stepdiff_smr_hybrid", SMR, 0.3),
+    pytest.param("stepdiff", STEPDIFF, 0.05, marks=pytest.mark.lean, id="stepdiff-lean"),
+    pytest.param("stepdiff_smr", SMR, 0.3, marks=pytest.mark.lean, id="stepdiff_smr-lean"),
+    pytest.param("stepdiff_smr_hybrid", SMR, 0.3, marks=pytest.mark.lean, id="stepdiff_smr_hybrid-lean")])
 def test_reference_regression_suite(gpu_device, deck, overrides, tol, capsys):
     from jaybenne_amd.__main__ import main
     rc = main(["-i", os.path.join(DECKS, deck + ".in"), "--tolerance", str(tol)] + overrides)
@@ -75,7 +81,8 @@ def test_three_level_hybrid_extension(gpu_device, tmp_path, capsys):
     assert "levels [0, 1, 2]" in out and rc == 0, out
 
 
-@pytest.mark.parametrize("deck,tol", [("inf", 0.03), ("inf_stiff", 0.04)])
+@pytest.mark.parametrize("deck,tol", [("inf", 0.03), ("inf_stiff", 0.04),
+                                      pytest.param("inf", 0.03, marks=pytest.mark.lean, id="inf-lean")])
 def test_infinite_medium_decks(gpu_device, deck, tol):
     """inputs/inf.in and inputs/inf_stiff.in (100 and 10 cycles; the swarm pool grows as emission
     particles accumulate): the domain-mean radiation energy density stays at a T0^4.  inf runs as
@@ -139,6 +146,10 @@ def test_full_size_c3_profile(gpu_device, capsys):
                        "parthenon/meshblock/nx1=16", "parthenon/meshblock/nx2=4",
                        "parthenon/meshblock/nx3=4", "jaybenne/num_particles=30000"]),
     ("stepdiff_smr_hybrid", ["jaybenne/num_particles=30000", "parthenon/time/nlim=2"]),   # 2-D, 2 levels
+    ("stepdiff", ["parthenon/mesh/nx1=64", "parthenon/meshblock/nx1=32", "jaybenne/num_particles=20000",
+                  "mcblock/time_scale=2.0", "mcblock/mass_scale=3.0", "mcblock/length_scale=5.0",
+                  "mcblock/temperature_scale=7.0", "mcblock/opacity_model=constant",
+                  "mcblock/opacity_constant_value=0.5"]),       # non-unit code -> CGS scales, absorbing
     ("stepdiff_smr_ddmc", ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16",
                            "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8",
                            "parthenon/meshblock/nx3=8", "jaybenne/num_particles=30000",
