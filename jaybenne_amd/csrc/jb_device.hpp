@@ -141,7 +141,9 @@ __device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
 constexpr int kLdsBlocks = 128;
 struct LdsBlockTable {
   double xmin[kLdsBlocks][3], dx[kLdsBlocks][3], inv_dx[kLdsBlocks][3];
+#ifndef JB_NO_LDS_X0
   double x0[kLdsBlocks][3];  // coordinate of cell index 0: xmin - first * dx
+#endif
   double *tally[kLdsBlocks];
   int owned[kLdsBlocks];
   int nbr_ent[kLdsBlocks][6];
@@ -152,14 +154,24 @@ __device__ __forceinline__ void fill_block_table(const DevMesh &M, LdsBlockTable
     (&T.xmin[0][0])[q] = M.blk_xmin[q];
     (&T.dx[0][0])[q] = M.blk_dx[q];
     (&T.inv_dx[0][0])[q] = M.blk_inv_dx[q];
+#ifndef JB_NO_LDS_X0
     const int first = (q % 3 == 0) ? M.is : (q % 3 == 1 ? M.js : M.ks);
     (&T.x0[0][0])[q] = M.blk_xmin[q] - (double)first * M.blk_dx[q];
+#endif
   }
   for (int q = threadIdx.x; q < M.nblocks; q += blockDim.x) {
     T.tally[q] = M.tally[q];
     T.owned[q] = M.owned[q];
   }
   for (int q = threadIdx.x; q < 6 * M.nblocks; q += blockDim.x) (&T.nbr_ent[0][0])[q] = M.nbr_ent[q];
+}
+__device__ __forceinline__ double lds_x0(const DevMesh &M, const LdsBlockTable &T, int b, int d) {
+#ifndef JB_NO_LDS_X0
+  return T.x0[b][d];
+#else
+  const int first = d == 0 ? M.is : (d == 1 ? M.js : M.ks);
+  return T.xmin[b][d] - (double)first * T.dx[b][d];
+#endif
 }
 __device__ __forceinline__ int block_nbr_ent(const DevMesh &M, const LdsBlockTable &T, int b, int face) {
   return M.nblocks > kLdsBlocks ? ((gcptr_i)M.nbr_ent)[6 * b + face] : T.nbr_ent[b][face];
@@ -179,7 +191,7 @@ __device__ __forceinline__ void load_block(const DevMesh &M, const LdsBlockTable
   for (int d = 0; d < 3; ++d) {
     B.xmin[d] = T.xmin[b][d];
     B.dx[d] = T.dx[b][d];
-    B.x0[d] = T.x0[b][d];
+    B.x0[d] = lds_x0(M, T, b, d);
     B.inv_dx[d] = T.inv_dx[b][d];
   }
   B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));
@@ -192,7 +204,7 @@ __device__ __forceinline__ void load_block_lds(const DevMesh &M, const LdsBlockT
   for (int d = 0; d < 3; ++d) {
     B.xmin[d] = T.xmin[b][d];
     B.dx[d] = T.dx[b][d];
-    B.x0[d] = T.x0[b][d];
+    B.x0[d] = lds_x0(M, T, b, d);
     B.inv_dx[d] = T.inv_dx[b][d];
   }
   B.dx_push = dmin(B.dx[0], dmin(B.dx[1], B.dx[2]));
@@ -237,9 +249,13 @@ __device__ __forceinline__ bool on_block(const DevMesh &M, int i, int j, int k) 
 // (through inline asm: left to itself the compiler forms k nj + j with v_mad_u64_u32, a
 // quarter-rate instruction, in the tracking loops)
 __device__ __forceinline__ int mad24(int a, int b_uniform, int c) {
+#ifdef JB_NO_MAD24_ASM
+  return __mul24(a, b_uniform) + c;
+#else
   int d;
   asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
   return d;
+#endif
 }
 __device__ __forceinline__ int cidx(const DevMesh &M, int k, int j, int i) {
   return mad24(mad24(k, M.nj, j), M.ni, i);

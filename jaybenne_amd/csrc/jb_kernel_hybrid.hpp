@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       g.dx[d] = lds_blocks.dx[b][d];
-      g.x0[d] = lds_blocks.x0[b][d];
+      g.x0[d] = lds_x0(M, lds_blocks, b, d);
       g.fd[d] = kEpsImc * g.dx[d];
     }
     dxp = dmin(g.dx[0], dmin(g.dx[1], g.dx[2]));
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
       }
     }
     b = ent & 0x0fffffff;
-    g.x0[AXIS] = lds_blocks.x0[b][AXIS];
+    g.x0[AXIS] = lds_x0(M, lds_blocks, b, AXIS);
     hyb_off = (unsigned)b * (ntot_u * 8u);
     idx = at_first ? first_i : last_i;
     if (!((kLean ? t > 0.0 : t < t_end))) ls = HS_DONE;

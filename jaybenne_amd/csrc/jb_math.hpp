@@ -63,18 +63,18 @@ __device__ __forceinline__ double m_min(double a, double b) {
   return d;
 }
 
-__shared__ double lds_log_tab[JB_LOG_N][4];  // 32-byte rows: one address serves both reads
+__shared__ double lds_log_tab[JB_LOG_N][4];  // {1/c, log c hi, log c lo, -}: 32-byte rows, one address serves both reads
+__shared__ double lds_log2_tab[JB_LOG_N][2];  // {1/c, log c as one double}: the lean logarithm's row
 __shared__ double lds_sc_tab[JB_SC_N + 1][2];
 __shared__ double lds_sc2_tab[JB_SC2_N + 1][2];
 
 // Copies the three tables into this workgroup's LDS (8.2 KB); ends with a barrier.
 __device__ __forceinline__ void load_math_tables() {
-  // LDS row: {1/c, log c (one double: the lean logarithm), log c in two parts (hi, lo)}
+  for (int q = threadIdx.x; q < JB_LOG_N * 3; q += blockDim.x)
+    lds_log_tab[q / 3][q % 3] = (&jb_log_tab[0][0])[q];
   for (int q = threadIdx.x; q < JB_LOG_N; q += blockDim.x) {
-    lds_log_tab[q][0] = jb_log_tab[q][0];
-    lds_log_tab[q][1] = jb_log_tab[q][1] + jb_log_tab[q][2];
-    lds_log_tab[q][2] = jb_log_tab[q][1];
-    lds_log_tab[q][3] = jb_log_tab[q][2];
+    lds_log2_tab[q][0] = jb_log_tab[q][0];
+    lds_log2_tab[q][1] = jb_log_tab[q][1] + jb_log_tab[q][2];
   }
   for (int q = threadIdx.x; q < (JB_SC_N + 1) * 2; q += blockDim.x)
     (&lds_sc_tab[0][0])[q] = (&jb_sc_tab[0][0])[q];
@@ -140,7 +140,7 @@ __device__ __forceinline__ double m_log(double x) {  // x positive, finite, norm
   const int i = (int)((th >> 13) & (JB_LOG_N - 1));
   const int k = (int)th >> 20;
   const double z = __hiloint2double((int)(hx - (th & 0xfff00000u)), __double2loint(x));
-  const double invc = lds_log_tab[i][0], lc_hi = lds_log_tab[i][2], lc_lo = lds_log_tab[i][3];
+  const double invc = lds_log_tab[i][0], lc_hi = lds_log_tab[i][1], lc_lo = lds_log_tab[i][2];
   const double r = fma(z, invc, -1.0);
   const double kd = (double)k;
   const double w = fma(kd, ln2_hi, lc_hi);  // exact: both terms are short
@@ -167,7 +167,7 @@ __device__ __forceinline__ double m_log_lean(double x) {
   const int i = (int)((th >> 13) & (JB_LOG_N - 1));
   const int k = (int)th >> 20;
   const double z = __hiloint2double((int)(hx - (th & 0xfff00000u)), __double2loint(x));
-  const double invc = lds_log_tab[i][0], lc = lds_log_tab[i][1];
+  const double invc = lds_log2_tab[i][0], lc = lds_log2_tab[i][1];
   const double r = fma(z, invc, -1.0);
   const double w = fma((double)k, ln2, lc);
   const double r2 = r * r;
