@@ -681,13 +681,13 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
           static int occ = 0;
           if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, true>, kBlock, 0) != hipSuccess || occ < 1)) occ = 3;
           const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
-          hipLaunchKernelGGL((k_ddmc_all<NDIM, true>), dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, S,
+          hipLaunchKernelGGL((k_ddmc_all<NDIM, true>), dim3(g), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, ctx->dp, S,
                              t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
         } else {
           static int occ = 0;
           if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, false>, kBlock, 0) != hipSuccess || occ < 1)) occ = 3;
           const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
-          hipLaunchKernelGGL((k_ddmc_all<NDIM, false>), dim3(g), dim3(kBlock), 0, ctx->stream, M, ctx->dp, S,
+          hipLaunchKernelGGL((k_ddmc_all<NDIM, false>), dim3(g), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, ctx->dp, S,
                              t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
         }
         return;

@@ -46,9 +46,12 @@ template <int NDIM, bool TALLY>
 #define JB_DDMC_ALL_ATTR
 #endif
 __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_ALL_ATTR
-    k_ddmc_all(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
-               long long last, unsigned long long *counters, const int *not_all_ddmc) {
-  if (*not_all_ddmc != 0) return;  // (uniform) some cell takes IMC steps: k_transport runs instead
+    k_ddmc_all(const DevMesh *__restrict__ Mp, DevParams P, DevSwarm S, double t_start, double dt,
+               long long first, long long last, unsigned long long *counters, const int *not_all_ddmc) {
+  if (*not_all_ddmc != 0) return;  // (uniform) some cell takes IMC steps: k_hybrid runs instead
+  // (the mesh view through a pointer to its copy in device memory: as a by-value argument its ~120
+  // dwords compete for the scalar registers, and parked scalars cost vector registers)
+  const DevMesh &M = *Mp;
   __shared__ double lds_tally[TALLY ? kLdsTally : 1];
   const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
   if constexpr (TALLY) {
@@ -70,9 +73,10 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   bool more = true;
   long long chunk_pos = 0, chunk_end = 0;
 
+  // wave-level counters (scalar registers; updated outside divergent branches): finished histories
+  // by outcome; events = running lanes summed over the event-loop passes + service-phase steps
   unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0;
-  unsigned long long c_ev = 0;   // wave-level: running lanes summed over the event-loop passes
-  unsigned int c_ev_real = 0;    // per lane: steps taken in the service phase
+  unsigned long long c_ev = 0;
   unsigned int c_pass = 0, c_service = 0;
 
   // ---- lane state that lives across the event loop ("virtual" particle)
@@ -80,7 +84,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   long long n = 0;
   LcgRng rng(0);
   int b = 0, ip = 0, jp = 0, kp = 0;
-  double t = 0.0, wgt = 0.0;
+  double t = 0.0;
   // channel of the last leak (0..5) while its direction is deferred; -1: the direction is the one
   // in vx, vy, vz (real_pos) or, for a lane in the loop, the one in S.vx, vy, vz [n]; -2: zero,
   // the flag a multi-D DDMC leak across a block face leaves behind (transport_ddmc.cpp:203-211)
@@ -225,8 +229,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     long long cand = -1;
     int st_in = ST_ABSORBED, b_in = 0;
     unsigned long long rng_in = 0ull;
-    double t_in = 0.0, x_in = 0.0, y_in = 0.0, z_in = 0.0, vx_in = 0.0, vy_in = 0.0, vz_in = 0.0,
-           w_in = 0.0;
+    double t_in = 0.0, x_in = 0.0, y_in = 0.0, z_in = 0.0, vx_in = 0.0, vy_in = 0.0, vz_in = 0.0;
     {
       unsigned long long need = __ballot(ls == DS_IDLE || ls == DS_DONE);
       while (need != 0ull && more) {
@@ -257,7 +260,6 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           b_in = S.blk[cand];
           t_in = S.t[cand]; x_in = S.x[cand]; y_in = S.y[cand]; z_in = S.z[cand];
           vx_in = S.vx[cand]; vy_in = S.vy[cand]; vz_in = S.vz[cand];
-          w_in = S.w[cand];
         }
         chunk_pos += give;
         need &= ~__ballot(mine);
@@ -265,6 +267,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     }
     JB_PH(1)
     // -- 2b. finished particles: census resampling, write-back, tally
+    const bool was_done = ls == DS_DONE;
     if (ls == DS_DONE) {
       bool write_v = real_pos;  // else: unchanged since it was loaded (or parked), or set below
       if (status != ST_OUTGOING && status != ST_ESCAPED) {
@@ -302,6 +305,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         } else if (status == ST_ACTIVE) {
           if constexpr (TALLY) {  // jaybenne.cpp:547-561
             const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
+            // (the weight is read here, once per history, rather than carried through the event loop)
+            const double wgt = S.w[n];
             if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
             else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], wgt / dv);
           }
@@ -316,12 +321,16 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
       S.status[n] = status;
       S.rng[n] = rng.s;
-      if (status == ST_ACTIVE) ++c_census;
-      else if (status == ST_ABSORBED) ++c_abs;
-      else if (status == ST_ESCAPED) ++c_esc;
-      else ++c_out;
       resample = false;
       ls = DS_IDLE;
+    }
+    {
+      const int n_done = __popcll(__ballot(was_done));
+      const int n_census = __popcll(__ballot(was_done && status == ST_ACTIVE));
+      const int n_abs = __popcll(__ballot(was_done && status == ST_ABSORBED));
+      const int n_esc = __popcll(__ballot(was_done && status == ST_ESCAPED));
+      c_census += n_census; c_abs += n_abs; c_esc += n_esc;
+      c_out += n_done - n_census - n_abs - n_esc;
     }
     JB_PH(2)
     // -- 3b. the lanes that claimed a slot in 2a take their new particle
@@ -330,7 +339,6 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       rng.s = rng_in;
       b = b_in;
       t = t_in;
-      wgt = w_in;
       x = x_in; y = y_in; z = z_in; vx = vx_in; vy = vy_in; vz = vz_in;
       status = ST_ACTIVE;
       resample = false;
@@ -345,8 +353,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     JB_PH(3)
     // -- 4. one step with the real position (first step after a load or a block crossing, and
     //       the steps after an albedo rejection): the general step functions
+    c_ev += (unsigned)__popcll(__ballot(ls == DS_REAL));
     if (ls == DS_REAL) {
-      ++c_ev_real;
       Blk Br;
       load_block_lds(M, lds_blocks, b, Br);
       Step s;
@@ -370,7 +378,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         ls = DS_RELOC;
       } else if (s.is_absorbed) {  // transport.cpp:157-163
         if (lds_blocks.owned[b] != 0) {
-          atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], wgt);
+          atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], S.w[n]);
           status = ST_ABSORBED;
         } else {
           status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
@@ -446,7 +454,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           }
         } else if (s.is_absorbed) {  // transport.cpp:157-163
           if (lds_blocks.owned[b] != 0) {
-            atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], wgt);
+            atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], S.w[n]);
             status = ST_ABSORBED;
           } else {
             status = ST_OUTGOING_ABSORBED;
@@ -471,9 +479,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       }
     }
   }
-  unsigned long long r_census = wave_sum(c_census), r_abs = wave_sum(c_abs), r_esc = wave_sum(c_esc),
-                     r_out = wave_sum(c_out);
-  const unsigned long long r_ev = c_ev + wave_sum(c_ev_real);
+  const unsigned long long r_census = c_census, r_abs = c_abs, r_esc = c_esc, r_out = c_out, r_ev = c_ev;
   if (lane == 0) {
     if (r_census) atomicAdd(&counters[CNT_CENSUS], r_census);
     if (r_abs) atomicAdd(&counters[CNT_ABSORBED], r_abs);
