@@ -401,6 +401,19 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
   // DDMC kernels re-read the block geometry at the top of every event pass (below): from LDS
   __shared__ std::conditional_t<DDMC, LdsBlockTable, int> blk_tab;
   if constexpr (DDMC) fill_block_table(M, blk_tab);
+  // gray IMC kernels: the face-crossing table (destination block and the coordinate that changes
+  // per face of a resident block) in LDS -- a crossing lane's two dependent look-ups then cost an
+  // LDS round trip instead of two trips to L2 that the whole wave waits for
+  struct FaceTable { int ent[kLdsBlocks][6]; double x0[kLdsBlocks][6]; };
+  __shared__ std::conditional_t<(GRAY != 0 && !DDMC), FaceTable, int> face_tab;
+  const bool faces_in_lds = M.nblocks <= kLdsBlocks;
+  if constexpr (GRAY != 0 && !DDMC) {
+    if (faces_in_lds)
+      for (int q = threadIdx.x; q < 6 * M.nblocks; q += blockDim.x) {
+        (&face_tab.ent[0][0])[q] = M.nbr_ent[q];
+        (&face_tab.x0[0][0])[q] = M.nbr_x0[q];
+      }
+  }
   load_math_tables();  // (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   constexpr bool kFastGray = GRAY != 0 && !DDMC;
@@ -557,9 +570,19 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
                         int last_i) -> bool {
     constexpr int AXIS = decltype(axis_c)::value;
     const int slot = 6 * b + 2 * AXIS + (int)up;
-    const int ent = M.nbr_ent[slot];
+    int ent;
     double nx0 = 0.0;  // (the DDMC kernels re-read the block geometry every pass)
-    if constexpr (kFastGray) nx0 = ((gcptr)M.nbr_x0)[slot];
+    if constexpr (kFastGray) {
+      if (faces_in_lds) {  // (uniform)
+        ent = (&face_tab.ent[0][0])[slot];
+        nx0 = (&face_tab.x0[0][0])[slot];
+      } else {
+        ent = M.nbr_ent[slot];
+        nx0 = ((gcptr)M.nbr_x0)[slot];
+      }
+    } else {
+      ent = M.nbr_ent[slot];
+    }
     if (ent < 0) return false;
     const int kind = ent >> 28;
     bool at_first = up;  // entered through the destination's lower face
