@@ -848,6 +848,19 @@ extern "C" jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats 
           ctx->counters_h[24], ctx->counters_h[25], ctx->counters_h[26], ctx->counters_h[27],
           ctx->counters_h[28]);
 #endif
+#ifdef JB_HYB_STATS  // (diagnostic build of k_hybrid: see jb_kernel_hybrid.hpp)
+  {
+    unsigned long long h[48];
+    (void)hipMemcpy(h, ctx->counters_d + 64, sizeof h, hipMemcpyDeviceToHost);
+    const char *nm[9] = {"idle", "imc", "virt", "real", "done", "reloc", "emerge", "new", "park"};
+    for (int ph = 0; ph < 3; ++ph) {
+      fprintf(stderr, "JB_HYB_STATS phase %d: services %llu imc passes %llu (lanes %llu) ddmc passes %llu | lanes at service:", ph,
+              h[16 * ph + 12], h[16 * ph + 9], h[16 * ph + 11], h[16 * ph + 10]);
+      for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %llu", nm[k], h[16 * ph + k]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   if (reset) JB_HIP(hipMemsetAsync(ctx->counters_d, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
   return JB_COMPLETE;
 }

@@ -234,9 +234,15 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
 
   int park_waste = 0;  // wave-level: lane-passes parked DDMC lanes have waited since the last DDMC loop
 
+#ifdef JB_HYB_STATS  // diagnostic build: lanes entering the service phase by state, loop passes by kind
+  unsigned int st_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_imc_pass = 0, st_ddmc_pass = 0, st_imc_lanes = 0;
+#endif
   for (;;) {
     // ================================ SERVICE ================================
     ++c_service;
+#ifdef JB_HYB_STATS
+    for (int k = 0; k < 9; ++k) st_cnt[k] += (unsigned)__popcll(__ballot(ls == k));
+#endif
     // lanes that left the IMC loop of a lean kernel: back to time and velocity (census: the
     // distance left is exactly 0, t = t_end)
     if constexpr (kLean) {
@@ -575,6 +581,9 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
           if (__double2hiint(s.sig) < 0) ls = HS_EMERGE;
         }
         const int stepping = __popcll(__ballot(ls == HS_VIRT));
+#ifdef JB_HYB_STATS
+        ++st_ddmc_pass;
+#endif
         ++c_pass;
         c_ev += (unsigned int)stepping;
         if (ls == HS_VIRT) {
@@ -621,6 +630,9 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
         const int stepping = __popcll(__ballot(ls == HS_IMC));
         ++c_pass;
         c_ev += (unsigned int)stepping;
+#ifdef JB_HYB_STATS
+        ++st_imc_pass; st_imc_lanes += stepping;
+#endif
         bool crossing = false;  // left its block in this pass
         if (ls == HS_IMC) {
           bool is_absorbed, is_scattered;
@@ -708,6 +720,13 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
     if (r_ev) atomicAdd(&counters[CNT_EVENTS], r_ev);
     atomicAdd(&counters[CNT_PASSES], (unsigned long long)c_pass);
     atomicAdd(&counters[CNT_SERVICE], (unsigned long long)c_service);
+#ifdef JB_HYB_STATS
+    for (int k = 0; k < 9; ++k) atomicAdd(&counters[64 + 16 * PHASE + k], (unsigned long long)st_cnt[k]);
+    atomicAdd(&counters[64 + 16 * PHASE + 9], (unsigned long long)st_imc_pass);
+    atomicAdd(&counters[64 + 16 * PHASE + 10], (unsigned long long)st_ddmc_pass);
+    atomicAdd(&counters[64 + 16 * PHASE + 11], (unsigned long long)st_imc_lanes);
+    atomicAdd(&counters[64 + 16 * PHASE + 12], (unsigned long long)c_service);
+#endif
   }
 }
 
