@@ -1,0 +1,39 @@
+# The command list behind profiles/r03_*: kernel stats of the default bench under rocprofv3, one
+# --pmc pass per counter group for the headline (c2) and the DDMC (c3) workloads, and the bench
+# lines of every workload.  tools/collect_profiles3.py turns gpurun_out/r03prof/ into profiles/.
+set -e
+O=gpurun_out/r03prof
+mkdir -p $O && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+C2="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
+C3="python3 bench.py --workload c3 --particles-per-gpu 100000000 --steps 1 --warmup 0 --no-cpu-baseline"
+C4="python3 bench.py --workload c4 --particles-per-gpu 10000000 --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
+C5="python3 bench.py --workload c5 --particles-per-gpu 10000000 --steps 1 --warmup 0 --no-cpu-baseline"
+C2X="python3 bench.py --arithmetic exact --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o runc -- python3 bench.py > $O/bench_c2_under_rocprof.json 2> $O/stats_c2.err
+echo "stats c2 done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -o runc -- python3 bench.py --workload c3 --particles-per-gpu 100000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c3_under_rocprof.json 2> $O/stats_c3.err
+echo "stats c3 done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -o runc -- python3 bench.py --workload c5 --particles-per-gpu 10000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c5_under_rocprof.json 2> $O/stats_c5.err
+echo "stats c5 done"
+PA="SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+PB="GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS"
+PC="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"
+PD="FETCH_SIZE"
+PE="WRITE_SIZE"
+PF="TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum"
+PG="TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum"
+for wl in c2 c3 c5 c4 c2x; do
+  case $wl in c2) CMD=$C2;; c3) CMD=$C3;; c4) CMD=$C4;; c5) CMD=$C5;; c2x) CMD=$C2X;; esac
+  for p in A B C D E F G; do
+    eval "CN=\$P$p"
+    timeout -k 5 150 rocprofv3 --kernel-trace --pmc $CN --output-format csv -d $O/pmc_${wl}_$p -o runc -- $CMD > $O/pmc_${wl}_$p.json 2> $O/pmc_${wl}_$p.err || echo "pass $wl $p FAILED"
+    echo "pmc $wl $p done"
+  done
+done
+timeout -k 10 400 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
+for w in "c1 100000" "c3 100000000" "c3-1d 100000000" "c4 10000000" "c5 10000000"; do
+  set -- $w
+  timeout -k 10 300 python3 bench.py --workload $1 --particles-per-gpu $2 --no-cpu-baseline > $O/bench_$1.json 2> $O/bench_$1.err
+  echo "bench $1 done"
+done
+echo all done
