@@ -87,17 +87,6 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
   }
   __shared__ LdsBlockTable lds_blocks;
   fill_block_table(M, lds_blocks);
-  // finest-level leaf -> resident block (local index, -1: another rank's), for the in-loop
-  // relocation of an IMC photon across a level change (below); meshes with more leaves than fit
-  // here send those crossings to the service phase
-  constexpr int kLdsLeaves = 2048;
-  __shared__ int lds_leaf[PHASE != 2 ? kLdsLeaves : 1];
-  const int nleaf_total = M.nleaf[0] * M.nleaf[1] * M.nleaf[2];
-  const bool leaves_in_lds = PHASE != 2 && nleaf_total <= kLdsLeaves;
-  if constexpr (PHASE != 2) {
-    if (leaves_in_lds)
-      for (int q = threadIdx.x; q < nleaf_total; q += blockDim.x) lds_leaf[q] = M.local_index[M.leaf_map[q]];
-  }
   load_math_tables();  // (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   constexpr bool kLean = MODE != 0, kExactG = MODE == 2;
@@ -238,38 +227,6 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
     g.x0[AXIS] = lds_x0(M, lds_blocks, b, AXIS);
     hyb_off = (unsigned)b * (ntot_u * 8u);
     idx = at_first ? first_i : last_i;
-    if (!((kLean ? t > 0.0 : t < t_end))) ls = HS_DONE;
-    else fetch_lam();
-    return true;
-  };
-
-  // An IMC photon that left its block other than through one face into a same-size neighbour (a
-  // level change, a corner): the comm phase of the reference -- swarm boundary conditions,
-  // destination leaf, Xtoijk in the new block (SampleDDMCBlockFace leaves a photon with a velocity
-  // alone) -- with every table in LDS, inside the IMC loop.  Same arithmetic as the service
-  // phase's relocation.  Returns false (nothing changed) when the photon escapes, the
-  // destination is not resident here, or the leaf table is not in LDS: the service phase decides.
-  auto relocate_in_loop = [&]() -> bool {
-    if (!leaves_in_lds) return false;
-    double rx = x, ry = y, rz = z, rvx = vx, rvy = vy, rvz = vz;
-    if (!apply_swarm_bcs<NDIM>(M, rx, ry, rz, rvx, rvy, rvz)) return false;
-    const double p[3] = {rx, ry, rz};
-    int l[3] = {0, 0, 0};
-#pragma unroll
-    for (int d = 0; d < NDIM; ++d) {  // (find_block)
-      int q = (int)floor((p[d] - M.gmin[d]) * M.inv_leaf_len[d]);
-      q = q < 0 ? 0 : q;
-      q = q > M.nleaf[d] - 1 ? M.nleaf[d] - 1 : q;
-      l[d] = q;
-    }
-    const int li = lds_leaf[(l[2] * M.nleaf[1] + l[1]) * M.nleaf[0] + l[0]];
-    if (li < 0) return false;
-    x = rx; y = ry; z = rz; vx = rvx; vy = rvy; vz = rvz;
-    b = li;
-    Blk Bn;
-    load_block_lds(M, lds_blocks, b, Bn);
-    xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);
-    bind_geometry();
     if (!((kLean ? t > 0.0 : t < t_end))) ls = HS_DONE;
     else fetch_lam();
     return true;
@@ -734,7 +691,6 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
             if (xo && !yo && !zo) done = cross_face(std::integral_constant<int, 0>{}, ip > l_ie, x, vx, ip, l_is, l_ie);
             else if (yo && !xo && !zo) done = cross_face(std::integral_constant<int, 1>{}, jp > l_je, y, vy, jp, l_js, l_je);
             else if (zo && !xo && !yo) done = cross_face(std::integral_constant<int, 2>{}, kp > l_ke, z, vz, kp, l_ks, l_ke);
-            if (!done) done = relocate_in_loop();
             if (!done) ls = HS_RELOC;
           }
         }
