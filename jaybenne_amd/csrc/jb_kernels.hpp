@@ -404,9 +404,11 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
   // gray IMC kernels: the face-crossing table (destination block and the coordinate that changes
   // per face of a resident block) in LDS -- a crossing lane's two dependent look-ups then cost an
   // LDS round trip instead of two trips to L2 that the whole wave waits for
-  struct FaceTable { int ent[kLdsBlocks][6]; double x0[kLdsBlocks][6]; };
+  // (256 resident blocks: BASELINE configs[1] on 8 GPUs holds 64 owned blocks + 80 halo copies per rank)
+  constexpr int kLdsFaceBlocks = 256;
+  struct FaceTable { int ent[kLdsFaceBlocks][6]; double x0[kLdsFaceBlocks][6]; };
   __shared__ std::conditional_t<(GRAY != 0 && !DDMC), FaceTable, int> face_tab;
-  const bool faces_in_lds = M.nblocks <= kLdsBlocks;
+  const bool faces_in_lds = M.nblocks <= kLdsFaceBlocks;
   if constexpr (GRAY != 0 && !DDMC) {
     if (faces_in_lds)
       for (int q = threadIdx.x; q < 6 * M.nblocks; q += blockDim.x) {
