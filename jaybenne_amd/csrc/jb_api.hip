@@ -621,7 +621,7 @@ extern "C" jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh,
 
 // ------------------------------------------------------------------------------------------------
 template <int NDIM, bool DDMC>
-static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, double t_start,
+static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, double t_start,
                              double dt, long long first, long long last, bool tally) {
   const DevMesh &M = mesh->dm;
   // The kernel is persistent (waves draw particles from queues until they are empty), so the grid
@@ -671,7 +671,7 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
       int *flag_h = (int *)(ctx->counters_h + kCounterWords - 1);
       *flag_h = 1;
       (void)hipMemcpyAsync(flag_h, M.not_all_ddmc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-      (void)hipStreamSynchronize(ctx->stream);
+      JB_HIP(hipStreamSynchronize(ctx->stream));
       const bool noabs_h = ctx->dp.kappa_a == 0.0;
       if (*flag_h == 0) {
         mesh->last_variant = NDIM == 1 ? (tally ? "k_ddmc_all<1, true>" : "k_ddmc_all<1, false>")
@@ -690,7 +690,7 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
           hipLaunchKernelGGL((k_ddmc_all<NDIM, false>), dim3(g), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, ctx->dp, S,
                              t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
         }
-        return;
+        return JB_COMPLETE;
       }
       // A mix of IMC and DDMC cells, three launches: k_hybrid<.., PHASE 1> follows the photons in
       // IMC cells (its service phase also takes the albedo step of a photon that enters a DDMC
@@ -702,7 +702,10 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
       // parked photons (slot numbers, 4 bytes each) live in the context's scratch buffer.
       // (variant string: NDIM, TALLY, NOABS, MODE: 0 exact arithmetic, 1 lean, 2 lean on exact geometry)
       const long long nrange = last - first;
-      if (ensure_scratch(ctx, (size_t)nrange + 16) != JB_COMPLETE) return;  // 2 lists x 4 bytes x n
+      {  // 2 lists x 4 bytes x n
+        const jb_status st_s = ensure_scratch(ctx, (size_t)nrange + 16);
+        if (st_s != JB_COMPLETE) return st_s;
+      }
       unsigned *list_d = (unsigned *)ctx->scratch_d;          // parked by phase 1, read by phase 2
       unsigned *list_i = list_d + nrange;                     // parked by phase 2, read by phase 1
       unsigned long long *cnt = ctx->counters_d + kCursorBase;  // [0] |list_d|, [1] |list_i|
@@ -739,21 +742,21 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
       if (tally) { if (noabs_h) JB_PHASE1(true, true, first, last, nullptr); else JB_PHASE1(true, false, first, last, nullptr); }
       else { if (noabs_h) JB_PHASE1(false, true, first, last, nullptr); else JB_PHASE1(false, false, first, last, nullptr); }
       (void)hipMemcpyAsync((void *)cnt_h, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
-      if (hipStreamSynchronize(ctx->stream) != hipSuccess) return;
+      JB_HIP(hipStreamSynchronize(ctx->stream));
       const long long n_d = (long long)cnt_h[0];
-      if (n_d == 0) return;
+      if (n_d == 0) return JB_COMPLETE;
       if (tally) JB_LAUNCH_H(true, true, 0, 2, 0, n_d, list_d, list_i, cnt + 1);
       else JB_LAUNCH_H(false, true, 0, 2, 0, n_d, list_d, list_i, cnt + 1);
       (void)hipMemcpyAsync((void *)(cnt_h + 1), cnt + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
-      if (hipStreamSynchronize(ctx->stream) != hipSuccess) return;
+      JB_HIP(hipStreamSynchronize(ctx->stream));
       const long long n_i = (long long)cnt_h[1];
-      if (n_i == 0) return;
+      if (n_i == 0) return JB_COMPLETE;
       if (tally) { if (noabs_h) JB_PHASE0(true, true, n_i, list_i); else JB_PHASE0(true, false, n_i, list_i); }
       else { if (noabs_h) JB_PHASE0(false, true, n_i, list_i); else JB_PHASE0(false, false, n_i, list_i); }
 #undef JB_PHASE0
 #undef JB_PHASE1
 #undef JB_LAUNCH_H
-      return;
+      return JB_COMPLETE;
     }
   }
   // gray opacity with kappa = 0 (opacity_model = none): sigma_a = rho * 0 in every cell
@@ -761,7 +764,7 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
   if (noabs) {
     if (tally) JB_LAUNCH(true, 2);
     else JB_LAUNCH(false, 2);
-    return;
+    return JB_COMPLETE;
   }
   if (tally && gray) JB_LAUNCH(true, 1);
   else if (tally) JB_LAUNCH(true, 0);
@@ -769,6 +772,7 @@ static void launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm &S, 
   else JB_LAUNCH(false, 0);
 #undef JB_LAUNCH
 #undef JB_LAUNCH_X
+  return JB_COMPLETE;
 }
 
 static jb_status transport_impl(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
@@ -788,13 +792,14 @@ static jb_status transport_impl(jb_context *ctx, jb_mesh *mesh, const jb_swarm_v
   const DevSwarm S = dev_swarm(swarm);
   const bool tl = tally != 0;
   switch (M.ndim * 2 + (ddmc ? 1 : 0)) {
-  case 2: launch_transport<1, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
-  case 3: launch_transport<1, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
-  case 4: launch_transport<2, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
-  case 5: launch_transport<2, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
-  case 6: launch_transport<3, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
-  default: launch_transport<3, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  case 2: st = launch_transport<1, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  case 3: st = launch_transport<1, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  case 4: st = launch_transport<2, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  case 5: st = launch_transport<2, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  case 6: st = launch_transport<3, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
+  default: st = launch_transport<3, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
   }
+  if (st != JB_COMPLETE) return st;
   JB_HIP(hipGetLastError());
   return JB_COMPLETE;
 }

@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
   // the one in vx, vy, vz
   int pend = -1;
   bool resample = false;  // reached census in a DDMC step: position / direction to be resampled
+  bool fresh = false;     // loaded and not touched since: parking it needs no write-back
   // IMC lanes: geometry of the lane's block (index-0 coordinate, cell width, nudge width per axis)
   // and the mean free paths of its cell (lam_cur < 0: the cell takes DDMC steps)
   // (bound when the IMC loop is entered: nothing of it is live in the service phase or the DDMC loop)
@@ -197,6 +198,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
     hyb_off = (unsigned)b * (ntot_u * 8u);
   };
   auto enter_imc = [&]() {
+    fresh = false;
     if constexpr (kLean) {
       t = vv * (t_end - t);
       vx *= P.rc; vy *= P.rc; vz *= P.rc;
@@ -254,6 +256,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
     }
     // -- 1. block crossings: the comm phase of the reference for one particle in flight
     if (ls == HS_RELOC) {
+      fresh = false;
       Blk Bo;
       load_block_lds(M, lds_blocks, b, Bo);
       Step s;
@@ -309,6 +312,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
     // -- 2. a DDMC photon that leaked into an IMC cell of its block: position and direction as
     //       the step function gave them (transport_utils.hpp:209-263), from the cell it left
     if (ls == HS_EMERGE) {
+      fresh = false;
       Blk Bo;
       load_block_lds(M, lds_blocks, b, Bo);
       Step s;
@@ -438,6 +442,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
       pend = -1;
       real_pos = true;
       in_dir = false;
+      fresh = true;
       Blk Bn;
       load_block_lds(M, lds_blocks, b, Bn);
       xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);  // transport.cpp:96
@@ -448,6 +453,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
     //       general step functions (transport_ddmc.cpp:137-179)
     c_ev += (unsigned)__popcll(__ballot(ls == HS_REAL));
     if (ls == HS_REAL) {
+      fresh = false;
       Blk Br;
       load_block_lds(M, lds_blocks, b, Br);
       Step s;
@@ -535,12 +541,15 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
           vx = s.vx; vy = s.vy; vz = s.vz;
           pend = -1;
         }
-        S.blk[n] = b;
-        S.t[n] = t;
-        S.x[n] = x; S.y[n] = y; S.z[n] = z;
-        S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
-        S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
-        S.rng[n] = rng.s;
+        if (!fresh) {  // (a photon parked as it was loaded -- e.g. one that starts the cycle in a DDMC
+                       // cell, seen by the IMC phase -- is only listed)
+          S.blk[n] = b;
+          S.t[n] = t;
+          S.x[n] = x; S.y[n] = y; S.z[n] = z;
+          S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+          S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
+          S.rng[n] = rng.s;
+        }
         const unsigned long long pm = __ballot(true);
         const int leader = __ffsll((long long)pm) - 1;
         unsigned long long base = 0ull;
