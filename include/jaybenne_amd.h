@@ -243,8 +243,12 @@ jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swa
  *         libm-arithmetic CPU path on the same streams (measured 3e-13 sigma on BASELINE
  *         configs[0], 0.016 sigma per x-plane on configs[1]'s geometry) and the reference's error
  *         metric against the analytic profile not worse than that path's + 0.01.
- * The IMC steps of a hybrid (IMC / DDMC) deck follow the same switch; DDMC steps and the
- * per-event-opacity kernels have the exact arithmetic only.  JB_EXACT_ARITH=1
+ * The IMC steps of a hybrid (IMC / DDMC) deck follow the same switch -- on a mesh without the
+ * exact geometry (jb_mesh_exact_geometry) testing BOTH faces per axis, as the reference does: there
+ * a photon that leaked from a coarse DDMC cell into a finer block can be left, unresampled and
+ * with zero velocity, on a face of the fine cells (sample_ddmc_bface.cpp's fuzzy test, tolerance
+ * 2e-16 dx, missing it) -- ; DDMC steps and the per-event-opacity kernels have the exact arithmetic
+ * only.  JB_EXACT_ARITH=1
  * in the environment makes exact the default of jb_initialize. */
 enum { JB_ARITH_EXACT = 0, JB_ARITH_LEAN = 1 };
 jb_status jb_set_arithmetic(jb_context *ctx, int mode);

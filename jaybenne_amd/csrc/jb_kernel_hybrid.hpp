@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
         if (ls == HS_IMC) {
           bool is_absorbed, is_scattered;
           if constexpr (kLean) {
-            imc_step_dir<NDIM, NOABS, kExactG>(g, dxp, lam_a_cur, lam_cur, rng, t, x, y, z, vx, vy, vz,
+            imc_step_dir<NDIM, NOABS, kExactG, !kExactG>(g, dxp, lam_a_cur, lam_cur, rng, t, x, y, z, vx, vy, vz,
                                                ip, jp, kp, is_absorbed, is_scattered);
           } else {
             ImcCell c;

@@ -303,7 +303,18 @@ __device__ __forceinline__ void dir_nudge(double &x, int &idx, double o, double 
   x = hit ? f + __hiloint2double(shi, __double2loint(fd)) : x;
   idx = iu - (int)(hit != up);
 }
-template <int NDIM, bool NOABS, bool EXACTG, class Rng>
+// ... and, BOTH, at the face behind as well -- pushed outwards through it as the reference does
+// whatever the direction (transport_utils.hpp:151-159).  The hybrid kernel on a general geometry
+// needs it: a DDMC leak across a block face leaves the photon with ZERO velocity at the centre of
+// the coarse cell it left -- a face of the fine cells -- and SampleDDMCBlockFace resamples it only if
+// its fuzzy test (tolerance 2e-16 dx) recognises the position, which on cell widths that are not
+// powers of two it does not always do; the photon then sits on that face until it scatters.
+__device__ __forceinline__ void dir_nudge_behind(double &x, int &idx, double fb, double fd, bool up) {
+  const bool hit = fabs(x - fb) < fd;
+  x = hit ? (up ? fb - fd : fb + fd) : x;
+  idx += hit ? (up ? -1 : 1) : 0;
+}
+template <int NDIM, bool NOABS, bool EXACTG, bool BOTH = false, class Rng>
 __device__ __forceinline__ void imc_step_dir(const DirGeom &g, double dx_push0, double lam_abs,
                                              double lam_sc, Rng &rng, double &d_rem, double &x,
                                              double &y, double &z, double ox, double oy, double oz,
@@ -336,6 +347,16 @@ __device__ __forceinline__ void imc_step_dir(const DirGeom &g, double dx_push0, 
   dir_nudge(x, ip, ox, fx, EXACTG ? g.fd[0] : kEpsImc * g.dx[0], iux, upx);
   if (multi_d) dir_nudge(y, jp, oy, fy, EXACTG ? g.fd[1] : kEpsImc * g.dx[1], iuy, upy);
   if (three_d) dir_nudge(z, kp, oz, fz, EXACTG ? g.fd[2] : kEpsImc * g.dx[2], iuz, upz);
+  if constexpr (BOTH) {
+    // (the other face of the cell the step started in; never both faces of one axis: they are dx
+    // apart, and a photon nudged through the face ahead ends fd beyond that one)
+    int unused;
+    dir_nudge_behind(x, ip, dir_face<EXACTG>(g, 0, iux - (int)upx, !upx, unused), kEpsImc * g.dx[0], upx);
+    if (multi_d)
+      dir_nudge_behind(y, jp, dir_face<EXACTG>(g, 1, iuy - (int)upy, !upy, unused), kEpsImc * g.dx[1], upy);
+    if (three_d)
+      dir_nudge_behind(z, kp, dir_face<EXACTG>(g, 2, iuz - (int)upz, !upz, unused), kEpsImc * g.dx[2], upz);
+  }
 }
 
 // scattering.hpp:21-29 in direction space: the new unit direction (2 draws)

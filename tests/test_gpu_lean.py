@@ -39,6 +39,13 @@ CASES = [
                   "jaybenne/num_particles": 20000}, 1),                        # absorbing (GRAY = 1)
     ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 30000}, 1),            # hybrid: IMC steps lean
     ("stepdiff_smr_hybrid", dict(C5_LEVEL2, **{"jaybenne/num_particles": 30000}), 1),   # ... 3 levels
+    # cell widths that are not powers of two: the lean step on general geometry
+    ("stepdiff", {"parthenon/mesh/nx1": 24, "parthenon/mesh/nx2": 12, "parthenon/mesh/nx3": 12,
+                  "parthenon/meshblock/nx1": 12, "parthenon/meshblock/nx2": 6,
+                  "parthenon/meshblock/nx3": 6, "jaybenne/num_particles": 4000}, 1),
+    ("stepdiff_smr_hybrid", {"parthenon/mesh/nx1": 120, "parthenon/mesh/nx2": 60,
+                             "parthenon/meshblock/nx1": 30, "parthenon/meshblock/nx2": 30,
+                             "jaybenne/num_particles": 30000}, 1),   # (sigma dx = 8.3 coarse, 4.2 fine)
 ]
 
 

@@ -276,6 +276,14 @@ CASES = [
     # 2 levels), all DDMC: coarse -> fine crossings pick one of 4 fine faces (SampleFace3D)
     ("stepdiff_smr_hybrid", dict(SMR3D, **{"jaybenne/num_particles": 30000,
                                            "jaybenne/tau_ddmc": 20.0}), 1),      # 3-D SMR, coarse DDMC / fine IMC
+    # cell widths that are not powers of two: the general-geometry kernels (EXACT = false, k_hybrid
+    # MODE 0 / 1), in 3-D pure IMC and on the 2-D hybrid deck
+    ("stepdiff", {"parthenon/mesh/nx1": 24, "parthenon/mesh/nx2": 12, "parthenon/mesh/nx3": 12,
+                  "parthenon/meshblock/nx1": 12, "parthenon/meshblock/nx2": 6,
+                  "parthenon/meshblock/nx3": 6, "jaybenne/num_particles": 4000}, 1),
+    ("stepdiff_smr_hybrid", {"parthenon/mesh/nx1": 120, "parthenon/mesh/nx2": 60,
+                             "parthenon/meshblock/nx1": 30, "parthenon/meshblock/nx2": 30,
+                             "jaybenne/num_particles": 30000}, 1),   # (sigma dx = 8.3 coarse, 4.2 fine)
 ]
 
 
