@@ -63,9 +63,11 @@ def make_deck(ngpus: int, particles_per_gpu: int, block_nx: int = 64, workload: 
                                            "parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128})
     if workload == "c3":
         ov = {"jaybenne/num_particles": particles_per_gpu * ngpus}
-        for d in range(3):
-            ov[f"parthenon/mesh/nx{d + 1}"] = 128
-            ov[f"parthenon/meshblock/nx{d + 1}"] = 64
+        # (development knob, tools/dev: JB_BENCH_C3_MESH="nx,block_nx,ndim" measures other table sizes)
+        nx, bnx, nd = (int(v) for v in os.environ.get("JB_BENCH_C3_MESH", "128,64,3").split(","))
+        for d in range(nd):
+            ov[f"parthenon/mesh/nx{d + 1}"] = nx
+            ov[f"parthenon/meshblock/nx{d + 1}"] = bnx
         return load_deck("stepdiff_ddmc", ov)
     if workload == "c4":     # stepdiff_smr.in as shipped: 2-D, 20 blocks of 32^2, 2 levels, pure IMC
         return load_deck("stepdiff_smr", {"jaybenne/num_particles": particles_per_gpu * ngpus})

@@ -57,6 +57,7 @@ struct jb_context {
   bool lean_arith = true;
   int blocks_per_cu_env = 0;  // JB_TRANSPORT_BLOCKS_PER_CU at jb_initialize (tuning aid), 0 = occupancy query
   bool no_ddmc_all = false;   // JB_NO_DDMC_ALL=1 at jb_initialize (tests: k_hybrid on all-DDMC meshes)
+  int coop_gather = -1;       // JB_COOP_GATHER=0 / 1: k_ddmc_all's quad-cooperative gather off / on whatever the table size
 };
 constexpr int kCounterWords = 1024;  // CNT_N.. | 16..17 cursors | 32.. per-rank counts (<= 480 ranks)
 constexpr int kCursorBase = 16;
@@ -138,6 +139,7 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   }
   if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) ctx->blocks_per_cu_env = atoi(e);
   if (const char *e = getenv("JB_NO_DDMC_ALL")) ctx->no_ddmc_all = e[0] == '1';
+  if (const char *e = getenv("JB_COOP_GATHER")) ctx->coop_gather = e[0] == '1' ? 1 : 0;  // (tests, A/B runs)
   ctx->dp.key0 = (uint32_t)params->seed;  // RngPool rng_pool(seed): unadjusted (quirk 1)
   ctx->dp.use_ddmc = params->use_ddmc;
   ctx->dp.do_feedback = params->do_feedback;
@@ -436,6 +438,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
     D.not_all_ddmc = (int *)flag;
   }
   D.ddmc_base = nullptr;
+  D.ddmc_step = nullptr;
   D.lam_hyb = nullptr;
   // gray (frequency-independent) opacities: library-owned per-cell mean-free-path arrays
   D.lam_base = nullptr;
@@ -475,6 +478,12 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
       if ((st = upload(m, (const double *const *)pp.data(), (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
       D.ddmc_cell = (double *const *)tmp;
       D.ddmc_base = pack;
+      double *step_rec = nullptr;
+      e = hipMalloc(&step_rec, sizeof(double) * per * 8 * (size_t)v->nblocks);
+      if (e != hipSuccess) { jb_mesh_destroy(m); return fail(JB_ERR_HIP, "hipMalloc of the DDMC step records failed: %s", hipGetErrorString(e)); }
+      m->owned.push_back(step_rec);
+      (void)hipMemset(step_rec, 0, sizeof(double) * per * 8 * (size_t)v->nblocks);
+      D.ddmc_step = step_rec;
       double *hyb = nullptr;
       e = hipMalloc(&hyb, sizeof(double) * per * (size_t)v->nblocks);
       if (e != hipSuccess) { jb_mesh_destroy(m); return fail(JB_ERR_HIP, "hipMalloc of the hybrid mean-free-path array failed: %s", hipGetErrorString(e)); }
@@ -674,22 +683,34 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
       JB_HIP(hipStreamSynchronize(ctx->stream));
       const bool noabs_h = ctx->dp.kappa_a == 0.0;
       if (*flag_h == 0) {
-        mesh->last_variant = NDIM == 1 ? (tally ? "k_ddmc_all<1, true>" : "k_ddmc_all<1, false>")
-                             : NDIM == 2 ? (tally ? "k_ddmc_all<2, true>" : "k_ddmc_all<2, false>")
-                                         : (tally ? "k_ddmc_all<3, true>" : "k_ddmc_all<3, false>");
+        // The quad-cooperative gather (jb_kernel_ddmc.hpp) addresses the step records with 32-bit byte
+        // offsets; it pays once the records no longer sit in the CU's vector L1 (measured, ms per
+        // 1e8 histories: 128^3 cells 31.5 -> 27.9, 64^3 7.2 -> 6.9, 32^3 equal, 128 cells in 1-D
+        // 11.6 -> 13.1: there every lookup hits L1 and the detour through LDS only adds latency).
+        const unsigned long long rec_bytes = 64ull * (unsigned long long)M.ntot * (unsigned long long)M.nblocks;
+        const bool coop = rec_bytes < (1ull << 32) &&
+                          (ctx->coop_gather >= 0 ? ctx->coop_gather == 1 : rec_bytes >= (1ull << 20));
+#define JB_LAUNCH_DDMC_ALL(TL, CO)                                                                          \
+  do {                                                                                                      \
+    static int occ = 0;                                                                                     \
+    if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, TL, CO>, kBlock, 0) != hipSuccess || occ < 1)) occ = 3; \
+    const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                           \
+    hipLaunchKernelGGL((k_ddmc_all<NDIM, TL, CO>), dim3(g), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, ctx->dp, S, \
+                       t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);             \
+  } while (0)
+        static const char *const names[3][2][2] = {
+            {{"k_ddmc_all<1, false>", "k_ddmc_all<1, false, quad gather>"}, {"k_ddmc_all<1, true>", "k_ddmc_all<1, true, quad gather>"}},
+            {{"k_ddmc_all<2, false>", "k_ddmc_all<2, false, quad gather>"}, {"k_ddmc_all<2, true>", "k_ddmc_all<2, true, quad gather>"}},
+            {{"k_ddmc_all<3, false>", "k_ddmc_all<3, false, quad gather>"}, {"k_ddmc_all<3, true>", "k_ddmc_all<3, true, quad gather>"}}};
+        mesh->last_variant = names[NDIM - 1][tally ? 1 : 0][coop ? 1 : 0];
         if (tally) {
-          static int occ = 0;
-          if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, true>, kBlock, 0) != hipSuccess || occ < 1)) occ = 3;
-          const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
-          hipLaunchKernelGGL((k_ddmc_all<NDIM, true>), dim3(g), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, ctx->dp, S,
-                             t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
+          if (coop) JB_LAUNCH_DDMC_ALL(true, true);
+          else JB_LAUNCH_DDMC_ALL(true, false);
         } else {
-          static int occ = 0;
-          if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, false>, kBlock, 0) != hipSuccess || occ < 1)) occ = 3;
-          const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);
-          hipLaunchKernelGGL((k_ddmc_all<NDIM, false>), dim3(g), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, ctx->dp, S,
-                             t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);
+          if (coop) JB_LAUNCH_DDMC_ALL(false, true);
+          else JB_LAUNCH_DDMC_ALL(false, false);
         }
+#undef JB_LAUNCH_DDMC_ALL
         return JB_COMPLETE;
       }
       // A mix of IMC and DDMC cells, three launches: k_hybrid<.., PHASE 1> follows the photons in

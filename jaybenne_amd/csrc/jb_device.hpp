@@ -43,6 +43,7 @@ struct DevMesh {
   // in one 64-byte record
   double *const *ddmc_cell;
   const double *ddmc_base;  // ddmc_cell[b] = ddmc_base + 8 b ntot
+  double *ddmc_step;        // step records of k_ddmc_all's event loop (DdmcStepRec), same indexing
   // ... and one double per cell (block b at lam_hyb + b ntot) for the hybrid kernel: the cell's
   // scattering mean free path lam_sc, with the sign bit set when the cell takes DDMC steps
   // (dx_push (sigma_a + sigma_s) > tau_ddmc) -- a lane in an IMC cell gathers nothing else
@@ -138,7 +139,10 @@ __device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
 // The same from a copy of the per-block tables in LDS (kernels whose service phase would wait
 // for these small dependent loads behind its own stores: vector-memory operations complete in
 // issue order, LDS reads have their own counter).  Up to kLdsBlocks resident blocks.
-constexpr int kLdsBlocks = 128;
+#ifndef JB_LDS_BLOCKS
+#define JB_LDS_BLOCKS 128
+#endif
+constexpr int kLdsBlocks = JB_LDS_BLOCKS;
 struct LdsBlockTable {
   double xmin[kLdsBlocks][3], dx[kLdsBlocks][3], inv_dx[kLdsBlocks][3];
 #ifndef JB_NO_LDS_X0
@@ -212,13 +216,18 @@ __device__ __forceinline__ void load_block_lds(const DevMesh &M, const LdsBlockT
 
 // A uniform value in scalar registers of its own (see k_ddmc_all).
 __device__ __forceinline__ unsigned sgpr_copy(unsigned v) {
+  // (readfirstlane: a value loaded from memory may arrive in a vector register even though every
+  // lane holds the same; on a value that is already scalar it folds away)
   unsigned r;
-  asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(v));
+  asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"((unsigned)__builtin_amdgcn_readfirstlane((int)v)));
   return r;
 }
 __device__ __forceinline__ const double *sgpr_copy_ptr(const double *p) {
+  const unsigned long long q = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(q >> 32));
   unsigned long long r;
-  asm volatile("s_mov_b64 %0, %1" : "=s"(r) : "s"((unsigned long long)p));
+  asm volatile("s_mov_b64 %0, %1" : "=s"(r) : "s"(((unsigned long long)hi << 32) | lo));
   return (const double *)r;
 }
 

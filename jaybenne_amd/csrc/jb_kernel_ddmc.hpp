@@ -41,17 +41,55 @@ namespace jb {
 
 enum { DS_IDLE = 0, DS_VIRT = 1, DS_REAL = 2, DS_DONE = 3, DS_RELOC = 4 };
 
-template <int NDIM, bool TALLY>
+// the kernel's argument list as the kernel-argument segment holds it (natural alignment, in order)
+struct DdmcAllArgs {
+  const DevMesh *Mp;
+  DevParams P;
+  DevSwarm S;
+  double t_start, dt;
+  long long first, last;
+  unsigned long long *counters;
+  const int *not_all_ddmc;
+};
+// (a pointer read from memory instead of passed as a kernel argument: say that it is global memory,
+// or every access through it is a flat_ instruction)
+template <class T>
+__device__ __forceinline__ T *g1(T *p) {
+  return (T *)(__attribute__((address_space(1))) T *)p;
+}
+
+// quad_bcast_add<K>(v, add): v of lane K of the caller's quad (lanes 4q .. 4q+3), plus the caller's add
+template <int K>
+__device__ __forceinline__ unsigned quad_bcast_add(unsigned v, unsigned add) {
+  constexpr int ctrl = K * 0x55;  // quad_perm:[K, K, K, K]
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, ctrl, 0xf, 0xf, true) + add;
+}
+
+// COOP (the cell records of all resident blocks span < 4 GiB: jb_transport_photons_ddmc): the four
+// lanes of a quad fetch the four 16-byte pieces of ONE record with one LDS-direct load, instruction
+// k serving the record of quad-lane k -- the vector L1 then looks up one line per record instead of
+// four (one per 16-byte piece of every lane), which is what bounds the loop: 4 x 64 lookups per wave
+// pass x 12 waves per CU = the ~3000 cycles a round of passes takes.
+template <int NDIM, bool TALLY, bool COOP>
 #ifndef JB_DDMC_ALL_ATTR
 #define JB_DDMC_ALL_ATTR
 #endif
 __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_ALL_ATTR
-    k_ddmc_all(const DevMesh *__restrict__ Mp, DevParams P, DevSwarm S, double t_start, double dt,
-               long long first, long long last, unsigned long long *counters, const int *not_all_ddmc) {
-  if (*not_all_ddmc != 0) return;  // (uniform) some cell takes IMC steps: k_hybrid runs instead
-  // (the mesh view through a pointer to its copy in device memory: as a by-value argument its ~120
-  // dwords compete for the scalar registers, and parked scalars cost vector registers)
-  const DevMesh &M = *Mp;
+    k_ddmc_all(const DevMesh *__restrict__, DevParams, DevSwarm, double, double, long long, long long,
+               unsigned long long *, const int *) {
+  // The arguments are read where they are used, straight from the kernel-argument segment (scalar
+  // loads from constant memory), not through the parameters: those are fetched at kernel entry and
+  // then live in ~80 scalar registers across both loops -- the registers the loop's constants
+  // (logarithm coefficients, stream multipliers) then do not get, so that they sit in vector
+  // registers instead.  The mesh view (~120 dwords) is behind a pointer for the same reason.
+  const DdmcAllArgs &A = *(const DdmcAllArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+  if (*A.not_all_ddmc != 0) return;  // (uniform) some cell takes IMC steps: k_hybrid runs instead
+  const DevMesh &M = *A.Mp;
+  const DevParams &P = A.P;
+  const DevSwarm &S = A.S;
+  const double t_start = A.t_start, dt = A.dt;
+  const long long first = A.first, last = A.last;
+  unsigned long long *const counters = g1(A.counters);
   __shared__ double lds_tally[TALLY ? kLdsTally : 1];
   const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
   if constexpr (TALLY) {
@@ -59,6 +97,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) lds_tally[q] = 0.0;
   }
   __shared__ LdsBlockTable lds_blocks;
+  // [wave][quad-lane k][quad q]: the record of lane 4 q + k of the wave (LDS-direct loads deposit
+  // lane l's 16 bytes at base + 16 l: the four pieces of a quad's record land side by side)
+  __shared__ __attribute__((aligned(16))) char lds_rec[COOP ? kBlock / 64 : 1][COOP ? 4 : 1][COOP ? 1024 : 16];
   fill_block_table(M, lds_blocks);
   load_math_tables();  // (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2;
@@ -105,7 +146,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   // arrive in 16-dword groups, and a group the compiler parks in VGPR lanes comes back whole
   // (16 v_readlane per pass for one dword of it).
   const unsigned ntot_u = sgpr_copy((unsigned)M.ntot);
-  const double *rec_base = sgpr_copy_ptr(M.ddmc_base);
+  const double *rec_base = M.ddmc_base;                    // cell records (service phase: albedo step)
+  const double *step_base = sgpr_copy_ptr(M.ddmc_step);    // step records (event loop)
   const int l_ni = (int)sgpr_copy((unsigned)M.ni), l_nj = (int)sgpr_copy((unsigned)M.nj);
   const int l_is = (int)sgpr_copy((unsigned)M.is), l_ie = (int)sgpr_copy((unsigned)M.ie);
   const int l_js = (int)sgpr_copy((unsigned)M.js), l_je = (int)sgpr_copy((unsigned)M.je);
@@ -114,8 +156,13 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   auto on_block_l = [&](int i, int j, int k) {
     return i >= l_is && i <= l_ie && j >= l_js && j <= l_je && k >= l_ks && k <= l_ke;
   };
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  const unsigned sub16 = 16u * (unsigned)(lane & 3);
+  const v4d *my_rec = (const v4d *)&lds_rec[COOP ? threadIdx.x >> 6 : 0][COOP ? lane & 3 : 0][COOP ? 64 * (lane >> 2) : 0];
+  typedef __attribute__((address_space(3))) char *lchar;
+  lchar const wave_buf = (lchar)(unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned)(size_t)(lchar)&lds_rec[COOP ? threadIdx.x >> 6 : 0][0][0]);
   auto load_record = [&](Step &s, int blk, int q) {
-    typedef double v4d __attribute__((ext_vector_type(4)));
     typedef const v4d __attribute__((address_space(1))) *grec;
     // (library-owned, contiguous: no pointer-table load in front of the gather)
     // (one 32 x 32 -> 64-bit multiply-add: jb_mesh_create keeps ntot below 2^31)
@@ -211,7 +258,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           if (t < t_end) {
             enter(Bn);
             if (ls == DS_VIRT) {  // (the loop does not carry the direction: park it)
-              S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+              g1(S.vx)[n] = vx; g1(S.vy)[n] = vy; g1(S.vz)[n] = vz;
             }
           } else {
             ls = DS_DONE;
@@ -255,11 +302,11 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         const bool mine = ((need >> lane) & 1ull) != 0ull && rank < give;
         if (mine) {
           cand = chunk_pos + rank;
-          st_in = S.status[cand];
-          rng_in = S.rng[cand];
-          b_in = S.blk[cand];
-          t_in = S.t[cand]; x_in = S.x[cand]; y_in = S.y[cand]; z_in = S.z[cand];
-          vx_in = S.vx[cand]; vy_in = S.vy[cand]; vz_in = S.vz[cand];
+          st_in = g1(S.status)[cand];
+          rng_in = g1(S.rng)[cand];
+          b_in = g1(S.blk)[cand];
+          t_in = g1(S.t)[cand]; x_in = g1(S.x)[cand]; y_in = g1(S.y)[cand]; z_in = g1(S.z)[cand];
+          vx_in = g1(S.vx)[cand]; vy_in = g1(S.vy)[cand]; vz_in = g1(S.vz)[cand];
         }
         chunk_pos += give;
         need &= ~__ballot(mine);
@@ -306,21 +353,21 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           if constexpr (TALLY) {  // jaybenne.cpp:547-561
             const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
             // (the weight is read here, once per history, rather than carried through the event loop)
-            const double wgt = S.w[n];
+            const double wgt = g1(S.w)[n];
             if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
             else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], wgt / dv);
           }
         }
       }
-      S.blk[n] = b;
-      S.t[n] = t;
-      S.x[n] = x; S.y[n] = y; S.z[n] = z;
+      g1(S.blk)[n] = b;
+      g1(S.t)[n] = t;
+      g1(S.x)[n] = x; g1(S.y)[n] = y; g1(S.z)[n] = z;
       if (write_v) {
-        S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
+        g1(S.vx)[n] = vx; g1(S.vy)[n] = vy; g1(S.vz)[n] = vz;
       }
-      S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
-      S.status[n] = status;
-      S.rng[n] = rng.s;
+      g1(S.ip)[n] = ip; g1(S.jp)[n] = jp; g1(S.kp)[n] = kp;
+      g1(S.status)[n] = status;
+      g1(S.rng)[n] = rng.s;
       resample = false;
       ls = DS_IDLE;
     }
@@ -378,7 +425,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         ls = DS_RELOC;
       } else if (s.is_absorbed) {  // transport.cpp:157-163
         if (lds_blocks.owned[b] != 0) {
-          atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], S.w[n]);
+          atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], g1(S.w)[n]);
           status = ST_ABSORBED;
         } else {
           status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
@@ -412,21 +459,39 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     while (nrun >= thresh) {
       ++c_pass;
       c_ev += (unsigned int)nrun;
+      if constexpr (COOP) {
+        // (every lane takes part; one without a particle in the loop asks for record 0)
+        const unsigned off = ls == DS_VIRT ? ((unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip)) << 6 : 0u;
+        typedef const __attribute__((address_space(1))) void *gvoid;
+        __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<0>(off, sub16)), wave_buf, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<1>(off, sub16)), wave_buf + 1024, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<2>(off, sub16)), wave_buf + 2048, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<3>(off, sub16)), wave_buf + 3072, 16, 0, 0);
+      }
       if (ls == DS_VIRT) {
-        Step s;
-        s.t_start = t_start; s.dt = dt; s.vv = vv;
-        s.t = t;
-        s.ip = ip; s.jp = jp; s.kp = kp;
-        s.is_absorbed = false;
-        s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
-        // (faces and position feed nothing that is read below: the cell record holds the leak
-        // opacities P / dx, the step's position output is never formed)
-        s.xl = s.yl = s.zl = 0.0; s.xu = s.yu = s.zu = 1.0;
-        load_record(s, b, cidx_l(kp, jp, ip));
-        const bool census = ddmc_step_event<NDIM, true, true>(s, rng);
-        t = s.t;
-        ip = s.ip; jp = s.jp; kp = s.kp;  // = Xtoijk of the position the step gives (see header)
-        pend = s.pend; pz1 = s.pz1; pz2 = s.pz2;
+        DdmcStepRec r;
+        double nlog;
+        if constexpr (COOP) {
+          nlog = -m_log(rng.drand());          // (the step's first draw, while the record is on its way)
+          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the four pieces have landed
+          const v4d r0 = my_rec[0];
+          const v4d r1 = my_rec[1];
+          r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
+          r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
+        } else {
+          typedef const v4d __attribute__((address_space(1))) *grec;
+          const grec rec = (grec)((gcptr)step_base +
+                                  8 * ((unsigned long long)(unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip)));
+          const v4d r0 = rec[0];
+          const v4d r1 = rec[1];
+          nlog = -m_log(rng.drand());
+          r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
+          r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
+        }
+        bool is_absorbed = false;
+        const bool census = ddmc_step_rec<NDIM>(r, vv, t_end - t, nlog, rng, t, ip, jp, kp, pend, pz1, pz2,
+                                                is_absorbed);
+        // (ip, jp, kp = Xtoijk of the position the step gives: see the header)
         resample = census;
         if (!on_block_l(ip, jp, kp)) {
           // A leak through a block face (0.4 per history on BASELINE configs[2]).  Into a resident
@@ -452,9 +517,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           } else {
             ls = DS_RELOC;
           }
-        } else if (s.is_absorbed) {  // transport.cpp:157-163
+        } else if (is_absorbed) {  // transport.cpp:157-163
           if (lds_blocks.owned[b] != 0) {
-            atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], S.w[n]);
+            atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], g1(S.w)[n]);
             status = ST_ABSORBED;
           } else {
             status = ST_OUTGOING_ABSORBED;

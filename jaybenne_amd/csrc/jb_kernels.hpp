@@ -176,6 +176,17 @@ __global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P) {
     o[5] = multi_d ? M.P2[b][cidx(M, k, j + 1, i)] / dy : 0.0;
     o[6] = three_d ? M.P3[b][q] / dz : 0.0;
     o[7] = three_d ? M.P3[b][cidx(M, k + 1, j, i)] / dz : 0.0;
+    {  // the step record (DdmcStepRec, jb_physics.hpp): ddmc_step_event's per-step sums, formed here
+      double *r = M.ddmc_step + 8 * ((long long)b * M.ntot + q);
+      const double c2 = o[2] + o[3];
+      const double c3 = c2 + o[4];
+      const double c4 = c3 + o[5];
+      const double c5 = c4 + o[6];
+      const double leak_tot = c5 + o[7];
+      const double cdf_ddmc = o[0] + leak_tot + DBL_MIN;
+      r[0] = o[0]; r[1] = o[2]; r[2] = c2; r[3] = c3; r[4] = c4; r[5] = c5; r[6] = leak_tot;
+      r[7] = m_rcp_refined(P.c * cdf_ddmc);
+    }
   }
 }
 

@@ -414,8 +414,10 @@ __device__ __forceinline__ void materialise_dir(Step &s) {
 // s.pz1, s.pz2).  While a particle stays in DDMC cells its direction is never read -- the next
 // leak, the census resampling or a block crossing (zero-velocity flag) overwrites it -- so the
 // square roots and the sincos are evaluated only where a consumer appears (materialise_dir).
-template <int NDIM, bool LEAK_READY = false, bool LAZY = false, class Rng>
-__device__ __forceinline__ bool ddmc_step_event(Step &s, Rng &rng) {
+// PRELOG: the caller has made the step's first draw and passes -ln(u) in nlog (to have the
+// logarithm evaluated while the cell record is still on its way).
+template <int NDIM, bool LEAK_READY = false, bool LAZY = false, bool PRELOG = false, class Rng>
+__device__ __forceinline__ bool ddmc_step_event(Step &s, Rng &rng, double nlog = 0.0) {
   constexpr int multi_d = NDIM >= 2 ? 1 : 0, three_d = NDIM == 3 ? 1 : 0;
   const double rmin = DBL_MIN;
   const double eps = kEpsDdmc;
@@ -434,7 +436,8 @@ __device__ __forceinline__ bool ddmc_step_event(Step &s, Rng &rng) {
   const double cdf_ddmc = s.ffaa + leak_tot + rmin;
   // (-ln u in [1e-16, 37], c cdf in [c DBL_MIN, ~1e30]: inside the range where the lean division
   // sequence of jb_math.hpp gives the IEEE quotient -- no scaling or fix-up step needed)
-  const double dt_ddmc = m_div(-m_log(rng.drand()), s.vv * cdf_ddmc);
+  if constexpr (!PRELOG) nlog = -m_log(rng.drand());
+  const double dt_ddmc = m_div(nlog, s.vv * cdf_ddmc);
   const double dt_end = (s.t_start + s.dt) - s.t;
   const bool is_ddmc_event = dt_ddmc < dt_end;
 
@@ -474,6 +477,55 @@ __device__ __forceinline__ bool ddmc_step_event(Step &s, Rng &rng) {
           sample_face_iso_dir(up ? s.vv : -s.vv, rng, v1, v2, v3);
           assign_cyclic(axis, v1, v2, v3, s.vx, s.vy, s.vz);
         }
+      }
+    }
+  }
+  return !is_ddmc_event;
+}
+
+// The same step for a particle in the virtual state (k_ddmc_all's event loop: LEAK_READY, LAZY,
+// position never formed), reading the cell's STEP record: what ddmc_step_event derives from the
+// cell record on every step -- the running sums of the leak opacities it compares the channel
+// draw against, their total, and the refined reciprocal of c (f sigma_a + leak_tot + DBL_MIN) its
+// division starts from -- formed once per cell and cycle by k_ddmc_pack, by the same operations
+// on the same operands in the same order (transport_utils.hpp:175-254).  Saves the loop 5 of 7
+// dependent additions and 5 of the 8 instructions of the division, right behind the gather.
+//   rec = {f sigma_a, c1 .. c5, leak_tot, rcp}
+struct DdmcStepRec {
+  double ffaa, c1, c2, c3, c4, c5, leak_tot, rcp;
+};
+template <int NDIM, class Rng>
+__device__ __forceinline__ bool ddmc_step_rec(const DdmcStepRec &r, double vv, double dt_end, double nlog,
+                                              Rng &rng, double &t, int &ip, int &jp, int &kp, int &pend,
+                                              double &pz1, double &pz2, bool &is_absorbed) {
+  constexpr int multi_d = NDIM >= 2 ? 1 : 0, three_d = NDIM == 3 ? 1 : 0;
+  const double a2 = r.ffaa + r.leak_tot;
+  const double cdf_ddmc = a2 + DBL_MIN;
+  const double dt_ddmc = m_div_r(nlog, vv * cdf_ddmc, r.rcp);
+  const bool is_ddmc_event = dt_ddmc < dt_end;
+  t += dmin(dt_ddmc, dt_end);
+  if (is_ddmc_event) {
+    const double xi = cdf_ddmc * rng.drand();
+    if (xi < r.ffaa) {
+      is_absorbed = true;
+    } else if (xi < a2) {
+      const double xim = xi - r.ffaa;
+      // the first threshold above xim, as the chain of transport_utils.hpp:218-254 finds it
+      int ch = (xim <= r.leak_tot) ? 5 : -1;
+      ch = (xim < r.c5) ? 4 : ch;
+      ch = (xim < r.c4) ? 3 : ch;
+      ch = (xim < r.c3) ? 2 : ch;
+      ch = (xim < r.c2) ? 1 : ch;
+      ch = (xim < r.c1) ? 0 : ch;
+      if (ch >= 0) {
+        const int axis = ch >> 1;
+        const int step = (ch & 1) != 0 ? 1 : -1;
+        ip += (axis == 0) ? step : 0;
+        jp += (axis == 1) ? step * multi_d : 0;
+        kp += (axis == 2) ? step * three_d : 0;
+        pz1 = rng.drand();
+        pz2 = rng.drand();
+        pend = ch;
       }
     }
   }

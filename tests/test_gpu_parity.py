@@ -324,6 +324,26 @@ def test_general_kernel_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, 
     assert drv.md.events == O.events
 
 
+@pytest.mark.parametrize("deck,overrides,cycles", [c for c in CASES if c[0].endswith("_ddmc")])
+def test_quad_cooperative_gather_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, monkeypatch):
+    """k_ddmc_all fetches its step records either with four loads per lane or, once the records of
+    the resident blocks exceed 1 MiB (BASELINE configs[2] in 3-D: 160 MB), with the four lanes of a
+    quad sharing the fetch of each record through LDS.  The test decks are far below that size:
+    force the second form on them -- same bits."""
+    from oracle import orc
+    monkeypatch.setenv("JB_COOP_GATHER", "1")
+    pin = load_deck(deck, overrides)
+    drv = _gpu_problem(pin, gpu_device)
+    O, mesh, _ = make_oracle(load_deck(deck, overrides), orc.MATH_PORTABLE)
+    for _ in range(cycles):
+        drv.Step()
+    run_oracle_cycles(O, pin, cycles)
+    assert "quad gather" in drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
+    _compare_swarm(drv.md, O)
+    _compare_fields(drv.md, O)
+    assert drv.md.events == O.events
+
+
 def test_all_ddmc_mesh_runs_the_lean_kernel(gpu_device):
     for deck, want in (("stepdiff_ddmc", "k_ddmc_all<1"), ("stepdiff_smr_hybrid", "k_hybrid<2"),
                        ("stepdiff_smr_ddmc", "k_ddmc_all<2"), ("stepdiff", "k_transport<1")):
