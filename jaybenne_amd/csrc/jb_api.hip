@@ -690,13 +690,35 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         const unsigned long long rec_bytes = 64ull * (unsigned long long)M.ntot * (unsigned long long)M.nblocks;
         const bool coop = rec_bytes < (1ull << 32) &&
                           (ctx->coop_gather >= 0 ? ctx->coop_gather == 1 : rec_bytes >= (1ull << 20));
+        // A particle that sits at a face of its cell when it is loaded or relocated (one in ~1e8) needs
+        // the albedo step: k_ddmc_all lists it, and k_hybrid<.., both loops>, launched behind it on
+        // that list (its length read on the device: no synchronisation), tracks it to the end.
+        {
+          const jb_status st_s = ensure_scratch(ctx, (size_t)(last - first) / 2 + 16);
+          if (st_s != JB_COMPLETE) return st_s;
+        }
+        unsigned *handed = (unsigned *)ctx->scratch_d;
+        unsigned long long *n_handed = ctx->counters_d + kCursorBase;
+        // (dynamic shared memory: the tally of a mesh with <= kLdsTally cells, resident blocks' ghosts included)
+        const size_t lds_tally_bytes =
+            tally && (long long)M.nblocks * M.ntot <= (long long)kLdsTally ? sizeof(double) * kLdsTally : 0;
+        (void)hipMemsetAsync(n_handed, 0, sizeof(unsigned long long), ctx->stream);
 #define JB_LAUNCH_DDMC_ALL(TL, CO)                                                                          \
   do {                                                                                                      \
-    static int occ = 0;                                                                                     \
-    if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ddmc_all<NDIM, TL, CO>, kBlock, 0) != hipSuccess || occ < 1)) occ = 3; \
-    const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                           \
-    hipLaunchKernelGGL((k_ddmc_all<NDIM, TL, CO>), dim3(g), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, ctx->dp, S, \
-                       t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc);             \
+    static int occ[2] = {0, 0};  /* without / with the LDS tally */                                         \
+    int &oc = occ[lds_tally_bytes ? 1 : 0];                                                                 \
+    if (oc < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, k_ddmc_all<NDIM, TL, CO>, kBlock, lds_tally_bytes) != hipSuccess || oc < 1)) oc = 3; \
+    const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : oc);                            \
+    hipLaunchKernelGGL((k_ddmc_all<NDIM, TL, CO>), dim3(g), dim3(kBlock), lds_tally_bytes, ctx->stream, mesh->dm_dev, ctx->dp, S, \
+                       t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc, handed, n_handed); \
+  } while (0)
+#define JB_LAUNCH_HANDED(TL, NA)                                                                            \
+  do {                                                                                                      \
+    (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream); \
+    hipLaunchKernelGGL((k_hybrid<NDIM, TL, NA, 0, 0>), dim3(kQueues), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, \
+                       ctx->dp, S, t_start, dt, 0ll, (long long)(last - first), ctx->counters_d,            \
+                       (const unsigned *)handed, (unsigned *)nullptr, (unsigned long long *)nullptr,         \
+                       (const unsigned long long *)n_handed);                                               \
   } while (0)
         static const char *const names[3][2][2] = {
             {{"k_ddmc_all<1, false>", "k_ddmc_all<1, false, quad gather>"}, {"k_ddmc_all<1, true>", "k_ddmc_all<1, true, quad gather>"}},
@@ -706,10 +728,15 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         if (tally) {
           if (coop) JB_LAUNCH_DDMC_ALL(true, true);
           else JB_LAUNCH_DDMC_ALL(true, false);
+          if (noabs_h) JB_LAUNCH_HANDED(true, true);
+          else JB_LAUNCH_HANDED(true, false);
         } else {
           if (coop) JB_LAUNCH_DDMC_ALL(false, true);
           else JB_LAUNCH_DDMC_ALL(false, false);
+          if (noabs_h) JB_LAUNCH_HANDED(false, true);
+          else JB_LAUNCH_HANDED(false, false);
         }
+#undef JB_LAUNCH_HANDED
 #undef JB_LAUNCH_DDMC_ALL
         return JB_COMPLETE;
       }
@@ -741,7 +768,8 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
     (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream); \
     hipLaunchKernelGGL((k_hybrid<NDIM, T, NA, MD, PH>), dim3(g), dim3(kBlock), 0, ctx->stream,     \
                        mesh->dm_dev, ctx->dp, S, t_start, dt, (long long)(F), (long long)(L), ctx->counters_d,   \
-                       (const unsigned *)(LIN), (unsigned *)(LOUT), (unsigned long long *)(COUT)); \
+                       (const unsigned *)(LIN), (unsigned *)(LOUT), (unsigned long long *)(COUT),  \
+                       (const unsigned long long *)nullptr);                                       \
   } while (0)
 #define JB_PHASE1(T, NA, F, L, LIN)                                                                \
   do {                                                                                             \

@@ -143,25 +143,29 @@ __device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
 #define JB_LDS_BLOCKS 128
 #endif
 constexpr int kLdsBlocks = JB_LDS_BLOCKS;
-struct LdsBlockTable {
+// (X0: also the coordinate of cell index 0, xmin - first dx, per block and axis -- 3 KB that
+// k_ddmc_all, which needs the room for a fourth workgroup per CU, forms where it reads it)
+template <bool X0>
+struct LdsBlockTableT {
+  static constexpr bool has_x0 = X0;
   double xmin[kLdsBlocks][3], dx[kLdsBlocks][3], inv_dx[kLdsBlocks][3];
-#ifndef JB_NO_LDS_X0
-  double x0[kLdsBlocks][3];  // coordinate of cell index 0: xmin - first * dx
-#endif
+  double x0[X0 ? kLdsBlocks : 1][3];
   double *tally[kLdsBlocks];
   int owned[kLdsBlocks];
   int nbr_ent[kLdsBlocks][6];
 };
-__device__ __forceinline__ void fill_block_table(const DevMesh &M, LdsBlockTable &T) {
+using LdsBlockTable = LdsBlockTableT<true>;
+template <class Tab>
+__device__ __forceinline__ void fill_block_table(const DevMesh &M, Tab &T) {
   if (M.nblocks > kLdsBlocks) return;
   for (int q = threadIdx.x; q < 3 * M.nblocks; q += blockDim.x) {
     (&T.xmin[0][0])[q] = M.blk_xmin[q];
     (&T.dx[0][0])[q] = M.blk_dx[q];
     (&T.inv_dx[0][0])[q] = M.blk_inv_dx[q];
-#ifndef JB_NO_LDS_X0
-    const int first = (q % 3 == 0) ? M.is : (q % 3 == 1 ? M.js : M.ks);
-    (&T.x0[0][0])[q] = M.blk_xmin[q] - (double)first * M.blk_dx[q];
-#endif
+    if constexpr (Tab::has_x0) {
+      const int first = (q % 3 == 0) ? M.is : (q % 3 == 1 ? M.js : M.ks);
+      (&T.x0[0][0])[q] = M.blk_xmin[q] - (double)first * M.blk_dx[q];
+    }
   }
   for (int q = threadIdx.x; q < M.nblocks; q += blockDim.x) {
     T.tally[q] = M.tally[q];
@@ -169,24 +173,29 @@ __device__ __forceinline__ void fill_block_table(const DevMesh &M, LdsBlockTable
   }
   for (int q = threadIdx.x; q < 6 * M.nblocks; q += blockDim.x) (&T.nbr_ent[0][0])[q] = M.nbr_ent[q];
 }
-__device__ __forceinline__ double lds_x0(const DevMesh &M, const LdsBlockTable &T, int b, int d) {
-#ifndef JB_NO_LDS_X0
-  return T.x0[b][d];
-#else
-  const int first = d == 0 ? M.is : (d == 1 ? M.js : M.ks);
-  return T.xmin[b][d] - (double)first * T.dx[b][d];
-#endif
+template <class Tab>
+__device__ __forceinline__ double lds_x0(const DevMesh &M, const Tab &T, int b, int d) {
+  if constexpr (Tab::has_x0) {
+    return T.x0[b][d];
+  } else {
+    const int first = d == 0 ? M.is : (d == 1 ? M.js : M.ks);
+    return T.xmin[b][d] - (double)first * T.dx[b][d];
+  }
 }
-__device__ __forceinline__ int block_nbr_ent(const DevMesh &M, const LdsBlockTable &T, int b, int face) {
+template <class Tab>
+__device__ __forceinline__ int block_nbr_ent(const DevMesh &M, const Tab &T, int b, int face) {
   return M.nblocks > kLdsBlocks ? ((gcptr_i)M.nbr_ent)[6 * b + face] : T.nbr_ent[b][face];
 }
-__device__ __forceinline__ bool block_owned(const DevMesh &M, const LdsBlockTable &T, int b) {
+template <class Tab>
+__device__ __forceinline__ bool block_owned(const DevMesh &M, const Tab &T, int b) {
   return (M.nblocks > kLdsBlocks ? M.owned[b] : T.owned[b]) != 0;
 }
-__device__ __forceinline__ double *block_tally(const DevMesh &M, const LdsBlockTable &T, int b) {
+template <class Tab>
+__device__ __forceinline__ double *block_tally(const DevMesh &M, const Tab &T, int b) {
   return M.nblocks > kLdsBlocks ? M.tally[b] : T.tally[b];
 }
-__device__ __forceinline__ void load_block(const DevMesh &M, const LdsBlockTable &T, int b, Blk &B) {
+template <class Tab>
+__device__ __forceinline__ void load_block(const DevMesh &M, const Tab &T, int b, Blk &B) {
   if (M.nblocks > kLdsBlocks) {  // (uniform)
     load_block(M, b, B);
     return;
@@ -203,7 +212,8 @@ __device__ __forceinline__ void load_block(const DevMesh &M, const LdsBlockTable
 
 // ... and without the fallback to the global tables (k_ddmc_all: the host only launches it when
 // the resident blocks fit the LDS table)
-__device__ __forceinline__ void load_block_lds(const DevMesh &M, const LdsBlockTable &T, int b, Blk &B) {
+template <class Tab>
+__device__ __forceinline__ void load_block_lds(const DevMesh &M, const Tab &T, int b, Blk &B) {
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     B.xmin[d] = T.xmin[b][d];

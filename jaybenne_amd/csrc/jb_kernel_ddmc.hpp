@@ -17,7 +17,10 @@
 // It loads a particle and evaluates the albedo step's six face tests on its real position: if
 // none holds (a particle lies within 5.5e-9 dx of a face of its cell once in ~1e8) the step
 // starts from the cell centre like every other and the lane goes straight to the loop; otherwise
-// that step is taken there and then with the general step functions.  A direction that no step
+// the particle is handed over: its slot goes on a list that k_hybrid -- which has the general
+// step functions, albedo step included -- works through right after this kernel (until round 3
+// that step was taken here: code that ran for a handful of particles per launch and set the
+// kernel's register count, 137 instead of 116).  A direction that no step
 // has changed is not carried either: it stays where it was loaded from (S.vx, vy, vz).  Position
 // and direction are rebuilt from the virtual state where a consumer appears (block crossing,
 // census resampling, absorption, write-back).  Same draws, same
@@ -30,7 +33,7 @@
 namespace jb {
 
 #ifndef JB_DDMC_ALL_WAVES_PER_SIMD
-#define JB_DDMC_ALL_WAVES_PER_SIMD 3
+#define JB_DDMC_ALL_WAVES_PER_SIMD 4   // (128 registers; 39 KB of LDS per workgroup without the LDS tally)
 #endif
 #ifndef JB_DDMC_ALL_BUDGET   // idle lane-passes that buy a service phase
 #define JB_DDMC_ALL_BUDGET 256
@@ -39,7 +42,7 @@ namespace jb {
 #define JB_DDMC_ALL_CHUNK 128
 #endif
 
-enum { DS_IDLE = 0, DS_VIRT = 1, DS_REAL = 2, DS_DONE = 3, DS_RELOC = 4 };
+enum { DS_IDLE = 0, DS_VIRT = 1, DS_PARK = 2, DS_DONE = 3, DS_RELOC = 4 };
 
 // the kernel's argument list as the kernel-argument segment holds it (natural alignment, in order)
 struct DdmcAllArgs {
@@ -50,6 +53,8 @@ struct DdmcAllArgs {
   long long first, last;
   unsigned long long *counters;
   const int *not_all_ddmc;
+  unsigned *park_list;              // slots handed over to k_hybrid ...
+  unsigned long long *park_count;   // ... and how many
 };
 // (a pointer read from memory instead of passed as a kernel argument: say that it is global memory,
 // or every access through it is a flat_ instruction)
@@ -76,7 +81,7 @@ template <int NDIM, bool TALLY, bool COOP>
 #endif
 __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_ALL_ATTR
     k_ddmc_all(const DevMesh *__restrict__, DevParams, DevSwarm, double, double, long long, long long,
-               unsigned long long *, const int *) {
+               unsigned long long *, const int *, unsigned *, unsigned long long *) {
   // The arguments are read where they are used, straight from the kernel-argument segment (scalar
   // loads from constant memory), not through the parameters: those are fetched at kernel entry and
   // then live in ~80 scalar registers across both loops -- the registers the loop's constants
@@ -90,18 +95,20 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   const double t_start = A.t_start, dt = A.dt;
   const long long first = A.first, last = A.last;
   unsigned long long *const counters = g1(A.counters);
-  __shared__ double lds_tally[TALLY ? kLdsTally : 1];
+  // (the LDS tally of a small mesh -- all resident blocks' cells, <= kLdsTally -- is dynamic shared
+  // memory: a mesh that does not use it leaves the room to a fourth workgroup per CU)
+  extern __shared__ double lds_tally[];
   const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
   if constexpr (TALLY) {
     if (tally_in_lds)
       for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) lds_tally[q] = 0.0;
   }
-  __shared__ LdsBlockTable lds_blocks;
+  __shared__ LdsBlockTableT<false> lds_blocks;
   // [wave][quad-lane k][quad q]: the record of lane 4 q + k of the wave (LDS-direct loads deposit
   // lane l's 16 bytes at base + 16 l: the four pieces of a quad's record land side by side)
   __shared__ __attribute__((aligned(16))) char lds_rec[COOP ? kBlock / 64 : 1][COOP ? 4 : 1][COOP ? 1024 : 16];
   fill_block_table(M, lds_blocks);
-  load_math_tables();  // (ends with a barrier)
+  load_math_tables<true, false, false, true>();  // logarithm, sincos of 2 pi u (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2;
   constexpr int kBudget = JB_DDMC_ALL_BUDGET;
   constexpr long long kChunk = JB_DDMC_ALL_CHUNK;
@@ -132,6 +139,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   int pend = -1;
   double pz1 = 0.0, pz2 = 0.0;
   bool resample = false;  // reached census in a DDMC step: position / direction to be resampled
+  bool fresh = false;     // loaded and not touched since: handing it over needs no write-back
   // ---- state that exists only between two points of one service phase
   int status = ST_ACTIVE;
   double x = 0.0, y = 0.0, z = 0.0, vx = 0.0, vy = 0.0, vz = 0.0;
@@ -181,7 +189,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     faces_of(s, Bq, ip, jp, kp);
     s.x = x; s.y = y; s.z = z;
     if (at_cell_face<NDIM>(s)) {
-      ls = DS_REAL;
+      ls = DS_PARK;
     } else {
       real_pos = false;
       ls = DS_VIRT;
@@ -206,6 +214,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
 #endif
     // -- 1. block crossings: the comm phase of the reference for one particle in flight
     if (ls == DS_RELOC) {
+      fresh = false;
       Blk Bo;
       load_block_lds(M, lds_blocks, b, Bo);
       Step s;
@@ -391,6 +400,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       resample = false;
       pend = -1;
       real_pos = true;
+      fresh = true;
       Blk Bn;
       load_block_lds(M, lds_blocks, b, Bn);
       xtoijk<NDIM>(M, Bn, x, y, z, ip, jp, kp);  // transport.cpp:96
@@ -398,51 +408,29 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       else ls = DS_DONE;  // already at census: nothing to track
     }
     JB_PH(3)
-    // -- 4. one step with the real position (first step after a load or a block crossing, and
-    //       the steps after an albedo rejection): the general step functions
-    c_ev += (unsigned)__popcll(__ballot(ls == DS_REAL));
-    if (ls == DS_REAL) {
-      Blk Br;
-      load_block_lds(M, lds_blocks, b, Br);
-      Step s;
-      s.t_start = t_start; s.dt = dt; s.vv = vv; s.rvv = P.rc; s.dx_push = Br.dx_push;
-      faces_of(s, Br, ip, jp, kp);
-      s.t = t; s.x = x; s.y = y; s.z = z; s.vx = vx; s.vy = vy; s.vz = vz;
-      s.ip = ip; s.jp = jp; s.kp = kp;
-      s.is_absorbed = false; s.is_scattered = false; s.is_rejected = false;
-      s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
-      load_record(s, b, cidx_l(kp, jp, ip));
-      ptcl_ddmc_albedo<NDIM, true>(s, rng);
-      bool census = false;
-      if (!s.is_rejected) census = ddmc_step_event<NDIM, true, true>(s, rng);
-      t = s.t; x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
-      pend = s.pend; pz1 = s.pz1; pz2 = s.pz2;
-      xtoijk<NDIM>(M, Br, x, y, z, ip, jp, kp);  // transport.cpp:146
-      if (!s.is_rejected) resample = census;  // (as k_transport: the flag of the last step)
-      real_pos = true;
-      if (!on_block_l(ip, jp, kp)) {
-        // (a rejected particle keeps its direction: pend < 0; a leak is flagged in step 1)
-        ls = DS_RELOC;
-      } else if (s.is_absorbed) {  // transport.cpp:157-163
-        if (lds_blocks.owned[b] != 0) {
-          atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], g1(S.w)[n]);
-          status = ST_ABSORBED;
-        } else {
-          status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
-        }
-        ls = DS_DONE;
-      } else if (!(t < t_end)) {  // census
-        ls = DS_DONE;
-      } else if (!s.is_rejected) {
-        real_pos = false;  // leaked into a neighbouring cell of this block: virtual from here on
-        ls = DS_VIRT;
-      }  // (else: rejected at a face, still a real position next to it: another step here)
+    // -- 4. a particle that sits at a face of its cell (just loaded, or just relocated): handed
+    //       over to k_hybrid as it stands
+    if (ls == DS_PARK) {
+      if (!fresh) {
+        g1(S.blk)[n] = b;
+        g1(S.t)[n] = t;
+        g1(S.x)[n] = x; g1(S.y)[n] = y; g1(S.z)[n] = z;
+        g1(S.vx)[n] = vx; g1(S.vy)[n] = vy; g1(S.vz)[n] = vz;
+        g1(S.rng)[n] = rng.s;
+      }
+      const unsigned long long pm = __ballot(true);
+      const int leader = __ffsll((long long)pm) - 1;
+      unsigned long long base = 0ull;
+      if (lane == leader) base = atomicAdd(g1(A.park_count), (unsigned long long)__popcll(pm));
+      base = __shfl(base, leader, 64);
+      g1(A.park_list)[base + (unsigned long long)__popcll(pm & ((1ull << lane) - 1ull))] = (unsigned)n;
+      ls = DS_IDLE;
     }
     JB_PH(4)
     // Lanes that still hold a real position (a step at a face, a general relocation, a particle
     // to write back) are served before the loop is entered again: position and direction are
     // then dead across the event loop and cost it no registers.
-    if (__ballot(ls == DS_REAL || ls == DS_DONE || ls == DS_RELOC) != 0ull) continue;
+    if (__ballot(ls == DS_DONE || ls == DS_RELOC) != 0ull) continue;
     const int running = __popcll(__ballot(ls == DS_VIRT));
     if (running == 0) {
       if (more) continue;

@@ -74,8 +74,15 @@ template <int NDIM, bool TALLY, bool NOABS, int MODE, int PHASE>
 __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 0 && (NDIM == 3 || !NOABS)) ||
                                            (PHASE == 1 && NDIM == 3 && !NOABS)) ? 2 : JB_HYBRID_WAVES_PER_SIMD)
     k_hybrid(const DevMesh *__restrict__ Mp, DevParams P, DevSwarm S, double t_start, double dt,
-             long long first, long long last, unsigned long long *counters, const unsigned *list_in,
-             unsigned *park_list, unsigned long long *park_count) {
+             long long first, long long last_arg, unsigned long long *counters, const unsigned *list_in,
+             unsigned *park_list, unsigned long long *park_count, const unsigned long long *list_count) {
+  // (list_count: the length of list_in where only the device knows it -- the photons k_ddmc_all
+  // hands over -- ; the launch then names the list's capacity)
+  long long last = last_arg;
+  if (list_count != nullptr) {
+    const long long have = first + (long long)*list_count;
+    last = have < last ? have : last;
+  }
   // (the mesh view is read through a pointer to its copy in device memory: as a by-value argument
   // its ~120 dwords compete for the scalar registers with everything else that is uniform here)
   const DevMesh &M = *Mp;

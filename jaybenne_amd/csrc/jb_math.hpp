@@ -68,18 +68,25 @@ __shared__ double lds_log2_tab[JB_LOG_N][2];  // {1/c, log c as one double}: the
 __shared__ double lds_sc_tab[JB_SC_N + 1][2];
 __shared__ double lds_sc2_tab[JB_SC2_N + 1][2];
 
-// Copies the three tables into this workgroup's LDS (8.2 KB); ends with a barrier.
+// Copies the tables into this workgroup's LDS (11.2 KB; a kernel that names the ones it reads
+// -- logarithm, lean logarithm, sincos, sincos of 2 pi u -- gets only those allocated); ends with a
+// barrier.
+template <bool LOG = true, bool LOG2 = true, bool SC = true, bool SC2 = true>
 __device__ __forceinline__ void load_math_tables() {
-  for (int q = threadIdx.x; q < JB_LOG_N * 3; q += blockDim.x)
-    lds_log_tab[q / 3][q % 3] = (&jb_log_tab[0][0])[q];
-  for (int q = threadIdx.x; q < JB_LOG_N; q += blockDim.x) {
-    lds_log2_tab[q][0] = jb_log_tab[q][0];
-    lds_log2_tab[q][1] = jb_log_tab[q][1] + jb_log_tab[q][2];
-  }
-  for (int q = threadIdx.x; q < (JB_SC_N + 1) * 2; q += blockDim.x)
-    (&lds_sc_tab[0][0])[q] = (&jb_sc_tab[0][0])[q];
-  for (int q = threadIdx.x; q < (JB_SC2_N + 1) * 2; q += blockDim.x)
-    (&lds_sc2_tab[0][0])[q] = (&jb_sc2_tab[0][0])[q];
+  if constexpr (LOG)
+    for (int q = threadIdx.x; q < JB_LOG_N * 3; q += blockDim.x)
+      lds_log_tab[q / 3][q % 3] = (&jb_log_tab[0][0])[q];
+  if constexpr (LOG2)
+    for (int q = threadIdx.x; q < JB_LOG_N; q += blockDim.x) {
+      lds_log2_tab[q][0] = jb_log_tab[q][0];
+      lds_log2_tab[q][1] = jb_log_tab[q][1] + jb_log_tab[q][2];
+    }
+  if constexpr (SC)
+    for (int q = threadIdx.x; q < (JB_SC_N + 1) * 2; q += blockDim.x)
+      (&lds_sc_tab[0][0])[q] = (&jb_sc_tab[0][0])[q];
+  if constexpr (SC2)
+    for (int q = threadIdx.x; q < (JB_SC2_N + 1) * 2; q += blockDim.x)
+      (&lds_sc2_tab[0][0])[q] = (&jb_sc2_tab[0][0])[q];
   __syncthreads();
 }
 

@@ -158,8 +158,9 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         "IMC, 3-D, exact geometry, exact arithmetic": "k_transportILi3ELb0ELb1ELi2ELb1ELb0E",
         "IMC, 2-D, exact geometry, lean arithmetic (configs[3])": "k_transportILi2ELb0ELb1ELi2ELb1ELb1E",
         "IMC, 1-D, exact geometry, lean arithmetic (configs[0])": "k_transportILi1ELb0ELb1ELi2ELb1ELb1E",
-        "all-DDMC, 3-D (configs[2])": "k_ddmc_allILi3ELb1E",
-        "all-DDMC, 1-D": "k_ddmc_allILi1ELb1E",
+        "all-DDMC, 3-D, quad-cooperative gather (configs[2])": "k_ddmc_allILi3ELb1ELb1E",
+        "all-DDMC, 3-D, small mesh": "k_ddmc_allILi3ELb1ELb0E",
+        "all-DDMC, 1-D": "k_ddmc_allILi1ELb1ELb0E",
         "hybrid, 2-D, IMC phase, lean on exact geometry (configs[4])": "k_hybridILi2ELb1ELb1ELi2ELi1E",
         "hybrid, 2-D, DDMC phase (configs[4])": "k_hybridILi2ELb1ELb1ELi0ELi2E",
         "hybrid, 3-D, IMC phase, lean on exact geometry": "k_hybridILi3ELb1ELb1ELi2ELi1E",
@@ -171,6 +172,14 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         vgpr, scratch = found[names[0]]
         assert vgpr <= 168, f"{what}: {vgpr} vector registers (> 168: two waves per SIMD)"
         assert scratch == 0, f"{what}: {scratch} bytes of scratch per lane (register spills)"
+    # the all-DDMC kernel is bound by the latency of its gathers and runs FOUR waves per SIMD:
+    # 128 registers, and at most 40 KB of LDS per workgroup (its LDS tally is dynamic shared memory)
+    ddmc = {n: v for n, v in found.items() if "k_ddmc_all" in n}
+    assert len(ddmc) == 12
+    for n, (vgpr, scratch) in ddmc.items():
+        assert vgpr <= 128 and scratch == 0, (n, vgpr, scratch)
+        lds = int(re.search(r"\.amdhsa_kernel %s.*?\.amdhsa_group_segment_fixed_size (\d+)" % re.escape(n), text, re.S).group(1))
+        assert lds <= 40960, (n, lds)
     # no launch of the hybrid IMC/DDMC path touches scratch memory (the remainder kernel, PHASE 0,
     # and the exact / absorbing 3-D variants of the IMC phase take two waves per SIMD instead)
     hybrid = {n: v for n, v in found.items() if "k_hybrid" in n}

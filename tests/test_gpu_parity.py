@@ -344,6 +344,53 @@ def test_quad_cooperative_gather_on_all_ddmc_meshes(gpu_device, deck, overrides,
     assert drv.md.events == O.events
 
 
+@pytest.mark.parametrize("coop", ["0", "1"])
+def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel(gpu_device, coop, monkeypatch):
+    """k_ddmc_all's event loop starts every step from the cell centre, which is what the albedo
+    step leaves behind unless the photon sits within 2.5 eps_imc dx of a face of its cell
+    (transport_utils.hpp:288-389; one sourced photon in ~1e8 does).  Those photons are listed and
+    tracked by k_hybrid, launched behind k_ddmc_all on that list.  Here every tenth photon of a 3-D
+    all-DDMC deck is put onto a face of its cell (lower or upper, x, y or z, inside the tolerance on
+    either side of it) before the first cycle -- in the oracle's swarm too -- and all must come
+    out bit-identical: accepted ones continue from the cell centre, rejected ones bounce back
+    into the neighbouring cell."""
+    import torch
+    from oracle import orc
+    monkeypatch.setenv("JB_COOP_GATHER", coop)
+    deck, ov, _ = [c for c in CASES if c[0] == "stepdiff_ddmc" and "parthenon/mesh/nx3" in c[1]][0]
+    pin = load_deck(deck, ov)
+    drv = _gpu_problem(pin, gpu_device)
+    O, mesh, _ = make_oracle(load_deck(deck, ov), orc.MATH_PORTABLE)
+    n = O.n
+    assert n == drv.md.n
+    sel = np.arange(0, n, 10)
+    tol = 2.5 * 1.0e6 * 2.220446049250313e-16
+    moved = 0
+    for k, q in enumerate(sel):
+        b = int(O.sw["blk"][q])
+        axis, upper = k % 3, (k // 3) % 2
+        name = "xyz"[axis]
+        dx = mesh.blk_dx[b, axis]
+        cell = np.floor((O.sw[name][q] - mesh.blk_xmin[b, axis]) / dx)
+        face = mesh.blk_xmin[b, axis] + (cell + upper) * dx
+        # inside the cell by a fraction of the tolerance (so that Xtoijk still finds this cell)
+        pos = face + (-1.0 if upper else 1.0) * 0.25 * tol * dx * ((k % 4) + 0.5) / 4.0
+        if np.floor((pos - mesh.blk_xmin[b, axis]) / dx) != cell:
+            continue
+        O.sw[name][q] = pos
+        moved += 1
+    assert moved > 0.9 * len(sel)
+    for name in "xyz":
+        drv.md.swarm[name][:n] = torch.from_numpy(O.sw[name][:n].copy()).to(drv.md.swarm[name].device)
+    for _ in range(2):
+        drv.Step()
+    run_oracle_cycles(O, pin, 2)
+    assert "k_ddmc_all<3" in drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
+    _compare_swarm(drv.md, O)
+    _compare_fields(drv.md, O)
+    assert drv.md.events == O.events
+
+
 def test_all_ddmc_mesh_runs_the_lean_kernel(gpu_device):
     for deck, want in (("stepdiff_ddmc", "k_ddmc_all<1"), ("stepdiff_smr_hybrid", "k_hybrid<2"),
                        ("stepdiff_smr_ddmc", "k_ddmc_all<2"), ("stepdiff", "k_transport<1")):

@@ -1,0 +1,6 @@
+set -e
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -k "ddmc or hybrid or general or faces" > gpurun_out/s16_pytest.txt 2>&1 || { tail -40 gpurun_out/s16_pytest.txt; exit 1; }
+tail -2 gpurun_out/s16_pytest.txt
+bash tools/dev/ab2.sh c3 100000000 prev cur prev cur cur@JB_TRANSPORT_BLOCKS_PER_CU=3 cur@JB_TRANSPORT_BLOCKS_PER_CU=5
+bash tools/dev/ab2.sh c3-1d 100000000 prev cur cur@JB_TRANSPORT_BLOCKS_PER_CU=3
