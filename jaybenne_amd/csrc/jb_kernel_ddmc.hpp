@@ -137,7 +137,14 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   // in vx, vy, vz (real_pos) or, for a lane in the loop, the one in S.vx, vy, vz [n]; -2: zero,
   // the flag a multi-D DDMC leak across a block face leaves behind (transport_ddmc.cpp:203-211)
   int pend = -1;
-  double pz1 = 0.0, pz2 = 0.0;
+  // ... kept as the stream state right before them: the loop only steps the stream past the two
+  // draws (one multiply-add by the two-step constants instead of two draws with their conversions)
+  unsigned long long pzs = 0ull;
+  auto pending_uniforms = [&](double &u1, double &u2) {
+    LcgRng at_leak(pzs);
+    u1 = at_leak.drand();
+    u2 = at_leak.drand();
+  };
   bool resample = false;  // reached census in a DDMC step: position / direction to be resampled
   bool fresh = false;     // loaded and not touched since: handing it over needs no write-back
   // ---- state that exists only between two points of one service phase
@@ -218,7 +225,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       Blk Bo;
       load_block_lds(M, lds_blocks, b, Bo);
       Step s;
-      s.vv = vv; s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
+      s.vv = vv; s.pend = pend; s.pz1 = 0.0; s.pz2 = 0.0;
+      if (pend >= 0) pending_uniforms(s.pz1, s.pz2);
       if (!real_pos) {
         // leak out of the block from the virtual state: the position the step function gave the
         // particle (transport_utils.hpp:209-263), from the cell it left and the channel
@@ -344,7 +352,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           x = 0.5 * (s.xl + s.xu); y = 0.5 * (s.yl + s.yu); z = 0.5 * (s.zl + s.zu);
         }
         if (pend >= 0) {
-          s.pend = pend; s.pz1 = pz1; s.pz2 = pz2;
+          s.pend = pend;
+          pending_uniforms(s.pz1, s.pz2);
           s.vx = vx; s.vy = vy; s.vz = vz;
           materialise_dir(s);
           vx = s.vx; vy = s.vy; vz = s.vz;
@@ -477,7 +486,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
         }
         bool is_absorbed = false;
-        const bool census = ddmc_step_rec<NDIM>(r, vv, t_end - t, nlog, rng, t, ip, jp, kp, pend, pz1, pz2,
+        const bool census = ddmc_step_rec<NDIM>(r, vv, t_end - t, nlog, rng, t, ip, jp, kp, pend, pzs,
                                                 is_absorbed);
         // (ip, jp, kp = Xtoijk of the position the step gives: see the header)
         resample = census;

@@ -497,7 +497,7 @@ struct DdmcStepRec {
 template <int NDIM, class Rng>
 __device__ __forceinline__ bool ddmc_step_rec(const DdmcStepRec &r, double vv, double dt_end, double nlog,
                                               Rng &rng, double &t, int &ip, int &jp, int &kp, int &pend,
-                                              double &pz1, double &pz2, bool &is_absorbed) {
+                                              unsigned long long &pzs, bool &is_absorbed) {
   constexpr int multi_d = NDIM >= 2 ? 1 : 0, three_d = NDIM == 3 ? 1 : 0;
   const double a2 = r.ffaa + r.leak_tot;
   const double cdf_ddmc = a2 + DBL_MIN;
@@ -523,8 +523,10 @@ __device__ __forceinline__ bool ddmc_step_rec(const DdmcStepRec &r, double vv, d
         ip += (axis == 0) ? step : 0;
         jp += (axis == 1) ? step * multi_d : 0;
         kp += (axis == 2) ? step * three_d : 0;
-        pz1 = rng.drand();
-        pz2 = rng.drand();
+        // the leak's two direction uniforms (transport_utils.hpp:217,235,253) are the next two
+        // draws of the stream: remember where they start, step past them
+        pzs = rng.s;
+        rng.skip2();
         pend = ch;
       }
     }

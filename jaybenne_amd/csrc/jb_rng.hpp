@@ -104,6 +104,11 @@ struct LcgRng {
   }
   // consume one draw whose value cannot influence the result
   __device__ __forceinline__ void skip() { s = s * kLcgMul + kLcgInc; }
+  // ... and two (one multiply-add by the constants of two steps: the same state)
+  __device__ __forceinline__ void skip2() {
+    constexpr uint64_t kMul2 = kLcgMul * kLcgMul, kInc2 = (kLcgMul + 1ull) * kLcgInc;
+    s = s * kMul2 + kInc2;
+  }
 };
 
 // Replays a caller-supplied list of uniforms (debug entry points / golden-vector tests only).
