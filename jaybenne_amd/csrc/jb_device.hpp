@@ -87,6 +87,13 @@ struct DevSwarm {
 typedef const double __attribute__((address_space(1))) *gcptr;
 typedef const int __attribute__((address_space(1))) *gcptr_i;
 
+// (a pointer read from memory instead of passed as a kernel argument: say that it is global memory,
+// or every access through it is a flat_ instruction)
+template <class T>
+__device__ __forceinline__ T *g1(T *p) {
+  return (T *)(__attribute__((address_space(1))) T *)p;
+}
+
 enum { ST_ACTIVE = 0, ST_ABSORBED = 1, ST_ESCAPED = 2, ST_OUTGOING = 3, ST_OUTGOING_ABSORBED = 4 };
 enum { BC_PERIODIC = 0, BC_REFLECT = 1, BC_OUTFLOW = 2 };
 

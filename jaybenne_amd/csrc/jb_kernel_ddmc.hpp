@@ -56,12 +56,6 @@ struct DdmcAllArgs {
   unsigned *park_list;              // slots handed over to k_hybrid ...
   unsigned long long *park_count;   // ... and how many
 };
-// (a pointer read from memory instead of passed as a kernel argument: say that it is global memory,
-// or every access through it is a flat_ instruction)
-template <class T>
-__device__ __forceinline__ T *g1(T *p) {
-  return (T *)(__attribute__((address_space(1))) T *)p;
-}
 
 // quad_bcast_add<K>(v, add): v of lane K of the caller's quad (lanes 4q .. 4q+3), plus the caller's add
 template <int K>

@@ -65,6 +65,20 @@ enum { HS_IDLE = 0, HS_IMC = 1, HS_VIRT = 2, HS_REAL = 3, HS_DONE = 4, HS_RELOC 
 // park_list, which the other phase's launch then works through (list_in), until both lists stay
 // empty (launch_hybrid in jb_api.hip).  Each phase is a kernel of its own to the register
 // allocator, and every loop runs with full waves.
+// the kernel's argument list as the kernel-argument segment holds it (natural alignment, in order)
+struct HybridArgs {
+  const DevMesh *Mp;
+  DevParams P;
+  DevSwarm S;
+  double t_start, dt;
+  long long first, last;
+  unsigned long long *counters;
+  const unsigned *list_in;
+  unsigned *park_list;
+  unsigned long long *park_count;
+  const unsigned long long *list_count;
+};
+
 template <int NDIM, bool TALLY, bool NOABS, int MODE, int PHASE>
 // (PHASE 0 keeps the state of both loops: two waves per SIMD, 256 registers; it only ever sees the
 // remainder.  PHASES 1 and 2 are held to three waves per SIMD, 168 registers, without spills.)
@@ -73,19 +87,31 @@ template <int NDIM, bool TALLY, bool NOABS, int MODE, int PHASE>
 // configurations; the stepdiff decks run none of them).
 __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 0 && (NDIM == 3 || !NOABS)) ||
                                            (PHASE == 1 && NDIM == 3 && !NOABS)) ? 2 : JB_HYBRID_WAVES_PER_SIMD)
-    k_hybrid(const DevMesh *__restrict__ Mp, DevParams P, DevSwarm S, double t_start, double dt,
-             long long first, long long last_arg, unsigned long long *counters, const unsigned *list_in,
-             unsigned *park_list, unsigned long long *park_count, const unsigned long long *list_count) {
+    k_hybrid(const DevMesh *__restrict__, DevParams, DevSwarm, double, double, long long, long long,
+             unsigned long long *, const unsigned *, unsigned *, unsigned long long *,
+             const unsigned long long *) {
+  // The arguments are read where they are used, from the kernel-argument segment (scalar loads),
+  // not through the parameters: fetched at kernel entry they occupy ~80 scalar registers across
+  // the loops, and what spills from there is fetched back with VALU instructions (v_readlane) in
+  // a loop that is bound by VALU issue (k_ddmc_all, section 4.2 of DESIGN.md, does the same).  The
+  // mesh view (~120 dwords) is behind a pointer for the same reason.
+  const HybridArgs &A = *(const HybridArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+  const DevMesh &M = *A.Mp;
+  const DevParams &P = A.P;
+  const DevSwarm &S = A.S;
+  const double t_start = A.t_start, dt = A.dt;
+  const long long first = A.first;
+  unsigned long long *const counters = g1(A.counters);
+  const unsigned *const list_in = g1(A.list_in);
+  unsigned *const park_list = g1(A.park_list);
+  unsigned long long *const park_count = g1(A.park_count);
   // (list_count: the length of list_in where only the device knows it -- the photons k_ddmc_all
   // hands over -- ; the launch then names the list's capacity)
-  long long last = last_arg;
-  if (list_count != nullptr) {
-    const long long have = first + (long long)*list_count;
+  long long last = A.last;
+  if (A.list_count != nullptr) {
+    const long long have = first + (long long)*g1(A.list_count);
     last = have < last ? have : last;
   }
-  // (the mesh view is read through a pointer to its copy in device memory: as a by-value argument
-  // its ~120 dwords compete for the scalar registers with everything else that is uniform here)
-  const DevMesh &M = *Mp;
   __shared__ double lds_tally[TALLY ? kLdsTally : 1];
   const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
   if constexpr (TALLY) {
@@ -372,18 +398,18 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
         } else if (status == ST_ACTIVE) {
           if constexpr (TALLY) {  // jaybenne.cpp:547-561
             const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
-            if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], S.w[n] / dv);
-            else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
+            if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], g1(S.w)[n] / dv);
+            else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], g1(S.w)[n] / dv);
           }
         }
       }
-      S.blk[n] = b;
-      S.t[n] = t;
-      S.x[n] = x; S.y[n] = y; S.z[n] = z;
-      S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
-      S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
-      S.status[n] = status;
-      S.rng[n] = rng.s;
+      g1(S.blk)[n] = b;
+      g1(S.t)[n] = t;
+      g1(S.x)[n] = x; g1(S.y)[n] = y; g1(S.z)[n] = z;
+      g1(S.vx)[n] = vx; g1(S.vy)[n] = vy; g1(S.vz)[n] = vz;
+      g1(S.ip)[n] = ip; g1(S.jp)[n] = jp; g1(S.kp)[n] = kp;
+      g1(S.status)[n] = status;
+      g1(S.rng)[n] = rng.s;
       resample = false;
       ls = HS_IDLE;
     }
@@ -427,11 +453,11 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
         if (mine) {
           cand = chunk_pos + rank;
           if (list_in != nullptr) cand = (long long)list_in[cand];  // (uniform)
-          st_in = S.status[cand];
-          rng_in = S.rng[cand];
-          b_in = S.blk[cand];
-          t_in = S.t[cand]; x_in = S.x[cand]; y_in = S.y[cand]; z_in = S.z[cand];
-          vx_in = S.vx[cand]; vy_in = S.vy[cand]; vz_in = S.vz[cand];
+          st_in = g1(S.status)[cand];
+          rng_in = g1(S.rng)[cand];
+          b_in = g1(S.blk)[cand];
+          t_in = g1(S.t)[cand]; x_in = g1(S.x)[cand]; y_in = g1(S.y)[cand]; z_in = g1(S.z)[cand];
+          vx_in = g1(S.vx)[cand]; vy_in = g1(S.vy)[cand]; vz_in = g1(S.vz)[cand];
         }
         chunk_pos += give;
         need &= ~__ballot(mine);
@@ -486,7 +512,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
         ls = HS_RELOC;
       } else if (s.is_absorbed) {  // transport.cpp:157-163
         if (lds_blocks.owned[b] != 0) {
-          atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], S.w[n]);
+          atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], g1(S.w)[n]);
           status = ST_ABSORBED;
         } else {
           status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
@@ -550,12 +576,12 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
         }
         if (!fresh) {  // (a photon parked as it was loaded -- e.g. one that starts the cycle in a DDMC
                        // cell, seen by the IMC phase -- is only listed)
-          S.blk[n] = b;
-          S.t[n] = t;
-          S.x[n] = x; S.y[n] = y; S.z[n] = z;
-          S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
-          S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
-          S.rng[n] = rng.s;
+          g1(S.blk)[n] = b;
+          g1(S.t)[n] = t;
+          g1(S.x)[n] = x; g1(S.y)[n] = y; g1(S.z)[n] = z;
+          g1(S.vx)[n] = vx; g1(S.vy)[n] = vy; g1(S.vz)[n] = vz;
+          g1(S.ip)[n] = ip; g1(S.jp)[n] = jp; g1(S.kp)[n] = kp;
+          g1(S.rng)[n] = rng.s;
         }
         const unsigned long long pm = __ballot(true);
         const int leader = __ffsll((long long)pm) - 1;
@@ -613,7 +639,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
             ls = HS_RELOC;  // a leak through a block face: the service phase
           } else if (s.is_absorbed) {  // transport.cpp:157-163
             if (lds_blocks.owned[b] != 0) {
-              atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], S.w[n]);
+              atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], g1(S.w)[n]);
               status = ST_ABSORBED;
             } else {
               status = ST_OUTGOING_ABSORBED;
@@ -679,7 +705,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
             crossing = true;
           } else if (is_absorbed) {  // transport.cpp:157-163
             if (lds_blocks.owned[b] != 0) {
-              atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], S.w[n]);
+              atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], g1(S.w)[n]);
               status = ST_ABSORBED;
             } else {
               status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
