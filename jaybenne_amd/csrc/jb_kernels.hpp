@@ -389,14 +389,30 @@ enum { LS_IDLE = 0, LS_RUN = 1, LS_DONE = 2, LS_RELOC = 3, LS_DONE_RAW = 4 };
 // general formulas (transport.cpp:114-119), in 3 instead of 8 operations per axis.
 // LEAN (gray IMC kernels only): lean arithmetic in the tracking step (imc_step_fast): within 2^-48
 // (relative) per operation of the exact variant, ~8 % fewer instructions; jb_set_arithmetic picks.
+// the kernel's argument list as the kernel-argument segment holds it (natural alignment, in order)
+struct TransportArgs {
+  DevMesh M;
+  DevParams P;
+  DevSwarm S;
+  double t_start, dt;
+  long long first, last;
+  unsigned long long *counters;
+  const int *skip_unless;
+};
 template <int NDIM, bool DDMC, bool TALLY, int GRAY, bool EXACT = false, bool LEAN = false>
 __global__ void
 __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
                             : (LEAN && GRAY == 2 ? JB_LEAN_WAVES_PER_SIMD : JB_TRANSPORT_WAVES_PER_SIMD))
-    k_transport(DevMesh M, DevParams P, DevSwarm S, double t_start, double dt, long long first,
+    k_transport(DevMesh M, DevParams, DevSwarm, double t_start, double dt, long long first,
                 long long last, unsigned long long *counters, const int *skip_unless) {
   static_assert(!EXACT || (GRAY != 0 && !DDMC), "EXACT is a variant of the gray IMC kernels");
   static_assert(!LEAN || (GRAY != 0 && !DDMC), "LEAN is a variant of the gray IMC kernels");
+  // The swarm view and the parameters are read where they are used (the service phase), from the
+  // kernel-argument segment, not through the parameters (see k_ddmc_all); the mesh view, which the
+  // event loop reads, stays in scalar registers.
+  const TransportArgs &A = *(const TransportArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+  const DevParams &P = A.P;
+  const DevSwarm &S = A.S;
   // (gray DDMC launches come in pairs: k_ddmc_all runs when every cell is a DDMC cell, this
   // kernel when *skip_unless says otherwise)
   if (skip_unless != nullptr && *skip_unless == 0) return;
@@ -672,19 +688,19 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
           vx *= vv; vy *= vv; vz *= vv;
         }
       }
-      S.blk[n] = b;
-      S.t[n] = t;
-      S.x[n] = x; S.y[n] = y; S.z[n] = z;
-      S.vx[n] = vx; S.vy[n] = vy; S.vz[n] = vz;
-      S.ip[n] = ip; S.jp[n] = jp; S.kp[n] = kp;
-      S.status[n] = status;
-      S.rng[n] = rng.s;
+      g1(S.blk)[n] = b;
+      g1(S.t)[n] = t;
+      g1(S.x)[n] = x; g1(S.y)[n] = y; g1(S.z)[n] = z;
+      g1(S.vx)[n] = vx; g1(S.vy)[n] = vy; g1(S.vz)[n] = vz;
+      g1(S.ip)[n] = ip; g1(S.jp)[n] = jp; g1(S.kp)[n] = kp;
+      g1(S.status)[n] = status;
+      g1(S.rng)[n] = rng.s;
       if (status == ST_ACTIVE) {
         ++c_census;
         if constexpr (TALLY) {  // jaybenne.cpp:547-561
           const double dv = B.dx[0] * B.dx[1] * B.dx[2];
-          if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], S.w[n] / dv);
-          else atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], S.w[n] / dv);
+          if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], g1(S.w)[n] / dv);
+          else atomicAdd(&M.tally[b][cidx(M, kp, jp, ip)], g1(S.w)[n] / dv);
         }
       } else if (status == ST_ABSORBED) {
         ++c_abs;
@@ -714,15 +730,15 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
           cur = (cur + 1) % kQueues;
           if (++tried == kQueues) more = false;
         }
-        if (ls == LS_IDLE && cand < q_last && S.status[cand] == ST_ACTIVE) {
+        if (ls == LS_IDLE && cand < q_last && g1(S.status)[cand] == ST_ACTIVE) {
           n = cand;
-          rng.s = S.rng[n];
-          b = S.blk[n];
+          rng.s = g1(S.rng)[n];
+          b = g1(S.blk)[n];
           bind_block(b);
-          t = S.t[n];
-          x = S.x[n]; y = S.y[n]; z = S.z[n];
-          vx = S.vx[n]; vy = S.vy[n]; vz = S.vz[n];
-          ee = S.e[n];
+          t = g1(S.t)[n];
+          x = g1(S.x)[n]; y = g1(S.y)[n]; z = g1(S.z)[n];
+          vx = g1(S.vx)[n]; vy = g1(S.vy)[n]; vz = g1(S.vz)[n];
+          ee = g1(S.e)[n];
           status = ST_ACTIVE;
           resample = false;
           xtoijk<NDIM>(M, B, x, y, z, ip, jp, kp);  // transport.cpp:96
@@ -769,11 +785,11 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
         if (ls == LS_IDLE && rank < give) {
           // every field is requested before the first one is looked at: one memory latency
           const long long cand = chunk_pos + rank;
-          const int st_in = S.status[cand];
-          const unsigned long long rng_in = S.rng[cand];
-          const int b_in = S.blk[cand];
-          const double t_in = S.t[cand], x_in = S.x[cand], y_in = S.y[cand], z_in = S.z[cand];
-          const double vx_in = S.vx[cand], vy_in = S.vy[cand], vz_in = S.vz[cand], e_in = S.e[cand];
+          const int st_in = g1(S.status)[cand];
+          const unsigned long long rng_in = g1(S.rng)[cand];
+          const int b_in = g1(S.blk)[cand];
+          const double t_in = g1(S.t)[cand], x_in = g1(S.x)[cand], y_in = g1(S.y)[cand], z_in = g1(S.z)[cand];
+          const double vx_in = g1(S.vx)[cand], vy_in = g1(S.vy)[cand], vz_in = g1(S.vz)[cand], e_in = g1(S.e)[cand];
           if (st_in == ST_ACTIVE) {
             n = cand;
             rng.s = rng_in;
@@ -863,7 +879,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
             ls = LS_RELOC;  // comm phase: below, for the lanes that need it
           } else if (is_absorbed) {  // transport.cpp:157-163
             if (M.owned[b]) {
-              atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
+              atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], g1(S.w)[n]);
               status = ST_ABSORBED;
             } else {
               status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
@@ -1018,7 +1034,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
           }
         } else if (s.is_absorbed) {  // transport.cpp:157-163
           if (M.owned[b]) {
-            atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], S.w[n]);
+            atomicAdd(&M.edelta[b][cidx(M, kp, jp, ip)], g1(S.w)[n]);
             status = ST_ABSORBED;
           } else {
             status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
