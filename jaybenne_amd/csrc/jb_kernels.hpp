@@ -857,6 +857,8 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
             g.fd[0] = fd[0]; g.fd[1] = fd[1]; g.fd[2] = fd[2];
             imc_step_dir<NDIM, kNoAbs, EXACT>(g, B.dx_push, lam_a, lam_s, rng, t, x, y, z,
                                               vx, vy, vz, ip, jp, kp, is_absorbed, is_scattered);
+            // (the nudge widths come back with the sign the direction last gave them)
+            if constexpr (EXACT) { fd[0] = g.fd[0]; fd[1] = g.fd[1]; fd[2] = g.fd[2]; }
           } else {
             ImcCell c;
             if constexpr (EXACT) {

@@ -178,8 +178,8 @@ __device__ __forceinline__ double m_log_lean(double x) {
   const double r = fma(z, invc, -1.0);
   const double w = fma((double)k, ln2, lc);
   const double r2 = r * r;
-  double p = m_fma(r, -0.125, 1.0 / 7.0);
-  p = m_fma(r, p, -1.0 / 6.0);
+  // (|r| <= 5.5e-3: the r^8 / 8 term of the series is below 2e-17 of the result, 0.2 ulp)
+  double p = m_fma(r, 1.0 / 7.0, -1.0 / 6.0);
   p = m_fma(r, p, 0.2);
   p = m_fma(r, p, -0.25);
   p = m_fma(r, p, 1.0 / 3.0);

@@ -303,6 +303,19 @@ __device__ __forceinline__ void dir_nudge(double &x, int &idx, double o, double 
   x = hit ? f + __hiloint2double(shi, __double2loint(fd)) : x;
   idx = iu - (int)(hit != up);
 }
+// ... with the nudge width carried from pass to pass WITH the sign it last had: only the sign bit
+// is rewritten (v_bfi_b32 on the high word, in place), so no pass has to rebuild the register
+// pair from the unsigned width (one v_mov_b32 per axis); the comparison reads |sfd| (a source
+// modifier, free)
+__device__ __forceinline__ void dir_nudge_carried(double &x, int &idx, double o, double f, double &sfd,
+                                                  int iu, bool up) {
+  int shi;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(shi) : "s"(0x7fffffff), "v"(__double2hiint(sfd)), "v"(__double2hiint(o)));
+  sfd = __hiloint2double(shi, __double2loint(sfd));
+  const bool hit = fabs(x - f) < fabs(sfd);
+  x = hit ? f + sfd : x;
+  idx = iu - (int)(hit != up);
+}
 // ... and, BOTH, at the face behind as well -- pushed outwards through it as the reference does
 // whatever the direction (transport_utils.hpp:151-159).  The hybrid kernel on a general geometry
 // needs it: a DDMC leak across a block face leaves the photon with ZERO velocity at the centre of
@@ -315,7 +328,7 @@ __device__ __forceinline__ void dir_nudge_behind(double &x, int &idx, double fb,
   idx += hit ? (up ? -1 : 1) : 0;
 }
 template <int NDIM, bool NOABS, bool EXACTG, bool BOTH = false, class Rng>
-__device__ __forceinline__ void imc_step_dir(const DirGeom &g, double dx_push0, double lam_abs,
+__device__ __forceinline__ void imc_step_dir(DirGeom &g, double dx_push0, double lam_abs,
                                              double lam_sc, Rng &rng, double &d_rem, double &x,
                                              double &y, double &z, double ox, double oy, double oz,
                                              int &ip, int &jp, int &kp, bool &is_absorbed,
@@ -344,9 +357,15 @@ __device__ __forceinline__ void imc_step_dir(const DirGeom &g, double dx_push0, 
   x = fma(ox, dx_move, x);
   if (multi_d) y = fma(oy, dx_move, y);
   if (three_d) z = fma(oz, dx_move, z);
-  dir_nudge(x, ip, ox, fx, EXACTG ? g.fd[0] : kEpsImc * g.dx[0], iux, upx);
-  if (multi_d) dir_nudge(y, jp, oy, fy, EXACTG ? g.fd[1] : kEpsImc * g.dx[1], iuy, upy);
-  if (three_d) dir_nudge(z, kp, oz, fz, EXACTG ? g.fd[2] : kEpsImc * g.dx[2], iuz, upz);
+  if constexpr (EXACTG) {  // (g.fd: eps_imc dx with the sign the direction component last had)
+    dir_nudge_carried(x, ip, ox, fx, g.fd[0], iux, upx);
+    if (multi_d) dir_nudge_carried(y, jp, oy, fy, g.fd[1], iuy, upy);
+    if (three_d) dir_nudge_carried(z, kp, oz, fz, g.fd[2], iuz, upz);
+  } else {
+    dir_nudge(x, ip, ox, fx, kEpsImc * g.dx[0], iux, upx);
+    if (multi_d) dir_nudge(y, jp, oy, fy, kEpsImc * g.dx[1], iuy, upy);
+    if (three_d) dir_nudge(z, kp, oz, fz, kEpsImc * g.dx[2], iuz, upz);
+  }
   if constexpr (BOTH) {
     // (the other face of the cell the step started in; never both faces of one axis: they are dx
     // apart, and a photon nudged through the face ahead ends fd beyond that one)
