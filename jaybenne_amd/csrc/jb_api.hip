@@ -690,6 +690,10 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         const unsigned long long rec_bytes = 64ull * (unsigned long long)M.ntot * (unsigned long long)M.nblocks;
         const bool coop = rec_bytes < (1ull << 32) &&
                           (ctx->coop_gather >= 0 ? ctx->coop_gather == 1 : rec_bytes >= (1ull << 20));
+        // ... and a mesh of at most kLdsRecCells cells (the reference's 1-D decks) keeps its records in
+        // LDS: 12.0 -> ?? ms per 1e8 histories on BASELINE configs[2] as shipped
+        const bool in_lds = !coop && ctx->coop_gather < 0 && (long long)M.nblocks * M.ntot <= (long long)kLdsRecCells;
+        const int gather = coop ? 1 : (in_lds ? 2 : 0);
         // A particle that sits at a face of its cell when it is loaded or relocated (one in ~1e8) needs
         // the albedo step: k_ddmc_all lists it, and k_hybrid<.., both loops>, launched behind it on
         // that list (its length read on the device: no synchronisation), tracks it to the end.
@@ -700,14 +704,16 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         unsigned *handed = (unsigned *)ctx->scratch_d;
         unsigned long long *n_handed = ctx->counters_d + kCursorBase;
         // (dynamic shared memory: the tally of a mesh with <= kLdsTally cells, resident blocks' ghosts included)
+        const size_t ncell_all = (size_t)M.nblocks * (size_t)M.ntot;
         const size_t lds_tally_bytes =
-            tally && (long long)M.nblocks * M.ntot <= (long long)kLdsTally ? sizeof(double) * kLdsTally : 0;
+            (tally && (long long)ncell_all <= (long long)kLdsTally ? sizeof(double) * ((ncell_all + 1) / 2 * 2) : 0) +
+            (in_lds ? 64 * ncell_all : 0);
         (void)hipMemsetAsync(n_handed, 0, sizeof(unsigned long long), ctx->stream);
 #define JB_LAUNCH_DDMC_ALL(TL, CO)                                                                          \
   do {                                                                                                      \
-    static int occ[2] = {0, 0};  /* without / with the LDS tally */                                         \
-    int &oc = occ[lds_tally_bytes ? 1 : 0];                                                                 \
-    if (oc < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, k_ddmc_all<NDIM, TL, CO>, kBlock, lds_tally_bytes) != hipSuccess || oc < 1)) oc = 3; \
+    /* (the dynamic LDS -- tally and record table of a small mesh -- changes with the mesh: ask per launch) */ \
+    int oc = 0;                                                                                             \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, k_ddmc_all<NDIM, TL, CO>, kBlock, lds_tally_bytes) != hipSuccess || oc < 1) oc = 3; \
     const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : oc);                            \
     hipLaunchKernelGGL((k_ddmc_all<NDIM, TL, CO>), dim3(g), dim3(kBlock), lds_tally_bytes, ctx->stream, mesh->dm_dev, ctx->dp, S, \
                        t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc, handed, n_handed); \
@@ -720,19 +726,24 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
                        (const unsigned *)handed, (unsigned *)nullptr, (unsigned long long *)nullptr,         \
                        (const unsigned long long *)n_handed);                                               \
   } while (0)
-        static const char *const names[3][2][2] = {
-            {{"k_ddmc_all<1, false>", "k_ddmc_all<1, false, quad gather>"}, {"k_ddmc_all<1, true>", "k_ddmc_all<1, true, quad gather>"}},
-            {{"k_ddmc_all<2, false>", "k_ddmc_all<2, false, quad gather>"}, {"k_ddmc_all<2, true>", "k_ddmc_all<2, true, quad gather>"}},
-            {{"k_ddmc_all<3, false>", "k_ddmc_all<3, false, quad gather>"}, {"k_ddmc_all<3, true>", "k_ddmc_all<3, true, quad gather>"}}};
-        mesh->last_variant = names[NDIM - 1][tally ? 1 : 0][coop ? 1 : 0];
+        static const char *const names[3][2][3] = {
+            {{"k_ddmc_all<1, false>", "k_ddmc_all<1, false, quad gather>", "k_ddmc_all<1, false, records in LDS>"},
+             {"k_ddmc_all<1, true>", "k_ddmc_all<1, true, quad gather>", "k_ddmc_all<1, true, records in LDS>"}},
+            {{"k_ddmc_all<2, false>", "k_ddmc_all<2, false, quad gather>", "k_ddmc_all<2, false, records in LDS>"},
+             {"k_ddmc_all<2, true>", "k_ddmc_all<2, true, quad gather>", "k_ddmc_all<2, true, records in LDS>"}},
+            {{"k_ddmc_all<3, false>", "k_ddmc_all<3, false, quad gather>", "k_ddmc_all<3, false, records in LDS>"},
+             {"k_ddmc_all<3, true>", "k_ddmc_all<3, true, quad gather>", "k_ddmc_all<3, true, records in LDS>"}}};
+        mesh->last_variant = names[NDIM - 1][tally ? 1 : 0][gather];
         if (tally) {
-          if (coop) JB_LAUNCH_DDMC_ALL(true, true);
-          else JB_LAUNCH_DDMC_ALL(true, false);
+          if (gather == 1) JB_LAUNCH_DDMC_ALL(true, 1);
+          else if (gather == 2) JB_LAUNCH_DDMC_ALL(true, 2);
+          else JB_LAUNCH_DDMC_ALL(true, 0);
           if (noabs_h) JB_LAUNCH_HANDED(true, true);
           else JB_LAUNCH_HANDED(true, false);
         } else {
-          if (coop) JB_LAUNCH_DDMC_ALL(false, true);
-          else JB_LAUNCH_DDMC_ALL(false, false);
+          if (gather == 1) JB_LAUNCH_DDMC_ALL(false, 1);
+          else if (gather == 2) JB_LAUNCH_DDMC_ALL(false, 2);
+          else JB_LAUNCH_DDMC_ALL(false, 0);
           if (noabs_h) JB_LAUNCH_HANDED(false, true);
           else JB_LAUNCH_HANDED(false, false);
         }

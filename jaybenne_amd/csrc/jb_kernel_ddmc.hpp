@@ -69,7 +69,13 @@ __device__ __forceinline__ unsigned quad_bcast_add(unsigned v, unsigned add) {
 // k serving the record of quad-lane k -- the vector L1 then looks up one line per record instead of
 // four (one per 16-byte piece of every lane), which is what bounds the loop: 4 x 64 lookups per wave
 // pass x 12 waves per CU = the ~3000 cycles a round of passes takes.
-template <int NDIM, bool TALLY, bool COOP>
+// GATHER: how the event loop fetches the step record of a lane's cell -- 0 four 16-byte loads per
+// lane; 1 = COOP above; 2 the records of ALL resident blocks' cells copied into LDS at kernel
+// start (<= kLdsRecCells cells, 64 B each: the reference's 1-D decks, BASELINE configs[2] as
+// shipped), after which the loop issues no vector-memory instruction at all.  Measured on that
+// deck the vector L1 was busy 95 % of the kernel's time serving 4.8e9 record look-ups.
+constexpr int kLdsRecCells = 256;
+template <int NDIM, bool TALLY, int GATHER>
 #ifndef JB_DDMC_ALL_ATTR
 #define JB_DDMC_ALL_ATTR
 #endif
@@ -89,13 +95,23 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   const double t_start = A.t_start, dt = A.dt;
   const long long first = A.first, last = A.last;
   unsigned long long *const counters = g1(A.counters);
-  // (the LDS tally of a small mesh -- all resident blocks' cells, <= kLdsTally -- is dynamic shared
-  // memory: a mesh that does not use it leaves the room to a fourth workgroup per CU)
-  extern __shared__ double lds_tally[];
+  constexpr bool COOP = GATHER == 1;
+  // (the LDS tally of a small mesh -- all resident blocks' cells, <= kLdsTally -- and the LDS copy
+  // of its step records are dynamic shared memory, sized by the launch: a mesh that uses neither
+  // leaves the room to a fourth workgroup per CU)
+  extern __shared__ double lds_dyn[];
+  double *const lds_tally = lds_dyn;
   const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
+  const int ncell_all = M.nblocks * (int)M.ntot;
+  // (behind the tally, on a 16-byte boundary)
+  const double *const lds_rec_tab = lds_dyn + (tally_in_lds ? (ncell_all + 1) / 2 * 2 : 0);
   if constexpr (TALLY) {
     if (tally_in_lds)
-      for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) lds_tally[q] = 0.0;
+      for (int q = threadIdx.x; q < ncell_all; q += blockDim.x) lds_tally[q] = 0.0;
+  }
+  if constexpr (GATHER == 2) {
+    double *const dst = lds_dyn + (tally_in_lds ? (ncell_all + 1) / 2 * 2 : 0);
+    for (int q = threadIdx.x; q < 8 * ncell_all; q += blockDim.x) dst[q] = ((gcptr)M.ddmc_step)[q];
   }
   __shared__ LdsBlockTableT<false> lds_blocks;
   // [wave][quad-lane k][quad q]: the record of lane 4 q + k of the wave (LDS-direct loads deposit
@@ -467,6 +483,13 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the four pieces have landed
           const v4d r0 = my_rec[0];
           const v4d r1 = my_rec[1];
+          r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
+          r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
+        } else if constexpr (GATHER == 2) {
+          const v4d *rec = (const v4d *)(lds_rec_tab + 8u * ((unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip)));
+          const v4d r0 = rec[0];
+          const v4d r1 = rec[1];
+          nlog = -m_log(rng.drand());
           r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
           r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
         } else {
