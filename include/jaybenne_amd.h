@@ -257,7 +257,8 @@ int jb_get_arithmetic(const jb_context *ctx);
  * <NDIM, TALLY (census tally fused), GRAY (0 per-event opacities, 1 gray, 2 gray without
  * absorption), EXACT (exact cell-face arithmetic, 32-bit cell offsets), LEAN (lean arithmetic)>;
  * "k_ddmc_all<3, true>" = <NDIM, TALLY> on a mesh whose every cell takes DDMC steps (", quad gather"
- * appended when its cell records, more than 1 MiB of them, are fetched quad-cooperatively);
+ * appended when its cell records, more than 1 MiB of them, are fetched quad-cooperatively,
+ * ", records in LDS" when the mesh has at most 256 cells and the kernel keeps them in LDS);
  * "k_hybrid<2, lean, exact geometry>" on a mesh that mixes IMC and DDMC cells (three launches: IMC
  * phase, DDMC phase, remainder); "" before the first launch.  jb_mesh_exact_geometry: 1 if every
  * resident block has power-of-two cell widths and a lower corner that is a whole number of them
