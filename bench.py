@@ -374,6 +374,18 @@ def main() -> None:
                     "l2_served_GBps": l2_gbs,
                     "l2_served_definition": "168 B per history + 72 B of cell gathers per DDMC step / "
                                             "kernel time"}
+            if "records in LDS" in variant:
+                # a mesh of <= 256 cells: the kernel copies the step records into LDS once and its
+                # event loop issues no vector-memory instruction -- nothing is gathered through L2;
+                # what HBM has to move is the particle stream, and that is the bound reported
+                roof.update({"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "frac": hbm / HBM_PEAK_GBS,
+                             "definition": "168 B per history (84 B read, 68 B write-back, 16 B tally) / "
+                                           "k_ddmc_all time (HIP events, this run), against 8 TB/s: the "
+                                           "cell records live in LDS (copied once per launch), the only "
+                                           "HBM traffic is the particle stream",
+                             "lds_served_GBps": gather,
+                             "lds_served_definition": "DDMC steps x 64 B read from the LDS copy of the "
+                                                      "records / kernel time"})
         else:
             roof = {"bound": "fp64_valu", "achieved": fp64, "peak": FP64_VALU_PEAK_TF,
                     "unit": "TFLOP/s", "frac": fp64 / FP64_VALU_PEAK_TF,

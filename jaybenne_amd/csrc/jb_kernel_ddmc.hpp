@@ -178,8 +178,12 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   const int l_js = (int)sgpr_copy((unsigned)M.js), l_je = (int)sgpr_copy((unsigned)M.je);
   const int l_ks = (int)sgpr_copy((unsigned)M.ks), l_ke = (int)sgpr_copy((unsigned)M.ke);
   auto cidx_l = [&](int k, int j, int i) { return __mul24(__mul24(k, l_nj) + j, l_ni) + i; };
+  // (the index along an inactive axis is the block's first there and never moves: Xtoijk, the step)
   auto on_block_l = [&](int i, int j, int k) {
-    return i >= l_is && i <= l_ie && j >= l_js && j <= l_je && k >= l_ks && k <= l_ke;
+    bool on = i >= l_is && i <= l_ie;
+    if constexpr (NDIM >= 2) on = on && j >= l_js && j <= l_je;
+    if constexpr (NDIM == 3) on = on && k >= l_ks && k <= l_ke;
+    return on;
   };
   typedef double v4d __attribute__((ext_vector_type(4)));
   const unsigned sub16 = 16u * (unsigned)(lane & 3);

@@ -530,10 +530,14 @@ __device__ __forceinline__ bool ddmc_step_rec(const DdmcStepRec &r, double vv, d
     } else if (xi < a2) {
       const double xim = xi - r.ffaa;
       // the first threshold above xim, as the chain of transport_utils.hpp:218-254 finds it
+      // (the leak opacities of an inactive axis are exactly zero -- k_ddmc_pack -- so its two
+      // thresholds repeat the one before them and their comparisons can never be the first to hold)
       int ch = (xim <= r.leak_tot) ? 5 : -1;
-      ch = (xim < r.c5) ? 4 : ch;
-      ch = (xim < r.c4) ? 3 : ch;
-      ch = (xim < r.c3) ? 2 : ch;
+      if constexpr (three_d) ch = (xim < r.c5) ? 4 : ch;   // (2-D: c5 = c4; 1-D: c5 = c4 = c3 = c2)
+      if constexpr (multi_d) {
+        ch = (xim < r.c4) ? 3 : ch;
+        ch = (xim < r.c3) ? 2 : ch;
+      }
       ch = (xim < r.c2) ? 1 : ch;
       ch = (xim < r.c1) ? 0 : ch;
       if (ch >= 0) {
