@@ -420,7 +420,15 @@ TaskStatus UpdateFluid(MeshData<Real> *md) {   // jaybenne.cpp:583-615
   return Status(jb_update_fluid(st.ctx, st.mesh));
 }
 
-TaskStatus DefragParticles(MeshBlock *) { return TaskStatus::complete; }   // jaybenne.cpp:499-509 (unscheduled)
+// jaybenne.cpp:499-509 (Swarm::Defrag; no task list of the reference schedules it).  The resident
+// swarm is one array set for all blocks of the rank and compact after UpdateFluid; the task sorts
+// it by (block, cell) -- the locality the tracking kernels' cell gathers live on (jaybenne_amd.h) --
+// once per call series: the first block of the rank does the work for all of them.
+TaskStatus DefragParticles(MeshBlock *pmb) {
+  AmdState &st = State(pmb->pmy_mesh);
+  if (pmb->lid != 0) return TaskStatus::complete;
+  return Status(jb_defrag_particles(st.ctx, st.mesh, &st.sw));
+}
 
 Real EstimateTimestepMesh(MeshData<Real> *md) {   // jaybenne.cpp:271-275
   return jb_estimate_timestep(State(md->GetParentPointer()).ctx);

@@ -206,6 +206,9 @@ def main() -> None:
     ap.add_argument("--force-exchange", action="store_true",
                     help="1 GPU: run the hand-off phase as well, in a one-rank group (nothing moves; "
                          "shows the fixed cost of the exchange per transport iteration)")
+    ap.add_argument("--defrag-interval", type=int, default=0,
+                    help="DefragParticles (sort of the swarm by cell) after every k-th cycle; matters "
+                         "for long runs (profiles/r03_long_run.json), not for the few cycles timed here")
     ap.add_argument("--no-other-variant", action="store_true",
                     help="skip the one extra step in the other arithmetic variant (profiling runs)")
     ap.add_argument("--arithmetic", choices=("lean", "exact"), default=None,
@@ -255,6 +258,7 @@ def main() -> None:
                                 capacity_factor=1.5 if world == 1 else 3.0)
     md = drv.md
     md.force_exchange = bool(args.force_exchange)
+    md.defrag_interval = int(args.defrag_interval)
 
     def sync_all():
         torch.cuda.synchronize(device)

@@ -122,6 +122,7 @@ PROTOTYPES = {
     "jb_update_fluid": (_int, [_vp, _vp]),
     "jb_photon_reflect_bc": (_int, [_vp, _vp, C.POINTER(SwarmView), _int]),
     "jb_remove_marked_particles": (_int, [_vp, C.POINTER(SwarmView)]),
+    "jb_defrag_particles": (_int, [_vp, _vp, C.POINTER(SwarmView)]),
     "jb_pack_outgoing": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, _i64, _int, _vp, _i64, _vp]),
     "jb_unpack_incoming": (_int, [_vp, _vp, C.POINTER(SwarmView), _vp, _i64]),
     "jb_gather_cells": (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp]),

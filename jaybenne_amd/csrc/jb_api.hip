@@ -1053,6 +1053,43 @@ extern "C" jb_status jb_remove_marked_particles(jb_context *ctx, jb_swarm_view *
   return JB_COMPLETE;
 }
 
+extern "C" jb_status jb_defrag_particles(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm) {
+  if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
+  jb_status st = check_swarm(swarm, "jb_defrag_particles");
+  if (st != JB_COMPLETE) return st;
+  const long long n = swarm->n;
+  if (n == 0) return JB_COMPLETE;
+  if (n >= (1ll << 32)) return fail(JB_ERR_INVALID, "jb_defrag_particles: more than 2^32 - 1 particles");
+  const DevMesh &M = mesh->dm;
+  const unsigned long long nkeys64 = (unsigned long long)M.nblocks * (unsigned long long)M.ntot;
+  if (nkeys64 >= (1ull << 32) - 1ull) return fail(JB_ERR_INVALID, "jb_defrag_particles: more than 2^32 - 2 cells");
+  const unsigned nkeys = (unsigned)nkeys64;
+  const long long nbins = (long long)nkeys + 1;                       // + the bin behind all cells
+  const int ntiles = (int)((nbins + kScanTile - 1) / kScanTile);
+  // scratch: the particle records (16 words each, on a 128-byte boundary), then histogram / offsets
+  // (nbins), tile sums (ntiles) and keys (n), 4 bytes each
+  const size_t rec_words = (size_t)kSortRecWords * (size_t)n;
+  st = ensure_scratch(ctx, rec_words + (size_t)((nbins + ntiles + n) / 2 + 16));
+  if (st != JB_COMPLETE) return st;
+  unsigned long long *rec = (unsigned long long *)ctx->scratch_d;
+  unsigned *hist = (unsigned *)(rec + rec_words);
+  unsigned *sums = hist + nbins;
+  unsigned *key = sums + ntiles;
+  JB_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)nbins, ctx->stream));
+  const DevSwarm S = dev_swarm(swarm);
+  hipLaunchKernelGGL(k_sort_count, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, M, S, n, nkeys, key, hist);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kBlock), 0, ctx->stream, hist, nbins, sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums, ntiles);
+  hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kBlock), 0, ctx->stream, hist, nbins, (const unsigned *)sums);
+  hipLaunchKernelGGL(k_sort_pack, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, S, n, (const unsigned *)key,
+                     hist, rec);
+  hipLaunchKernelGGL(k_sort_unpack, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, S, n,
+                     (const unsigned long long *)rec);
+  JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
 extern "C" jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
                                       int64_t first, int64_t last, int nranks, int64_t *records_dev,
                                       int64_t record_capacity, int64_t *counts_host) {

@@ -1254,6 +1254,192 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // -------------------------------------------------------------------------------------------
+// DefragParticles (reference jaybenne.cpp:499-509: Swarm::Defrag, never scheduled there).  Here the
+// swarm is compact after RemoveMarkedParticles; what degrades over the cycles is its ORDER: photons
+// are sourced in (block, cell) order, so the photons a wave holds -- and the ones in flight on an
+// XCD -- gather their cell data from a few neighbouring rows that stay in that XCD's 4 MiB L2, and
+// every cycle of diffusion loosens that (measured on BASELINE configs[2] in 3-D: 26.5 ms per cycle
+// at cycle 2, 39.9 at cycle 16).  The defragmentation is therefore a counting sort of the photons
+// by (resident block, cell of their position): histogram, exclusive scan, move (through records in
+// scratch memory, back into the same arrays).  Photons of one cell come out in arbitrary order
+// (the move claims slots with atomics); nothing a photon carries changes.
+// (Photons of one cell sit next to each other in a swarm that is still nearly in order -- ~50 per
+// cell on the stepdiff decks --, so a wave's 64 keys are a few RUNS of equal keys: one atomic per run,
+// by its first lane, instead of one per photon on the same address.)
+// run_of: for the calling lane, the first lane of its run of equal keys among consecutive active
+// lanes and the length of that run
+__device__ __forceinline__ void run_of(unsigned key, bool active, int lane, int &head, int &len) {
+  const unsigned prev = __shfl_up(key, 1, 64);
+  const unsigned long long act = __ballot(active);
+  const unsigned long long heads = __ballot(active && (lane == 0 || key != prev));
+  const unsigned long long upto = heads & ((2ull << lane) - 1ull);          // heads at or below me
+  head = 63 - __clzll((long long)upto);
+  const unsigned long long above = heads & ~((2ull << head) - 1ull);        // heads above my run's
+  const int nact = __popcll(act);                                            // (active lanes: 0 .. nact-1)
+  len = (above != 0ull ? __ffsll((long long)above) - 1 : nact) - head;
+}
+__global__ void __launch_bounds__(kBlock)
+    k_sort_count(DevMesh M, DevSwarm S, long long n, unsigned nkeys, unsigned *key, unsigned *hist) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) - lane;
+  for (long long base = wave0; base < n; base += (long long)gridDim.x * blockDim.x) {
+    const long long p = base + lane;
+    const bool active = p < n;
+    unsigned k = nkeys;  // (anything but an active photon in a resident block: behind all cells)
+    if (active) {
+      const int b = S.blk[p];
+      if (S.status[p] == ST_ACTIVE && b >= 0 && b < M.nblocks) {
+        Blk B;
+        load_block(M, b, B);
+        int i, j, kk;
+        if (M.ndim == 1) xtoijk<1>(M, B, S.x[p], S.y[p], S.z[p], i, j, kk);
+        else if (M.ndim == 2) xtoijk<2>(M, B, S.x[p], S.y[p], S.z[p], i, j, kk);
+        else xtoijk<3>(M, B, S.x[p], S.y[p], S.z[p], i, j, kk);
+        i = i < 0 ? 0 : (i >= M.ni ? M.ni - 1 : i);
+        j = j < 0 ? 0 : (j >= M.nj ? M.nj - 1 : j);
+        kk = kk < 0 ? 0 : (kk >= M.nk ? M.nk - 1 : kk);
+        k = (unsigned)b * (unsigned)M.ntot + (unsigned)cidx(M, kk, j, i);
+      }
+      key[p] = k;
+    }
+    int head, len;
+    run_of(k, active, lane, head, len);
+    if (active && lane == head) atomicAdd(&hist[k], (unsigned)len);
+  }
+}
+
+// In-place exclusive scan of `data` in tiles of kScanTile elements (one workgroup each); the tile
+// totals go to `sums`, which k_scan_sums scans and k_scan_add adds back.
+constexpr int kScanItems = 8, kScanTile = kBlock * kScanItems;
+__global__ void __launch_bounds__(kBlock) k_scan_tiles(unsigned *data, long long n, unsigned *sums) {
+  __shared__ unsigned wave_tot[kBlock / 64];
+  const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+  unsigned v[kScanItems], mine = 0u;
+#pragma unroll
+  for (int q = 0; q < kScanItems; ++q) {
+    v[q] = base + q < n ? data[base + q] : 0u;
+    mine += v[q];
+  }
+  // exclusive scan of `mine` over the workgroup: wave shuffles, then the wave totals through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  unsigned before = 0u, total = 0u;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    if (w < wave) before += wave_tot[w];
+    total += wave_tot[w];
+  }
+  unsigned run = before + incl - mine;
+#pragma unroll
+  for (int q = 0; q < kScanItems; ++q) {
+    if (base + q < n) data[base + q] = run;
+    run += v[q];
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(1024) k_scan_sums(unsigned *sums, int count) {
+  // one workgroup, any count: a running offset carried from one stretch of 1024 entries to the next
+  __shared__ unsigned wave_tot[16];
+  __shared__ unsigned carry;
+  if (threadIdx.x == 0) carry = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int s0 = 0; s0 < count; s0 += 1024) {
+    const int q = s0 + (int)threadIdx.x;
+    const unsigned mine = q < count ? sums[q] : 0u;
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned before = 0u, total = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) before += wave_tot[w];
+      total += wave_tot[w];
+    }
+    const unsigned off = carry;
+    if (q < count) sums[q] = off + before + incl - mine;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = off + total;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_scan_add(unsigned *data, long long n, const unsigned *sums) {
+  const unsigned add = sums[blockIdx.x];
+  const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+#pragma unroll
+  for (int q = 0; q < kScanItems; ++q)
+    if (base + q < n) data[base + q] += add;
+}
+
+// The move goes through an array of 128-byte particle records in device scratch memory: moving a
+// photon then costs ONE out-of-order access of a full line instead of sixteen 8-byte ones (after a
+// few cycles a photon's new slot is millions of slots from its old one: measured per 1e8 photons,
+// sixteen scattered stores 47.6 ms, sixteen scattered loads 34.8 ms, the histogram 3.8 ms).
+//   k_sort_pack:   slot s, read in order -> record at the photon's new position (8 x 16 B, one line)
+//   k_sort_unpack: records in order -> the swarm arrays, written in order -- the SAME arrays
+// record: {x, y} {z, vx} {vy, vz} {t, w} {e, id} {rng, ip | jp << 32} {kp | blk << 32, status} {-, -}
+constexpr int kSortRecWords = 16;  // 8-byte words per record
+__global__ void __launch_bounds__(kBlock)
+    k_sort_pack(DevSwarm S, long long n, const unsigned *key, unsigned *offs, unsigned long long *rec) {
+  typedef unsigned long long u64;
+  typedef u64 v2u __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) - lane;
+  for (long long base = wave0; base < n; base += (long long)gridDim.x * blockDim.x) {
+    const long long s = base + lane;
+    const bool active = s < n;
+    const unsigned k = active ? key[s] : 0u;
+    int head, len;
+    run_of(k, active, lane, head, len);
+    unsigned first = 0u;
+    if (active && lane == head) first = atomicAdd(&offs[k], (unsigned)len);   // (one claim per run)
+    first = __shfl(first, head, 64);
+    if (active) {
+      v2u *o = (v2u *)(rec + (size_t)kSortRecWords * ((size_t)first + (size_t)(lane - head)));
+      auto bits = [](double v) { return (u64)__double_as_longlong(v); };
+      o[0] = v2u{bits(S.x[s]), bits(S.y[s])};
+      o[1] = v2u{bits(S.z[s]), bits(S.vx[s])};
+      o[2] = v2u{bits(S.vy[s]), bits(S.vz[s])};
+      o[3] = v2u{bits(S.t[s]), bits(S.w[s])};
+      o[4] = v2u{bits(S.e[s]), (u64)S.id[s]};
+      o[5] = v2u{(u64)S.rng[s], (u64)(unsigned)S.ip[s] | ((u64)(unsigned)S.jp[s] << 32)};
+      o[6] = v2u{(u64)(unsigned)S.kp[s] | ((u64)(unsigned)S.blk[s] << 32), (u64)(unsigned)S.status[s]};
+      o[7] = v2u{0ull, 0ull};
+    }
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+    k_sort_unpack(DevSwarm D, long long n, const unsigned long long *rec) {
+  typedef unsigned long long u64;
+  typedef u64 v2u __attribute__((ext_vector_type(2)));
+  for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < n;
+       d += (long long)gridDim.x * blockDim.x) {
+    const v2u *r = (const v2u *)(rec + (size_t)kSortRecWords * (size_t)d);
+    const v2u a = r[0], b = r[1], c = r[2], e = r[3], f = r[4], g = r[5], h = r[6];
+    auto dbl = [](u64 v) { return __longlong_as_double((long long)v); };
+    D.x[d] = dbl(a.x); D.y[d] = dbl(a.y); D.z[d] = dbl(b.x);
+    D.vx[d] = dbl(b.y); D.vy[d] = dbl(c.x); D.vz[d] = dbl(c.y);
+    D.t[d] = dbl(e.x); D.w[d] = dbl(e.y); D.e[d] = dbl(f.x);
+    D.id[d] = f.y; D.rng[d] = g.x;
+    D.ip[d] = (int)(unsigned)g.y; D.jp[d] = (int)(unsigned)(g.y >> 32);
+    D.kp[d] = (int)(unsigned)h.x; D.blk[d] = (int)(unsigned)(h.x >> 32);
+    D.status[d] = (int)(unsigned)h.y;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // Inter-rank hand-off records: 13 x 8 bytes
 //   0..8  x y z vx vy vz t w e   9 id   10 (ip | jp << 32)   11 (kp | gblock << 32)   12 rng state
 constexpr int kRecWords = 13;

@@ -217,6 +217,10 @@ class MeshData:
         # measurement aid (bench.py --force-exchange): run the hand-off phase of the iterate-sublist
         # also when this rank holds the whole mesh (nothing moves; its fixed cost becomes visible)
         self.force_exchange = False
+        # DefragParticles after every k-th RadiationStep (0: never; the reference schedules none)
+        self.defrag_interval = 0
+        self.defrags = 0
+        self._steps_since_defrag = 0
         self._make_mesh_handle(owner)
 
     def reserve(self, nslots: int) -> None:
@@ -449,8 +453,17 @@ def RemoveMarkedParticles(md: MeshData) -> int:
 
 
 def DefragParticles(md: MeshData) -> TaskStatus:
-    """reference jaybenne.cpp:499-509 (never scheduled by the reference either); the swarm here
-    is always compact after RemoveMarkedParticles, so there is nothing to defragment."""
+    """reference jaybenne.cpp:499-509 (``Swarm::Defrag``; scheduled by no task list of the
+    reference).  The swarm here is always compact after RemoveMarkedParticles; what this task
+    restores is its *order*: the photons sorted by (block, cell), as they are sourced -- the order
+    that keeps the cell data a wave gathers in the L2 of its XCD, and that diffusion loosens from
+    cycle to cycle (include/jaybenne_amd.h: ``jb_defrag_particles``; in place).
+    ``MeshData.defrag_interval = k`` makes RadiationStep schedule it after every k-th cycle."""
+    if md.n == 0:
+        return TaskStatus.complete
+    md._sync_stream()
+    _lib.check(md.lib.jb_defrag_particles(md.pkg.ctx, md.handle, C.byref(md.sv)))
+    md.defrags += 1
     return TaskStatus.complete
 
 
@@ -593,4 +606,8 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
             RemoveMarkedParticles(md)
         md.events += after["n_events"] - before["n_events"]
         UpdateFluid(md)
+        md._steps_since_defrag += 1
+        if md.defrag_interval > 0 and md._steps_since_defrag >= md.defrag_interval:
+            DefragParticles(md)
+            md._steps_since_defrag = 0
     return TaskStatus.complete

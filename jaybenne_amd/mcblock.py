@@ -203,6 +203,9 @@ class McblockDriver:
         share = self.pkg.Param("num_particles") * n_local_blocks / self.mesh.nblocks
         capacity = int(share * capacity_factor) + 4096
         self.md = jb.MeshData(self.pkg, self.mesh, capacity, rank, nranks, comm, halo_rings)
+        # (not a parameter of the reference: DefragParticles -- here a sort of the swarm by cell, for
+        # the locality of the cell gathers -- after every k-th cycle; 0 = never, as the reference)
+        self.md.defrag_interval = pin.GetOrAddInteger("jaybenne", "defrag_interval", 0)
         self.tlim = pin.GetReal("parthenon/time", "tlim")
         self.nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1)
         self.time = 0.0

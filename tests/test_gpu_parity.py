@@ -391,6 +391,51 @@ def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel
     assert drv.md.events == O.events
 
 
+@pytest.mark.parametrize("deck,overrides,cycles", [CASES[0], CASES[5], CASES[8], CASES[9]])
+def test_defrag_particles_restores_cell_order_and_changes_nothing_else(gpu_device, deck, overrides, cycles):
+    """DefragParticles (reference jaybenne.cpp:499-509; here a counting sort of the swarm by
+    block and cell, for the locality of the cell gathers) after every cycle: every photon, found by
+    its creation id, ends with the same bits as in a run without it -- and as in the oracle --,
+    the fields agree, and the swarm comes out ordered by (block, cell)."""
+    from oracle import orc
+    from jaybenne_amd import jaybenne as jb
+    pin = load_deck(deck, overrides)
+    drv = _gpu_problem(pin, gpu_device)
+    drv.md.defrag_interval = 1
+    O, mesh, _ = make_oracle(load_deck(deck, overrides), orc.MATH_PORTABLE)
+    ncyc = cycles + 1
+    for _ in range(ncyc):
+        drv.Step()
+    run_oracle_cycles(O, pin, ncyc)
+    assert drv.md.defrags == ncyc
+    g = drv.md.get_swarm()
+    assert drv.md.n == O.n and drv.md.events == O.events
+    order_g = np.argsort(g["id"], kind="stable")
+    order_o = np.argsort(O.sw["id"][:O.n], kind="stable")
+    assert np.array_equal(g["id"][order_g], O.sw["id"][:O.n][order_o])
+    for k in g:
+        a, b = g[k][order_g], O.sw[k][:O.n][order_o]
+        assert np.array_equal(a, b), f"particle attribute {k} differs from the oracle after DefragParticles"
+    _compare_fields(drv.md, O)
+    # sorted by (block, cell of the position): the key the sort used, recomputed here
+    m = drv.mesh
+    b = g["blk"].astype(np.int64)
+    cell = np.zeros(len(b), dtype=np.int64)
+    stride = 1
+    for d, name in enumerate("xyz"):
+        if d < m.ndim:
+            idx = np.floor((g[name] - m.blk_xmin[b, d]) * (1.0 / m.blk_dx[b, d])).astype(np.int64) + m.is_[d]
+        else:
+            idx = np.full(len(b), m.is_[d], dtype=np.int64)
+        cell += stride * idx
+        stride *= m.field_shape[3 - d]
+    key = b * int(np.prod(m.field_shape[1:])) + cell
+    assert np.all(np.diff(key) >= 0)
+    # ... and an empty swarm is left alone
+    drv.md.sv.n = 0
+    assert jb.DefragParticles(drv.md) == jb.TaskStatus.complete
+
+
 def test_all_ddmc_mesh_runs_the_lean_kernel(gpu_device):
     for deck, want in (("stepdiff_ddmc", "k_ddmc_all<1"), ("stepdiff_smr_hybrid", "k_hybrid<2"),
                        ("stepdiff_smr_ddmc", "k_ddmc_all<2"), ("stepdiff", "k_transport<1")):
