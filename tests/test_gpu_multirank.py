@@ -35,6 +35,9 @@ CASES = [
     # resident count (the relocation path must not index per-resident-block tables with it)
     ("stepdiff_ddmc", {"jaybenne/num_particles": 20000, "parthenon/mesh/nx1": 128,
                        "parthenon/meshblock/nx1": 4}, 2),
+    # DefragParticles (every rank sorts its part of the swarm by block and cell) after every cycle:
+    # arrivals are appended behind a sorted swarm, local block indices include the halo copies
+    ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 20000, "jaybenne/defrag_interval": 1}, 3),
 ]
 
 
