@@ -222,7 +222,9 @@ jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swa
  *   JB_ARITH_LEAN (default): while a lane follows a photon it carries the unit direction v / c and
  *     the distance left to census c (t_end - t) instead of v and t; distance to a face as
  *     (face - x) times a once-refined reciprocal of the direction component (within 2^-48, ~20 ulp,
- *     of the correctly rounded quotient), position update as one fused multiply-add per axis,
+ *     of the correctly rounded quotient; in 3-D the three reciprocals come from one, of the product
+ *     of the components: 1 / ox = oy oz / (ox oy oz), to the same accuracy), position update as one
+ *     fused multiply-add per axis,
  *     logarithm without its compensated sum (<= 3 ulp), square root of 1 - mu^2 with one residual
  *     correction (<= 2 ulp) -- every operation within 4e-15 (relative) of the exact variant's; and,
  *     per axis, only the face the photon moves TOWARDS is tested for the nudge of

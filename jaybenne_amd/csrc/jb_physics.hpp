@@ -346,9 +346,33 @@ __device__ __forceinline__ void imc_step_dir(DirGeom &g, double dx_push0, double
   const double fx = dir_face<EXACTG>(g, 0, ip, upx, iux);
   const double fy = multi_d ? dir_face<EXACTG>(g, 1, jp, upy, iuy) : 0.0;
   const double fz = three_d ? dir_face<EXACTG>(g, 2, kp, upz, iuz) : 0.0;
-  dx_push = m_min(dx_push, (fx - x) * m_rcp_once(ox));
-  if (multi_d) dx_push = m_min(dx_push, (fy - y) * m_rcp_once(oy));
-  if (three_d) dx_push = m_min(dx_push, (fz - z) * m_rcp_once(oz));
+#ifndef JB_NO_PRODUCT_RCP
+  if constexpr (three_d) {
+    // The three reciprocals from ONE hardware reciprocal, of the product of the components: 1 / ox =
+    // (oy oz) / (ox oy oz) etc. -- one quarter-rate instruction (16 cycles) instead of three, at
+    // 10 instructions instead of 9; each quotient within ~4e-15 of the exact one, as before.  A
+    // component that is zero (or a product that underflows) takes the three separate reciprocals,
+    // whose NaN for a zero component is what minNum then ignores (see above).  (In 2-D the same
+    // trick, one reciprocal instead of two, was measured slower: +0.9 % on C4, +3 % on C5.)
+    const double pxy = ox * oy, q = pxy * oz;
+    double rx, ry, rz;
+    if (fabs(q) > 1.0e-250) {
+      const double r = m_rcp_once(q);
+      const double roz = r * oz;
+      rz = r * pxy; rx = roz * oy; ry = roz * ox;
+    } else {
+      rx = m_rcp_once(ox); ry = m_rcp_once(oy); rz = m_rcp_once(oz);
+    }
+    dx_push = m_min(dx_push, (fx - x) * rx);
+    dx_push = m_min(dx_push, (fy - y) * ry);
+    dx_push = m_min(dx_push, (fz - z) * rz);
+  } else
+#endif
+  {
+    dx_push = m_min(dx_push, (fx - x) * m_rcp_once(ox));
+    if (multi_d) dx_push = m_min(dx_push, (fy - y) * m_rcp_once(oy));
+    if (three_d) dx_push = m_min(dx_push, (fz - z) * m_rcp_once(oz));
+  }
   is_absorbed = NOABS ? false : (dx_abs < dx_push) && (dx_abs < dx_sc);
   is_scattered = !is_absorbed && (dx_sc < dx_push);
   const double dx_move =
