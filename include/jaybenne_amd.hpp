@@ -105,6 +105,8 @@ class MeshData {
   uint64_t next_id = 0;    // first unused random-stream id
   uint32_t epoch = 0;      // source-call counter (keys the per-cell rounding streams)
   int64_t events = 0;      // tracking events so far
+  int defrag_interval = 0;      // DefragParticles after every k-th RadiationStep (0: never, as the reference)
+  int steps_since_defrag = 0;
 
  private:
   std::shared_ptr<StateDescriptor> pkg_;
@@ -210,6 +212,11 @@ inline TaskStatus EvaluateRadiationEnergy(MeshData *md) {
   return Check(jb_evaluate_radiation_energy(md->ctx(), md->mesh(), &md->swarm));
 }
 inline TaskStatus UpdateFluid(MeshData *md) { return Check(jb_update_fluid(md->ctx(), md->mesh())); }
+// jaybenne::DefragParticles -- jaybenne.cpp:499-509 (scheduled by no task list of the reference):
+// the swarm sorted by block and cell, in place (jaybenne_amd.h: jb_defrag_particles)
+inline TaskStatus DefragParticles(MeshData *md) {
+  return Check(jb_defrag_particles(md->ctx(), md->mesh(), &md->swarm));
+}
 inline Real EstimateTimestepMesh(MeshData *md) { return jb_estimate_timestep(md->ctx()); }
 
 // jaybenne::InitializeRadiation(mbd, is_thermal) -- jaybenne.cpp:570-578
@@ -236,6 +243,11 @@ inline TaskStatus RadiationStep(MeshData *md, const Real t_start, const Real dt)
   md->events += after.n_events - before.n_events;
   if (CheckCompletion(md, t_start + dt) != TaskStatus::complete) return TaskStatus::iterate;
   UpdateFluid(md);
+  // (not in the reference's task list: DefragParticles after every defrag_interval-th cycle)
+  if (md->defrag_interval > 0 && ++md->steps_since_defrag >= md->defrag_interval) {
+    DefragParticles(md);
+    md->steps_since_defrag = 0;
+  }
   return TaskStatus::complete;
 }
 

@@ -153,7 +153,9 @@ def test_full_size_c3_profile(gpu_device, capsys):
     ("stepdiff_smr_ddmc", ["parthenon/mesh/nx1=32", "parthenon/mesh/nx2=16", "parthenon/mesh/nx3=16",
                            "parthenon/meshblock/nx1=8", "parthenon/meshblock/nx2=8",
                            "parthenon/meshblock/nx3=8", "jaybenne/num_particles=30000",
-                           "parthenon/time/nlim=2"])])                                   # 3-D, 72 blocks
+                           "parthenon/time/nlim=2"]),                                    # 3-D, 72 blocks
+    ("stepdiff_smr_hybrid", ["jaybenne/num_particles=30000", "parthenon/time/nlim=4",
+                             "jaybenne/defrag_interval=2"])])   # DefragParticles after cycles 2 and 4
 def test_native_cpp_host_application(gpu_device, tmp_path, deck, overrides):
     """examples/mcblock_amd: the C++ host application on include/jaybenne_amd.hpp (deck parser,
     uniform mesh, device buffers through the HIP runtime, cycle loop) -- no Python, no PyTorch in
