@@ -438,6 +438,7 @@ def main() -> None:
                       "(BASELINE.json configs[4])"}[args.workload],
                        "blocks_per_gpu": md.nowned, "halo_blocks_per_gpu": md.nblocks - md.nowned,
                        "particles_per_gpu": args.particles_per_gpu,
+                       "defrag_interval": int(args.defrag_interval),
                        "parallelism": f"meshblocks over {args.gpus} rank(s), "
                                       f"{'RCCL' if backend == 'nccl' else backend} particle hand-off"},
             "events_per_s": events / wall,

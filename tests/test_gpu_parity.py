@@ -772,6 +772,12 @@ def test_c_abi_error_paths(gpu_device):
         _lib.check(st)
     # bad face
     assert lib.jb_photon_reflect_bc(md.pkg.ctx, md.handle, C.byref(md.sv), 7) == _lib.JB_ERR_INVALID
+    # DefragParticles: null mesh, a swarm view that claims more particles than it has room for
+    assert lib.jb_defrag_particles(md.pkg.ctx, None, C.byref(md.sv)) == _lib.JB_ERR_INVALID
+    bad = _lib.SwarmView(n=md.capacity + 1, capacity=md.capacity)
+    for name in ("x", "y", "z", "vx", "vy", "vz", "t", "w", "e", "ip", "jp", "kp", "blk", "status", "id", "rng"):
+        setattr(bad, name, getattr(md.sv, name))
+    assert lib.jb_defrag_particles(md.pkg.ctx, md.handle, C.byref(bad)) == _lib.JB_ERR_INVALID
     # field refresh: unknown field, sample count that is not 1 / 2 / 4 / 8, empty request
     idx = torch.zeros(4, dtype=torch.int32, device=gpu_device)
     val = torch.zeros(4, dtype=torch.float64, device=gpu_device)
