@@ -714,6 +714,10 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
     /* (the dynamic LDS -- tally and record table of a small mesh -- changes with the mesh: ask per launch) */ \
     int oc = 0;                                                                                             \
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, k_ddmc_all<NDIM, TL, CO>, kBlock, lds_tally_bytes) != hipSuccess || oc < 1) oc = 3; \
+    /* (four 16-byte loads per lane on a table that does not sit in L1 -- only a table of >= 4 GiB, or  \
+       JB_COOP_GATHER=0, gets here -- saturate the vector L1's look-ups: a fourth wave per SIMD then  \
+       costs time, 38.2 against 31.5 ms per 1e8 histories on the 160 MB table) */                      \
+    if ((CO) == 0 && rec_bytes >= (1ull << 20) && oc > 3) oc = 3;                                           \
     const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : oc);                            \
     hipLaunchKernelGGL((k_ddmc_all<NDIM, TL, CO>), dim3(g), dim3(kBlock), lds_tally_bytes, ctx->stream, mesh->dm_dev, ctx->dp, S, \
                        t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc, handed, n_handed); \
