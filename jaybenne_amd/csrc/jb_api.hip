@@ -57,7 +57,7 @@ struct jb_context {
   bool lean_arith = true;
   int blocks_per_cu_env = 0;  // JB_TRANSPORT_BLOCKS_PER_CU at jb_initialize (tuning aid), 0 = occupancy query
   bool no_ddmc_all = false;   // JB_NO_DDMC_ALL=1 at jb_initialize (tests: k_hybrid on all-DDMC meshes)
-  int coop_gather = -1;       // JB_COOP_GATHER=0 / 1: k_ddmc_all's quad-cooperative gather off / on whatever the table size
+  int coop_gather = -1;       // JB_COOP_GATHER=0 / 1 / 2: k_ddmc_all's quad-cooperative gather off / on / on with 64-bit addresses, whatever the table size
 };
 constexpr int kCounterWords = 1024;  // CNT_N.. | 16..17 cursors | 32.. per-rank counts (<= 480 ranks)
 constexpr int kCursorBase = 16;
@@ -139,7 +139,7 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   }
   if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) ctx->blocks_per_cu_env = atoi(e);
   if (const char *e = getenv("JB_NO_DDMC_ALL")) ctx->no_ddmc_all = e[0] == '1';
-  if (const char *e = getenv("JB_COOP_GATHER")) ctx->coop_gather = e[0] == '1' ? 1 : 0;  // (tests, A/B runs)
+  if (const char *e = getenv("JB_COOP_GATHER")) ctx->coop_gather = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);  // (tests, A/B runs)
   ctx->dp.key0 = (uint32_t)params->seed;  // RngPool rng_pool(seed): unadjusted (quirk 1)
   ctx->dp.use_ddmc = params->use_ddmc;
   ctx->dp.do_feedback = params->do_feedback;
@@ -688,12 +688,15 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         // 1e8 histories: 128^3 cells 31.5 -> 27.9, 64^3 7.2 -> 6.9, 32^3 equal, 128 cells in 1-D
         // 11.6 -> 13.1: there every lookup hits L1 and the detour through LDS only adds latency).
         const unsigned long long rec_bytes = 64ull * (unsigned long long)M.ntot * (unsigned long long)M.nblocks;
-        const bool coop = rec_bytes < (1ull << 32) &&
-                          (ctx->coop_gather >= 0 ? ctx->coop_gather == 1 : rec_bytes >= (1ull << 20));
+        // (record numbers are 32-bit: fewer than 2^32 resident cells; 64-bit addresses when the records
+        // span 4 GiB or more -- JB_COOP_GATHER=2 forces that form on any table, for the parity tests)
+        const bool coop = rec_bytes < (64ull << 32) &&
+                          (ctx->coop_gather >= 0 ? ctx->coop_gather >= 1 : rec_bytes >= (1ull << 20));
+        const bool wide = coop && (rec_bytes >= (1ull << 32) || ctx->coop_gather == 2);
         // ... and a mesh of at most kLdsRecCells cells (the reference's 1-D decks) keeps its records in
         // LDS: 12.0 -> ?? ms per 1e8 histories on BASELINE configs[2] as shipped
         const bool in_lds = !coop && ctx->coop_gather < 0 && (long long)M.nblocks * M.ntot <= (long long)kLdsRecCells;
-        const int gather = coop ? 1 : (in_lds ? 2 : 0);
+        const int gather = coop ? (wide ? 3 : 1) : (in_lds ? 2 : 0);
         // A particle that sits at a face of its cell when it is loaded or relocated (one in ~1e8) needs
         // the albedo step: k_ddmc_all lists it, and k_hybrid<.., both loops>, launched behind it on
         // that list (its length read on the device: no synchronisation), tracks it to the end.
@@ -737,16 +740,18 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
              {"k_ddmc_all<2, true>", "k_ddmc_all<2, true, quad gather>", "k_ddmc_all<2, true, records in LDS>"}},
             {{"k_ddmc_all<3, false>", "k_ddmc_all<3, false, quad gather>", "k_ddmc_all<3, false, records in LDS>"},
              {"k_ddmc_all<3, true>", "k_ddmc_all<3, true, quad gather>", "k_ddmc_all<3, true, records in LDS>"}}};
-        mesh->last_variant = names[NDIM - 1][tally ? 1 : 0][gather];
+        mesh->last_variant = names[NDIM - 1][tally ? 1 : 0][gather == 3 ? 1 : gather];
         if (tally) {
           if (gather == 1) JB_LAUNCH_DDMC_ALL(true, 1);
           else if (gather == 2) JB_LAUNCH_DDMC_ALL(true, 2);
+          else if (gather == 3) JB_LAUNCH_DDMC_ALL(true, 3);
           else JB_LAUNCH_DDMC_ALL(true, 0);
           if (noabs_h) JB_LAUNCH_HANDED(true, true);
           else JB_LAUNCH_HANDED(true, false);
         } else {
           if (gather == 1) JB_LAUNCH_DDMC_ALL(false, 1);
           else if (gather == 2) JB_LAUNCH_DDMC_ALL(false, 2);
+          else if (gather == 3) JB_LAUNCH_DDMC_ALL(false, 3);
           else JB_LAUNCH_DDMC_ALL(false, 0);
           if (noabs_h) JB_LAUNCH_HANDED(false, true);
           else JB_LAUNCH_HANDED(false, false);

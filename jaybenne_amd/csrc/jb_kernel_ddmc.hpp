@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   const double t_start = A.t_start, dt = A.dt;
   const long long first = A.first, last = A.last;
   unsigned long long *const counters = g1(A.counters);
-  constexpr bool COOP = GATHER == 1;
+  constexpr bool COOP = GATHER == 1 || GATHER == 3;   // (3: COOP with 64-bit addresses, records >= 4 GiB)
   // (the LDS tally of a small mesh -- all resident blocks' cells, <= kLdsTally -- and the LDS copy
   // of its step records are dynamic shared memory, sized by the launch: a mesh that uses neither
   // leaves the room to a fourth workgroup per CU)
@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   fill_block_table(M, lds_blocks);
   load_math_tables<true, false, false, true>();  // logarithm, sincos of 2 pi u (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2;
+  constexpr bool coop_wide = GATHER == 3;
   constexpr int kBudget = JB_DDMC_ALL_BUDGET;
   constexpr long long kChunk = JB_DDMC_ALL_CHUNK;
   const double vv = P.c;
@@ -472,12 +473,21 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       c_ev += (unsigned int)nrun;
       if constexpr (COOP) {
         // (every lane takes part; one without a particle in the loop asks for record 0)
-        const unsigned off = ls == DS_VIRT ? ((unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip)) << 6 : 0u;
+        const unsigned rec = ls == DS_VIRT ? (unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip) : 0u;
         typedef const __attribute__((address_space(1))) void *gvoid;
-        __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<0>(off, sub16)), wave_buf, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<1>(off, sub16)), wave_buf + 1024, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<2>(off, sub16)), wave_buf + 2048, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<3>(off, sub16)), wave_buf + 3072, 16, 0, 0);
+        if constexpr (!coop_wide) {  // the records span < 4 GiB: 32-bit byte offsets from a scalar base
+          const unsigned off = rec << 6;
+          __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<0>(off, sub16)), wave_buf, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<1>(off, sub16)), wave_buf + 1024, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<2>(off, sub16)), wave_buf + 2048, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<3>(off, sub16)), wave_buf + 3072, 16, 0, 0);
+        } else {           // ... or more (> 67e6 resident cells): the record number travels, 64-bit addresses
+          const char *const mine = (const char *)step_base + sub16;
+          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<0>(rec, 0u) << 6)), wave_buf, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<1>(rec, 0u) << 6)), wave_buf + 1024, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<2>(rec, 0u) << 6)), wave_buf + 2048, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<3>(rec, 0u) << 6)), wave_buf + 3072, 16, 0, 0);
+        }
       }
       if (ls == DS_VIRT) {
         DdmcStepRec r;

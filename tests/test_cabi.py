@@ -175,7 +175,7 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
     # the all-DDMC kernel is bound by the latency of its gathers and runs FOUR waves per SIMD:
     # 128 registers, and at most 40 KB of LDS per workgroup (its LDS tally is dynamic shared memory)
     ddmc = {n: v for n, v in found.items() if "k_ddmc_all" in n}
-    assert len(ddmc) == 18
+    assert len(ddmc) == 24
     for n, (vgpr, scratch) in ddmc.items():
         assert vgpr <= 128 and scratch == 0, (n, vgpr, scratch)
         lds = int(re.search(r"\.amdhsa_kernel %s.*?\.amdhsa_group_segment_fixed_size (\d+)" % re.escape(n), text, re.S).group(1))

@@ -324,14 +324,16 @@ def test_general_kernel_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, 
     assert drv.md.events == O.events
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
 @pytest.mark.parametrize("deck,overrides,cycles", [c for c in CASES if c[0].endswith("_ddmc")])
-def test_quad_cooperative_gather_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, monkeypatch):
+def test_quad_cooperative_gather_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, form, monkeypatch):
     """k_ddmc_all fetches its step records either with four loads per lane or, once the records of
     the resident blocks exceed 1 MiB (BASELINE configs[2] in 3-D: 160 MB), with the four lanes of a
     quad sharing the fetch of each record through LDS.  The test decks are far below that size:
-    force the second form on them -- same bits."""
+    force the second form on them -- same bits -- with 32-bit byte offsets ("1") and with the 64-bit
+    addresses it uses once the records span 4 GiB or more ("2")."""
     from oracle import orc
-    monkeypatch.setenv("JB_COOP_GATHER", "1")
+    monkeypatch.setenv("JB_COOP_GATHER", form)
     pin = load_deck(deck, overrides)
     drv = _gpu_problem(pin, gpu_device)
     O, mesh, _ = make_oracle(load_deck(deck, overrides), orc.MATH_PORTABLE)
