@@ -674,6 +674,34 @@ def test_separate_tasks_match_fused_step(gpu_device):
         assert np.array_equal(ga[k], gb[k]), k
 
 
+@pytest.mark.parametrize("deck,overrides,coop", [
+    ("stepdiff_ddmc", {"jaybenne/num_particles": 20000}, None),        # 1-D: records in LDS
+    (CASES[9][0], CASES[9][1], "1"),                                    # 3-D, quad-cooperative gather
+    (CASES[9][0], CASES[9][1], "0"),                                    # 3-D, four loads per lane
+    ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 30000}, None),  # IMC / DDMC hybrid: k_hybrid
+])
+def test_separate_tasks_match_fused_step_ddmc(gpu_device, deck, overrides, coop, monkeypatch):
+    """The same for TransportPhotons_DDMC: the kernels without the fused census tally
+    (k_ddmc_all<.., TALLY = false, ..>, k_hybrid<.., false, ..>: what a host that schedules
+    EvaluateRadiationEnergy as its own task runs, e.g. examples/handoff_mpi.cpp) leave the same
+    particles, and the separate tally task the same tally, as the fused step."""
+    from jaybenne_amd import jaybenne as jb
+    if coop is not None:
+        monkeypatch.setenv("JB_COOP_GATHER", coop)
+    a = _gpu_problem(load_deck(deck, overrides), gpu_device)
+    b = _gpu_problem(load_deck(deck, overrides), gpu_device)
+    a.Step()
+    dt = b.dt
+    jb.UpdateDerivedTransportFields(b.md, dt)
+    jb.TransportPhotons_DDMC(b.md, 0.0, dt)
+    assert jb.CheckCompletion(b.md, dt) == jb.TaskStatus.complete
+    jb.EvaluateRadiationEnergy(b.md)
+    np.testing.assert_allclose(a.md.get_field("tally"), b.md.get_field("tally"), rtol=1e-12)
+    ga, gb = a.md.get_swarm(), b.md.get_swarm()
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+
+
 # ------------------------------------------------------------------------------------------------
 def test_ddmc_face_probabilities_match_oracle(gpu_device):
     """UpdateDerivedTransportFields, DDMC part (jaybenne.cpp:319-489) on a 2-level mesh: interior
