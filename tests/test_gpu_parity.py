@@ -346,7 +346,7 @@ def test_quad_cooperative_gather_on_all_ddmc_meshes(gpu_device, deck, overrides,
     assert drv.md.events == O.events
 
 
-@pytest.mark.parametrize("coop", ["0", "1"])
+@pytest.mark.parametrize("coop", ["0", "1", "2", "lds"])
 def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel(gpu_device, coop, monkeypatch):
     """k_ddmc_all's event loop starts every step from the cell centre, which is what the albedo
     step leaves behind unless the photon sits within 2.5 eps_imc dx of a face of its cell
@@ -358,8 +358,11 @@ def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel
     into the neighbouring cell."""
     import torch
     from oracle import orc
-    monkeypatch.setenv("JB_COOP_GATHER", coop)
-    deck, ov, _ = [c for c in CASES if c[0] == "stepdiff_ddmc" and "parthenon/mesh/nx3" in c[1]][0]
+    if coop == "lds":   # the 1-D deck as shipped: 136 cells, step records in LDS
+        deck, ov = "stepdiff_ddmc", {"jaybenne/num_particles": 20000}
+    else:
+        monkeypatch.setenv("JB_COOP_GATHER", coop)
+        deck, ov, _ = [c for c in CASES if c[0] == "stepdiff_ddmc" and "parthenon/mesh/nx3" in c[1]][0]
     pin = load_deck(deck, ov)
     drv = _gpu_problem(pin, gpu_device)
     O, mesh, _ = make_oracle(load_deck(deck, ov), orc.MATH_PORTABLE)
@@ -370,7 +373,7 @@ def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel
     moved = 0
     for k, q in enumerate(sel):
         b = int(O.sw["blk"][q])
-        axis, upper = k % 3, (k // 3) % 2
+        axis, upper = k % mesh.ndim, (k // 3) % 2
         name = "xyz"[axis]
         dx = mesh.blk_dx[b, axis]
         cell = np.floor((O.sw[name][q] - mesh.blk_xmin[b, axis]) / dx)
@@ -387,7 +390,8 @@ def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel
     for _ in range(2):
         drv.Step()
     run_oracle_cycles(O, pin, 2)
-    assert "k_ddmc_all<3" in drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
+    variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
+    assert ("k_ddmc_all<1, true, records in LDS>" if coop == "lds" else "k_ddmc_all<3") in variant
     _compare_swarm(drv.md, O)
     _compare_fields(drv.md, O)
     assert drv.md.events == O.events
