@@ -345,7 +345,8 @@ def main() -> None:
                 # arguments = a kernel from before the lean variant existed, i.e. exact arithmetic)
                 kargs = tr.get("kernel", "").split("<")[-1].rstrip("> ").split(",")
                 tr_lean = len(kargs) == 6 and kargs[-1].strip() == "true"
-                same_arith = tr_lean == variant.endswith("true>") or "k_ddmc_all" in tr.get("kernel", "")
+                tr_lean = tr_lean or kargs[-1].strip() == "lean"
+                same_arith = tr_lean == variant.endswith(("true>", "lean>")) or "k_ddmc_all" in tr.get("kernel", "")
                 if (tr["workload"] == args.workload and tr["particles_per_gpu"] == args.particles_per_gpu
                         and args.block_nx == 64 and args.gpus == 1 and same_arith):
                     pmc, pmc_file = tr, os.path.relpath(f, ROOT)

@@ -17,6 +17,7 @@
 #include "../../include/jaybenne_amd.h"
 #include "jb_kernels.hpp"
 #include "jb_kernel_hybrid.hpp"
+#include "jb_kernel_imc.hpp"
 
 using namespace jb;
 
@@ -58,6 +59,7 @@ struct jb_context {
   int blocks_per_cu_env = 0;  // JB_TRANSPORT_BLOCKS_PER_CU at jb_initialize (tuning aid), 0 = occupancy query
   bool no_ddmc_all = false;   // JB_NO_DDMC_ALL=1 at jb_initialize (tests: k_hybrid on all-DDMC meshes)
   int coop_gather = -1;       // JB_COOP_GATHER=0 / 1 / 2: k_ddmc_all's quad-cooperative gather off / on / on with 64-bit addresses, whatever the table size
+  bool no_imc_cell = false;   // JB_NO_IMC_CELL=1 at jb_initialize (tests, A/B): the lean step in x-space (k_transport<.., LEAN>) instead of k_imc_cell
 };
 constexpr int kCounterWords = 1024;  // CNT_N.. | 16..17 cursors | 32.. per-rank counts (<= 480 ranks)
 constexpr int kCursorBase = 16;
@@ -74,6 +76,7 @@ struct jb_mesh {
   const char *last_variant = "";  // the k_transport instantiation launched last
   const char *last_pair = "";     // ... and the k_ddmc_all launched beside it (gray DDMC), or ""
   const DevMesh *dm_dev = nullptr;  // copy of dm in device memory (k_hybrid reads the view through it)
+  const int *nbr_dq = nullptr;      // k_imc_cell: change of the cell's byte offset per (block, face) crossing
 };
 
 __global__ void k_rcp_refined(double b, double *out) { *out = m_rcp_refined(b); }
@@ -139,6 +142,7 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   }
   if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) ctx->blocks_per_cu_env = atoi(e);
   if (const char *e = getenv("JB_NO_DDMC_ALL")) ctx->no_ddmc_all = e[0] == '1';
+  if (const char *e = getenv("JB_NO_IMC_CELL")) ctx->no_imc_cell = e[0] == '1';
   if (const char *e = getenv("JB_COOP_GATHER")) ctx->coop_gather = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);  // (tests, A/B runs)
   ctx->dp.key0 = (uint32_t)params->seed;  // RngPool rng_pool(seed): unadjusted (quirk 1)
   ctx->dp.use_ddmc = params->use_ddmc;
@@ -384,6 +388,12 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   {
     std::vector<int32_t> ent(6 * (size_t)v->nblocks, -1);
     std::vector<double> x0(6 * (size_t)v->nblocks, 0.0);
+    // k_imc_cell: a photon that has stepped through face f of block b sits in b's ghost cell behind
+    // that face; dq moves the byte offset of that cell (16 ntot bytes per block, 8 per cell) to the
+    // cell it is in after the crossing -- the first / last interior cell along the axis of the
+    // destination block, or, at a reflecting wall, the interior cell it came from
+    std::vector<int32_t> dq(6 * (size_t)v->nblocks, 0);
+    const long long stride8[3] = {8, 8ll * D.ni, 8ll * D.ni * D.nj};
     const int first[3] = {D.is, D.js, D.ks};
     for (int b = 0; b < v->nblocks; ++b) {
       long long l0[3] = {0, 0, 0}, cnt[3] = {1, 1, 1};
@@ -409,6 +419,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
             if (bc == JB_BC_REFLECT) {
               ent[6 * (size_t)b + f] = (2 << 28) | b;
               x0[6 * (size_t)b + f] = v->blk_xmin[3 * b + d] - (double)first[d] * v->blk_dx[3 * b + d];
+              dq[6 * (size_t)b + f] = (int32_t)(up ? -stride8[d] : stride8[d]);
               continue;
             }
             if (bc != JB_BC_PERIODIC) continue;  // outflow: the particle escapes
@@ -426,8 +437,12 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
           if (!same || li >= (1 << 28)) continue;
           ent[6 * (size_t)b + f] = (kind << 28) | li;
           x0[6 * (size_t)b + f] = v->blk_xmin[3 * li + d] - (double)first[d] * v->blk_dx[3 * li + d];
+          if (m->exact_geom)  // (offsets below 4 GiB: the difference fits 32 bits, as a wrapping sum)
+            dq[6 * (size_t)b + f] = (int32_t)(uint32_t)(16ll * D.ntot * ((long long)li - b) +
+                                                        (up ? -stride8[d] : stride8[d]) * v->nx[d]);
         }
     }
+    if ((st = upload(m, dq.data(), dq.size(), &m->nbr_dq)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
     if ((st = upload(m, ent.data(), ent.size(), &D.nbr_ent)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
     if ((st = upload(m, x0.data(), x0.size(), &D.nbr_x0)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
   }
@@ -467,6 +482,15 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
     D.lam_abs = (double *const *)tmp;
     if ((st = upload(m, (const double *const *)ps.data(), (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
     D.lam_sc = (double *const *)tmp;
+    // ghost cells of the scattering mean free path: which face of the block lies between them and
+    // the interior (k_imc_cell reads "the photon has left its block" off the value it gathers);
+    // UpdateDerivedTransportFields only ever writes interior cells
+    hipLaunchKernelGGL(k_lam_ghost_codes, dim3(grid_for(ctx, (long long)v->nblocks * D.ntot)), dim3(kBlock), 0,
+                       ctx->stream, D, m->nbr_dq);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      jb_mesh_destroy(m);
+      return fail(JB_ERR_HIP, "writing the ghost-cell codes of the mean-free-path arrays failed");
+    }
     D.ddmc_cell = nullptr;
     if (ctx->params.use_ddmc) {
       double *pack = nullptr;
@@ -656,11 +680,33 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
   } while (0)
   // (variant string: NDIM, TALLY, GRAY, EXACT geometry, LEAN arithmetic; the DDMC flag is the
   // entry point that was called)
+  // lean arithmetic on exact geometry: the step in cell-local coordinates (jb_kernel_imc.hpp)
+  static const char *const imc_cell_names[3][2][2] = {
+      {{"k_imc_cell<1, false, false, lean>", "k_imc_cell<1, false, true, lean>"},
+       {"k_imc_cell<1, true, false, lean>", "k_imc_cell<1, true, true, lean>"}},
+      {{"k_imc_cell<2, false, false, lean>", "k_imc_cell<2, false, true, lean>"},
+       {"k_imc_cell<2, true, false, lean>", "k_imc_cell<2, true, true, lean>"}},
+      {{"k_imc_cell<3, false, false, lean>", "k_imc_cell<3, false, true, lean>"},
+       {"k_imc_cell<3, true, false, lean>", "k_imc_cell<3, true, true, lean>"}}};
+  (void)imc_cell_names;
+#define JB_LAUNCH_CELL(T, NA)                                                                      \
+  do {                                                                                             \
+    static int occ = 0;                                                                            \
+    if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(                                  \
+                        &occ, k_imc_cell<NDIM, T, NA>, kBlock, 0) != hipSuccess || occ < 1))       \
+      occ = 3;                                                                                     \
+    const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
+    hipLaunchKernelGGL((k_imc_cell<NDIM, T, NA>), dim3(g), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, \
+                       ctx->dp, S, t_start, dt, first, last, ctx->counters_d, mesh->nbr_dq);       \
+    /* (variant string: NDIM, TALLY, NOABS, and the arithmetic) */                                 \
+    mesh->last_variant = imc_cell_names[NDIM - 1][(T) ? 1 : 0][(NA) ? 1 : 0];                      \
+  } while (0)
 #define JB_LAUNCH(T, G)                                                                            \
   do {                                                                                             \
     if constexpr (!DDMC && G != 0) {                                                               \
       if (mesh->exact_geom) {                                                                      \
-        if (ctx->lean_arith) JB_LAUNCH_X(T, G, true, true);                                        \
+        if (ctx->lean_arith && !ctx->no_imc_cell) JB_LAUNCH_CELL(T, (G == 2));                     \
+        else if (ctx->lean_arith) JB_LAUNCH_X(T, G, true, true);                                   \
         else JB_LAUNCH_X(T, G, true, false);                                                       \
       } else {                                                                                     \
         if (ctx->lean_arith) JB_LAUNCH_X(T, G, false, true);                                       \
@@ -840,6 +886,7 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
   else if (gray) JB_LAUNCH(false, 1);
   else JB_LAUNCH(false, 0);
 #undef JB_LAUNCH
+#undef JB_LAUNCH_CELL
 #undef JB_LAUNCH_X
   return JB_COMPLETE;
 }

@@ -43,6 +43,21 @@ __device__ __forceinline__ double m_fma(double a, double b, double c) {
 #endif
 }
 
+// ... with the addend a loop-invariant constant held in a SCALAR register pair (a VOP3 instruction
+// reads one): the "v" form above parks every polynomial coefficient in two vector registers for
+// the life of the kernel; k_imc_cell, whose mesh view no longer occupies the scalar file, can afford
+// the scalar ones and needs the vector ones for a fourth wave per SIMD
+__device__ __forceinline__ double m_fma_s(double a, double b, double c_uniform) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+  return d;
+}
+template <bool SC>
+__device__ __forceinline__ double m_fma_k(double a, double b, double c_const) {
+  if constexpr (SC) return m_fma_s(a, b, c_const);
+  else return m_fma(a, b, c_const);
+}
+
 // fma(-a, b, c) with the negation as a source modifier (an asm operand `-a` would cost a v_xor)
 __device__ __forceinline__ double m_fnma(double a, double b, double c) {
 #ifdef JB_NO_ASM_FMA
@@ -167,6 +182,7 @@ __device__ __forceinline__ double m_log(double x) {  // x positive, finite, norm
 // multiply-add on the rounded constants, plus r + r^2 P(r), added in plain double (<= 3 ulp of the
 // result for the arguments in (0, 1) the kernels feed it, measured <= 2; next to x = 1 the table
 // row is {1, 0} and the result is r + r^2 P(r) itself) ...
+template <bool SC = false>
 __device__ __forceinline__ double m_log_lean(double x) {
   constexpr double ln2 = 6.93147180559945286227e-01;
   const uint32_t hx = (uint32_t)__double2hiint(x);
@@ -179,11 +195,11 @@ __device__ __forceinline__ double m_log_lean(double x) {
   const double w = fma((double)k, ln2, lc);
   const double r2 = r * r;
   // (|r| <= 5.5e-3: the r^8 / 8 term of the series is below 2e-17 of the result, 0.2 ulp)
-  double p = m_fma(r, 1.0 / 7.0, -1.0 / 6.0);
-  p = m_fma(r, p, 0.2);
-  p = m_fma(r, p, -0.25);
-  p = m_fma(r, p, 1.0 / 3.0);
-  p = m_fma(r, p, -0.5);
+  double p = m_fma_k<SC>(r, 1.0 / 7.0, -1.0 / 6.0);
+  p = m_fma_k<SC>(r, p, 0.2);
+  p = m_fma_k<SC>(r, p, -0.25);
+  p = m_fma_k<SC>(r, p, 1.0 / 3.0);
+  p = m_fma_k<SC>(r, p, -0.5);
   return w + fma(r2, p, r);
 }
 
@@ -222,13 +238,14 @@ __device__ __forceinline__ void m_sincos(double x, double &sn, double &cs) {  //
 // extended-precision subtraction, and |r| <= pi/256 needs only r - r^3/6 + r^5/120 and
 // -r^2/2 + r^4/24 - r^6/720 (next terms < 1e-17).  Absolute error <= 1.7e-16.
 constexpr double kTwoPiM = 6.283185307179586476925286766559;
+template <bool SC = false>
 __device__ __forceinline__ void m_sincos2pi(double u, double &sn, double &cs) {
   const int i = (int)fma(u, 256.0, 0.5);
   const double r = fma((double)i, -0.00390625, u) * kTwoPiM;
   const double si = lds_sc2_tab[i][0], ci = lds_sc2_tab[i][1];
   const double r2 = r * r;
-  const double sr = m_fma(r * r2, m_fma(r2, 1.0 / 120.0, -1.0 / 6.0), r);
-  const double cm1 = r2 * m_fma(r2, m_fma(r2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
+  const double sr = m_fma(r * r2, m_fma_k<SC>(r2, 1.0 / 120.0, -1.0 / 6.0), r);
+  const double cm1 = r2 * m_fma_k<SC>(r2, m_fma_k<SC>(r2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
   sn = m_fma(si, cm1, m_fma(ci, sr, si));
   cs = m_fma(ci, cm1, m_fnma(si, sr, ci));
 }

@@ -403,14 +403,14 @@ __device__ __forceinline__ void imc_step_dir(DirGeom &g, double dx_push0, double
 }
 
 // scattering.hpp:21-29 in direction space: the new unit direction (2 draws)
-template <class Rng>
+template <bool SC = false, class Rng>
 __device__ __forceinline__ void scatter_dir(Rng &rng, double &ox, double &oy, double &oz) {
   double xi1, xi2;
   rng.drand2(xi1, xi2);
   const double mu = fma(2.0, xi1, -1.0);
   const double st = m_sqrt_lean(1.0 - mu * mu);
   double sn, cs;
-  m_sincos2pi(xi2, sn, cs);
+  m_sincos2pi<SC>(xi2, sn, cs);
   ox = st * cs;
   oy = st * sn;
   oz = mu;
