@@ -29,7 +29,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_GATHER_PEAK_GBS = 16800.0  # MI355X_MICROARCH.md, "Indexed rows": rows shared through the XCDs' L2,
@@ -54,7 +53,7 @@ def make_deck(ngpus: int, particles_per_gpu: int, block_nx: int = 64, workload: 
     """c2: stepdiff.in pure IMC, 64 x 64^3 blocks per GPU (the headline workload).
     c3: stepdiff_ddmc.in, 3-D 128^3 cells in 8 x 64^3 blocks (sigma dx = 7.8: every step DDMC).
     c3-1d: stepdiff_ddmc.in as shipped but 128 cells in one block (tally-contention stress)."""
-    from helpers import load_deck
+    from jaybenne_amd.deck import load_deck
     if workload == "c1":     # BASELINE configs[0]: the reference's own regression case (tst/stepdiff.py)
         return load_deck("stepdiff", {"jaybenne/num_particles": particles_per_gpu * ngpus,
                                       "parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128})
@@ -90,8 +89,8 @@ def make_deck(ngpus: int, particles_per_gpu: int, block_nx: int = 64, workload: 
 def cpu_baseline(sample_particles: int, block_nx: int):
     """The oracle (CPU port of the reference algorithm, libm arithmetic) on the same workload with
     a bounded number of particles, on this box's host cores."""
-    from helpers import make_oracle
     from oracle import orc
+    from oracle.harness import make_oracle
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = min(avail, 16)   # the GPU box grants a 16-core share per GPU
     pin = make_deck(1, sample_particles, block_nx)
@@ -107,7 +106,7 @@ def cpu_baseline(sample_particles: int, block_nx: int):
     # BASELINE configs[0] (the reference's own CPU-runnable case: stepdiff, 1-D,
     # 128 cells in one block, 1e5 particles) on ONE thread -- the analogue of mcblock with one MPI
     # rank on Kokkos Serial, the reference's default build
-    from helpers import load_deck
+    from jaybenne_amd.deck import load_deck
     pin1 = load_deck("stepdiff", {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128})
     O1, _, _ = make_oracle(pin1, orc.MATH_LIBM, threads=1)
     n1 = O1.n
@@ -126,9 +125,10 @@ def accuracy(device, threads: int):
     with the reference's libm arithmetic run the same streams; both are scored with the
     reference's metric (tst/regression_test.py:383-406) against the analytic erf profile, and
     against each other in units of the Monte Carlo noise of a cell."""
-    from helpers import load_deck, make_oracle, run_oracle_cycles
     from jaybenne_amd import analysis, mcblock
+    from jaybenne_amd.deck import load_deck
     from oracle import orc
+    from oracle.harness import make_oracle, run_oracle_cycles
     ov = {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 128}
     drv = mcblock.McblockDriver(load_deck("stepdiff", ov), device=device)
     arithmetic = drv.pkg.arithmetic()
@@ -163,10 +163,14 @@ def accuracy(device, threads: int):
                     "cell within 6 sigma of its Monte Carlo noise; measured values above."}
 
 
+LOG_DIR = os.path.join(ROOT, "gpurun_out", "bench_logs")
+
+
 def self_launch(args) -> int:
     """--gpus N > 1 from a plain `python bench.py`: N fresh rank processes, started before this
     process has imported torch or made any HIP call (re-executing a process that has initialised
-    the GPU is not allowed on this pool)."""
+    the GPU is not allowed on this pool).  The ranks supervise their workers exactly as they do
+    under the driver's own `python -m torch.distributed.run` (supervise())."""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -187,6 +191,162 @@ def self_launch(args) -> int:
     if line is not None:
         print(line, flush=True)
     return proc.returncode if (proc.returncode != 0 or line is not None) else 1
+
+
+def _tail(path: str, n: int = 25) -> str:
+    try:
+        with open(path, "r", errors="replace") as fh:
+            return "".join(fh.readlines()[-n:])
+    except OSError as e:
+        return f"({e})\n"
+
+
+def supervise(args) -> int:
+    """A rank of an N > 1 run (under `python -m torch.distributed.run`): it never touches the GPU
+    itself.  It starts a WORKER process that does (first over RCCL), watches it, and agrees with the
+    other ranks -- over a CPU-only gloo group on the launcher's rendezvous -- on the outcome:
+
+      * every worker returns 0: rank 0 relays the worker's JSON line;
+      * a worker exits non-zero, is killed, or the attempt runs out of time: its rank posts an
+        abort key in the rendezvous store, every rank kills its worker within a second, rank 0
+        prints the tail of every rank's log, and -- unless JB_BENCH_BACKEND pinned the backend --
+        FRESH workers repeat the run over gloo (records through host memory), the line labelled
+        `"backend": "gloo (rccl failed: ...)"`;
+      * both attempts fail: exit code 1, diagnostics on stderr.  Nothing waits longer than
+        JB_BENCH_BUDGET_S (default 540 s) in total, whatever a collective does.
+    """
+    import subprocess
+    from datetime import timedelta
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    t_start = time.time()
+    budget = float(os.environ.get("JB_BENCH_BUDGET_S", "540"))
+    dist.init_process_group("gloo", timeout=timedelta(seconds=60))   # CPU only: no HIP call
+    from torch.distributed.distributed_c10d import _get_default_store
+    store = _get_default_store()
+    os.makedirs(LOG_DIR, exist_ok=True)
+    pinned = os.environ.get("JB_BENCH_BACKEND")
+    attempts = [pinned] if pinned else ["nccl", "gloo"]
+    failure_note, rc_final, line = None, 1, None
+    for ai, backend in enumerate(attempts):
+        # time for this attempt: RCCL gets at most 55 % of what is left when a fallback follows it
+        left = budget - (time.time() - t_start)
+        limit = left * (0.55 if ai + 1 < len(attempts) else 1.0) - 10.0
+        if limit < 20.0:
+            failure_note = (failure_note or "") + f"; no time left for attempt {ai} ({backend})"
+            break
+        port_t = torch.zeros(1, dtype=torch.int64)
+        if rank == 0:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port_t[0] = sk.getsockname()[1]
+        dist.broadcast(port_t, 0)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port_t[0])), JB_BENCH_BACKEND=backend,
+                   JB_BENCH_WORKER="1", JB_BENCH_ATTEMPT=str(ai))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        log_path = os.path.join(LOG_DIR, f"rank{rank}.attempt{ai}.{backend}.log")
+        out_path = os.path.join(LOG_DIR, f"rank{rank}.attempt{ai}.{backend}.out")
+        key = f"jb_abort_{ai}"
+        with open(log_path, "w") as log, open(out_path, "w") as out:
+            log.write(f"[supervisor] rank {rank}/{world} attempt {ai} backend {backend} limit {limit:.0f} s\n")
+            log.flush()
+            child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                     env=env, stdout=out, stderr=log)
+            t0, rc, why = time.time(), None, ""
+            while rc is None:
+                time.sleep(0.25)
+                rc = child.poll()
+                if rc is not None:
+                    break
+                aborted = store.check([key])
+                timed_out = time.time() - t0 > limit
+                if aborted or timed_out:
+                    why = "another rank failed" if aborted else f"no result after {limit:.0f} s"
+                    if timed_out and not aborted:
+                        store.set(key, f"rank {rank}: {why}")
+                    child.terminate()
+                    try:
+                        child.wait(timeout=5)
+                    except subprocess.TimeoutExpired:
+                        child.kill()
+                        child.wait()
+                    rc = child.returncode if child.returncode not in (0, None) else -15
+                    log.write(f"[supervisor] worker stopped: {why}\n")
+            if rc != 0 and not why:
+                store.set(key, f"rank {rank}: worker exit code {rc}")
+                log.write(f"[supervisor] worker exit code {rc}\n")
+        bad = torch.tensor([1 if rc != 0 else 0], dtype=torch.int64)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad[0]) == 0:
+            rc_final = 0
+            if rank == 0:
+                for ln in open(out_path, "r", errors="replace"):
+                    if ln.startswith("{") and '"metric"' in ln:
+                        line = ln.strip()
+                if line is None:
+                    rc_final = 1
+                    print(f"bench: attempt {ai} ({backend}) ended without a result line", file=sys.stderr)
+            break
+        try:
+            reason = store.get(key).decode()
+        except Exception:   # (the key is set by whichever rank failed first; it exists by now)
+            reason = "unknown"
+        failure_note = ((failure_note + "; ") if failure_note else "") + f"{backend}: {reason}"
+        if rank == 0:
+            print(f"bench: attempt {ai} over {backend} failed ({reason}); per-rank logs in {LOG_DIR}:",
+                  file=sys.stderr)
+            for r in range(world):
+                print(f"---- rank {r} ----\n" + _tail(os.path.join(LOG_DIR, f"rank{r}.attempt{ai}.{backend}.log")),
+                      file=sys.stderr)
+    ok = torch.tensor([rc_final], dtype=torch.int64)
+    dist.broadcast(ok, 0)
+    rc_final = int(ok[0])
+    if rank == 0 and line is not None and rc_final == 0:
+        d = json.loads(line)
+        d["ranks"] = world
+        if failure_note:
+            d["backend"] = f"gloo ({failure_note.replace('nccl', 'rccl failed')})"
+        print(json.dumps(d), flush=True)
+    dist.destroy_process_group()
+    return rc_final
+
+
+def fake_worker(args) -> int:
+    """JB_BENCH_FAKE_WORKER=1 (tests/test_bench_supervisor.py, CPU only): the worker's process-group
+    life cycle without a GPU -- rendezvous over gloo, a barrier per 'step', a result line -- with the
+    failures the supervisor has to survive injected through the environment."""
+    from datetime import timedelta
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    backend = os.environ.get("JB_BENCH_BACKEND", "nccl")
+    print(f"[fake worker] rank {rank}/{world} backend {backend}", file=sys.stderr, flush=True)
+    if backend == "nccl" and os.environ.get("JB_BENCH_FAKE_NCCL_FAILS") == "1":
+        print("[fake worker] RCCL refused the uneven all_to_all_single (injected)", file=sys.stderr, flush=True)
+        return 3
+    dist.init_process_group("gloo", timeout=timedelta(seconds=90))
+    kill = os.environ.get("JB_BENCH_FAKE_KILL", "")       # "rank@step[@backend]"
+    hang = os.environ.get("JB_BENCH_FAKE_HANG", "")       # "rank@step"
+    for step in range(args.warmup + args.steps):
+        if kill:
+            kr, ks, *kb = kill.split("@")
+            if int(kr) == rank and int(ks) == step and (not kb or kb[0] == backend):
+                print(f"[fake worker] rank {rank} dies at step {step} (injected)", file=sys.stderr, flush=True)
+                os._exit(17)
+        if hang and int(hang.split("@")[0]) == rank and int(hang.split("@")[1]) == step:
+            print(f"[fake worker] rank {rank} hangs at step {step} (injected)", file=sys.stderr, flush=True)
+            time.sleep(3600)
+        dist.barrier()
+        time.sleep(0.05)
+    if rank == 0:
+        print(json.dumps({"metric": "particle-histories/s (whole node) on stepdiff", "value": 1.0,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"parallelism": f"fake worker over {backend}"}}), flush=True)
+    dist.destroy_process_group()
+    return 0
 
 
 def main() -> None:
@@ -217,7 +377,12 @@ def main() -> None:
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(self_launch(args))
+    if args.gpus > 1 and os.environ.get("JB_BENCH_WORKER") != "1":
+        sys.exit(supervise(args))          # a rank of the launcher: it watches a worker (see there)
+    if os.environ.get("JB_BENCH_FAKE_WORKER") == "1":
+        sys.exit(fake_worker(args))
 
+    t_import = time.perf_counter()
     import torch
     import torch.distributed as dist
     from jaybenne_amd import mcblock
@@ -244,19 +409,32 @@ def main() -> None:
             dist.init_process_group(backend, rank=0, world_size=1)
         from jaybenne_amd.comm import Comm
         comm = Comm(device=device)
+    def rank_log(msg: str) -> None:
+        # (stderr of a supervised worker is gpurun_out/bench_logs/rank<k>.attempt<i>.<backend>.log)
+        if world > 1:
+            print(f"[rank {rank} +{time.perf_counter() - t_import:7.1f} s] {msg}", file=sys.stderr, flush=True)
+
     if world > 1:
+        from datetime import timedelta
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a collective that does not complete in 90 s raises (and takes the worker down) instead of
+        # sitting out torch's default 10 minutes: the supervisor then falls back or reports
+        rank_log(f"device {dev_index} = {torch.cuda.get_device_name(dev_index)}, backend {backend}: rendezvous")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=timedelta(seconds=90))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timedelta(seconds=90))
         from jaybenne_amd.comm import Comm
         comm = Comm(device=device)
+        comm.barrier()
+        rank_log("process group up, first barrier passed")
 
     pin = make_deck(args.gpus, args.particles_per_gpu, args.block_nx, args.workload)
     drv = mcblock.McblockDriver(pin, rank=rank, nranks=world, comm=comm, device=device,
                                 capacity_factor=1.5 if world == 1 else 3.0)
     md = drv.md
+    rank_log(f"mesh: {md.mesh.nblocks} blocks in all, {md.nowned} owned + {md.nblocks - md.nowned} halo copies "
+             f"resident; {md.n} photons sourced here")
     md.force_exchange = bool(args.force_exchange)
     md.defrag_interval = int(args.defrag_interval)
 
@@ -268,8 +446,15 @@ def main() -> None:
 
     if args.arithmetic is not None:
         drv.pkg.set_arithmetic(args.arithmetic)
-    for _ in range(args.warmup):
+    kill = os.environ.get("JB_BENCH_KILL_RANK", "")   # "rank@step": the failure rehearsal of tools/dev
+    for w in range(args.warmup):
+        if kill and int(kill.split("@")[0]) == rank and int(kill.split("@")[1]) == w:
+            rank_log("dies here (JB_BENCH_KILL_RANK)")
+            os._exit(17)
         drv.Step()
+        if w == 0:
+            rank_log(f"first cycle done: {md.transport_iterations_total} transport iterations, "
+                     f"{md.handoff_records} records handed over by this rank, {md.n} photons here now")
     if os.environ.get("JB_PHASE_TIMES"):     # diagnostic: per-phase wall time (adds syncs)
         md.phase_times = {}
     sync_all()
@@ -415,6 +600,8 @@ def main() -> None:
             "unit": "particle-histories/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * wall / args.steps,
+            "value_per_gpu": histories / wall / args.gpus,
+            "backend": "rccl" if (backend == "nccl" and world > 1) else (backend if world > 1 else "none (one rank)"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": {

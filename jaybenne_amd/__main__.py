@@ -1,6 +1,6 @@
 """Run an input deck the way the reference's regression harness drives `mcblock`:
 
-    python -m jaybenne_amd -i tests/golden/decks/stepdiff.in parthenon/mesh/nx1=128 \\
+    python -m jaybenne_amd -i jaybenne_amd/decks/stepdiff.in parthenon/mesh/nx1=128 \\
            parthenon/meshblock/nx1=128 [--tolerance 0.05] [--comparison weighted_mean]
 
 Trailing ``block/key=value`` arguments override deck values (Parthenon's command-line syntax,

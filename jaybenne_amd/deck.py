@@ -10,7 +10,12 @@ surface used on the hot path is ``GetInteger / GetReal / GetString / GetBoolean`
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
+
+# the reference's own input decks (inputs/*.in: key / value content only), shipped as data of the
+# package: what BASELINE.json:configs name, what the regression harness and bench.py run
+DECK_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "decks")
 
 
 class ParameterInput:
@@ -112,3 +117,13 @@ class ParameterInput:
 
     def GetOrAddBoolean(self, block: str, key: str, default: bool) -> bool:
         return self._get_or_add(self.GetBoolean, block, key, default)
+
+
+def load_deck(name: str, overrides: Optional[Dict[str, object]] = None) -> ParameterInput:
+    """One of the reference's decks by name (``stepdiff``, ``stepdiff_ddmc``, ``stepdiff_smr``,
+    ``stepdiff_smr_ddmc``, ``stepdiff_smr_hybrid``, ``inf``, ``inf_stiff``) with the override
+    mechanism of the reference's regression harness (tst/regression_test.py:85-145)."""
+    pin = ParameterInput.from_file(os.path.join(DECK_DIR, name + ".in"))
+    if overrides:
+        pin.modify(overrides)
+    return pin

@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-DECKS = os.path.join(os.path.dirname(__file__), "golden", "decks")
+from jaybenne_amd.deck import DECK_DIR as DECKS  # noqa: E402  (the reference's decks, data of the package)
 STEPDIFF = ["parthenon/mesh/nx1=128", "parthenon/meshblock/nx1=128"]
 SMR = ["parthenon/mesh/nx1=64", "parthenon/mesh/nx2=32", "parthenon/meshblock/nx1=16",
        "parthenon/meshblock/nx2=16"]
