@@ -366,9 +366,10 @@ def main() -> None:
     ap.add_argument("--force-exchange", action="store_true",
                     help="1 GPU: run the hand-off phase as well, in a one-rank group (nothing moves; "
                          "shows the fixed cost of the exchange per transport iteration)")
-    ap.add_argument("--defrag-interval", type=int, default=0,
-                    help="DefragParticles (sort of the swarm by cell) after every k-th cycle; matters "
-                         "for long runs (profiles/r03_long_run.json), not for the few cycles timed here")
+    ap.add_argument("--defrag-interval", type=int, default=-1,
+                    help="DefragParticles (sort of the swarm by cell): -1 (default) on the library's "
+                         "schedule (jb_defrag_policy), k > 0 after every k-th cycle, 0 never; matters "
+                         "for long runs (profiles/r04_long_run.json), not for the few cycles timed here")
     ap.add_argument("--no-other-variant", action="store_true",
                     help="skip the one extra step in the other arithmetic variant (profiling runs)")
     ap.add_argument("--arithmetic", choices=("lean", "exact"), default=None,

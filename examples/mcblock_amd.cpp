@@ -575,7 +575,7 @@ int main(int argc, char **argv) {
     }
 
     // (as the Python driver: the swarm sorted by block and cell after every k-th cycle; 0 = never)
-    md.defrag_interval = (int)pin.GetOrAddInteger("jaybenne", "defrag_interval", 0);
+    md.defrag_interval = (int)pin.GetOrAddInteger("jaybenne", "defrag_interval", -1);
     jb::InitializeRadiation(&md, initial_radiation == "thermal");
     std::printf("problem %s: %d-D, %d meshblocks, %d level(s), %lld photons\n", problem_id.c_str(), ndim,
                 nb, max_level + 1, (long long)md.swarm.n);

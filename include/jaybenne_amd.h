@@ -302,6 +302,27 @@ jb_status jb_remove_marked_particles(jb_context *ctx, jb_swarm_view *swarm);
  * come out in arbitrary order.  Works through 128 bytes of library scratch memory per particle.
  * Asynchronous on the context's stream. */
 jb_status jb_defrag_particles(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm);
+/* The default schedule of DefragParticles ("defrag_interval = -1", what RadiationStep of the hosts
+ * calls at the end of a cycle, after it has read the cycle's event count): the library times the
+ * tracking kernels of every jb_transport_photons* call and every sort with HIP events on the
+ * context's stream.  It keeps the lowest time per event seen since the last sort and adds up what
+ * the cycles since have cost above it; when that loss reaches the cost of a sort (measured; 15 ms
+ * per 1e8 photons until one has been) -- the period that minimises loss + sort cost per cycle for a
+ * loss growing linearly -- and the current cycle is at least 3 % slower than the best one, at least
+ * 2 cycles after the last sort and with at least 2^20 photons in the swarm, the swarm is sorted
+ * (*sorted = 1).  A sort after which the next cycle is not at least 3 % faster was not what the
+ * kernels needed: the minimum distance between sorts doubles (2, 4, .. 256 cycles) until one pays
+ * again.  Slot order only affects speed, never results; defrag_interval = 0 in the hosts keeps the
+ * order of the reference (never sorted), k > 0 sorts after every k-th cycle.
+ * The caller must have synchronised the stream since the cycle's last transport call. */
+jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                           int64_t events_this_cycle, int32_t *sorted);
+/* Gives the library's scratch memory back (synchronises the stream first).  The scratch buffer
+ * grows on demand and is otherwise kept for the life of the context: 128 bytes per photon after a
+ * DefragParticles (sized exactly), a few bytes per photon for the hole / hand-off lists.  If it cannot
+ * be allocated, jb_defrag_particles returns JB_ERR_HIP and leaves the swarm as it was; jb_defrag_policy
+ * then skips the sort with a message on stderr and stops asking. */
+jb_status jb_release_scratch(jb_context *ctx);
 
 /* MeshSend / MeshReceive (jaybenne.cpp:36-61) for the inter-rank part: OUTGOING particles are
  * among [first,last) are copied into fixed-size records (JB_RECORD_WORDS x 8 bytes), ordered by

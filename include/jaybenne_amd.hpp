@@ -105,7 +105,11 @@ class MeshData {
   uint64_t next_id = 0;    // first unused random-stream id
   uint32_t epoch = 0;      // source-call counter (keys the per-cell rounding streams)
   int64_t events = 0;      // tracking events so far
-  int defrag_interval = 0;      // DefragParticles after every k-th RadiationStep (0: never, as the reference)
+  // DefragParticles: -1 (default) when the library's policy asks for it (jb_defrag_policy: a cycle
+  // that costs 10 % more per event than the best one since the last sort); k > 0 after every k-th
+  // RadiationStep; 0 never, as the reference (slot order then stays what the task list makes it)
+  int defrag_interval = -1;
+  int defrags = 0;
   int steps_since_defrag = 0;
 
  private:
@@ -243,10 +247,15 @@ inline TaskStatus RadiationStep(MeshData *md, const Real t_start, const Real dt)
   md->events += after.n_events - before.n_events;
   if (CheckCompletion(md, t_start + dt) != TaskStatus::complete) return TaskStatus::iterate;
   UpdateFluid(md);
-  // (not in the reference's task list: DefragParticles after every defrag_interval-th cycle)
-  if (md->defrag_interval > 0 && ++md->steps_since_defrag >= md->defrag_interval) {
+  // (not in the reference's task list: DefragParticles on the library's schedule, or every k-th cycle)
+  if (md->defrag_interval < 0) {
+    int32_t sorted = 0;
+    Check(jb_defrag_policy(md->ctx(), md->mesh(), &md->swarm, after.n_events - before.n_events, &sorted));
+    md->defrags += sorted;
+  } else if (md->defrag_interval > 0 && ++md->steps_since_defrag >= md->defrag_interval) {
     DefragParticles(md);
     md->steps_since_defrag = 0;
+    ++md->defrags;
   }
   return TaskStatus::complete;
 }

@@ -60,7 +60,23 @@ struct jb_context {
   bool no_ddmc_all = false;   // JB_NO_DDMC_ALL=1 at jb_initialize (tests: k_hybrid on all-DDMC meshes)
   int coop_gather = -1;       // JB_COOP_GATHER=0 / 1 / 2: k_ddmc_all's quad-cooperative gather off / on / on with 64-bit addresses, whatever the table size
   bool no_imc_cell = false;   // JB_NO_IMC_CELL=1 at jb_initialize (tests, A/B): the lean step in x-space (k_transport<.., LEAN>) instead of k_imc_cell
+  // jb_defrag_policy: HIP events around every transport call of the running cycle, and what the
+  // policy remembers from cycle to cycle
+  std::vector<hipEvent_t> tev;       // pairs (start, stop)
+  int tev_used = 0;                  // events of tev recorded since the last policy call
+  bool tev_overflow = false;
+  double rate_ref = 0.0;             // lowest ms per event seen since the last sort (0: none yet)
+  double rate_before_sort = 0.0;     // ... the rate of the cycle that triggered the last sort
+  double excess_ms = 0.0;            // time spent above rate_ref since the last sort
+  double sort_ms_per_photon = 1.5e-7;  // cost of a sort: 15 ms per 1e8 photons until one has been timed
+  hipEvent_t sort_ev[2] = {nullptr, nullptr};
+  bool sort_timed = false;           // sort_ev brackets a sort whose time has not been read yet
+  long long sort_n = 0;
+  int cycles_since_sort = 0;
+  int min_interval = 2;              // cycles between two sorts (doubles when a sort bought nothing)
+  int policy_sorts = 0;
 };
+constexpr int kTransportEventPairs = 64;
 constexpr int kCounterWords = 1024;  // CNT_N.. | 16..17 cursors | 32.. per-rank counts (<= 480 ranks)
 constexpr int kCursorBase = 16;
 constexpr int kRankBase = 32;
@@ -92,12 +108,15 @@ static int grid_for(const jb_context *ctx, long long n, int per_cu = 8) {
   return (int)blocks;
 }
 
-static jb_status ensure_scratch(jb_context *ctx, size_t words) {
+// (slack: small tables grow with the run and are re-requested often; the sort's particle records --
+// 128 bytes per photon -- are sized exactly: 25 % on top of 12.8 GB is memory a run near the card's
+// capacity may not have)
+static jb_status ensure_scratch(jb_context *ctx, size_t words, bool slack = true) {
   if (words <= ctx->scratch_words) return JB_COMPLETE;
   if (ctx->scratch_d) JB_HIP(hipFree(ctx->scratch_d));
   ctx->scratch_d = nullptr;
   ctx->scratch_words = 0;
-  const size_t want = words + words / 4 + 1024;
+  const size_t want = slack ? words + words / 4 + 1024 : words + 16;
   JB_HIP(hipMalloc(&ctx->scratch_d, want * sizeof(long long)));
   ctx->scratch_words = want;
   return JB_COMPLETE;
@@ -214,6 +233,8 @@ extern "C" jb_status jb_finalize(jb_context *ctx) {
   if (ctx->counters_d) (void)hipFree(ctx->counters_d);
   if (ctx->counters_h) (void)hipHostFree(ctx->counters_h);
   if (ctx->scratch_d) (void)hipFree(ctx->scratch_d);
+  for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->sort_ev) if (e) (void)hipEventDestroy(e);
   delete ctx;
   return JB_COMPLETE;
 }
@@ -907,6 +928,20 @@ static jb_status transport_impl(jb_context *ctx, jb_mesh *mesh, const jb_swarm_v
   if (first == last) return JB_COMPLETE;
   const DevSwarm S = dev_swarm(swarm);
   const bool tl = tally != 0;
+  // (jb_defrag_policy: the time of the tracking kernels of this cycle, per event)
+  hipEvent_t ev_stop = nullptr;
+  if (ctx->tev_used + 2 <= 2 * kTransportEventPairs) {
+    while ((int)ctx->tev.size() < ctx->tev_used + 2) {
+      hipEvent_t e = nullptr;
+      JB_HIP(hipEventCreate(&e));
+      ctx->tev.push_back(e);
+    }
+    JB_HIP(hipEventRecord(ctx->tev[ctx->tev_used], ctx->stream));
+    ev_stop = ctx->tev[ctx->tev_used + 1];
+    ctx->tev_used += 2;
+  } else {
+    ctx->tev_overflow = true;
+  }
   switch (M.ndim * 2 + (ddmc ? 1 : 0)) {
   case 2: st = launch_transport<1, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
   case 3: st = launch_transport<1, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
@@ -915,6 +950,7 @@ static jb_status transport_impl(jb_context *ctx, jb_mesh *mesh, const jb_swarm_v
   case 6: st = launch_transport<3, false>(ctx, mesh, S, t_start, dt, first, last, tl); break;
   default: st = launch_transport<3, true>(ctx, mesh, S, t_start, dt, first, last, tl); break;
   }
+  if (ev_stop) (void)hipEventRecord(ev_stop, ctx->stream);
   if (st != JB_COMPLETE) return st;
   JB_HIP(hipGetLastError());
   return JB_COMPLETE;
@@ -1126,7 +1162,7 @@ extern "C" jb_status jb_defrag_particles(jb_context *ctx, jb_mesh *mesh, const j
   // scratch: the particle records (16 words each, on a 128-byte boundary), then histogram / offsets
   // (nbins), tile sums (ntiles) and keys (n), 4 bytes each
   const size_t rec_words = (size_t)kSortRecWords * (size_t)n;
-  st = ensure_scratch(ctx, rec_words + (size_t)((nbins + ntiles + n) / 2 + 16));
+  st = ensure_scratch(ctx, rec_words + (size_t)((nbins + ntiles + n) / 2 + 16), /*slack=*/false);
   if (st != JB_COMPLETE) return st;
   unsigned long long *rec = (unsigned long long *)ctx->scratch_d;
   unsigned *hist = (unsigned *)(rec + rec_words);
@@ -1143,6 +1179,86 @@ extern "C" jb_status jb_defrag_particles(jb_context *ctx, jb_mesh *mesh, const j
   hipLaunchKernelGGL(k_sort_unpack, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, S, n,
                      (const unsigned long long *)rec);
   JB_HIP(hipGetLastError());
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_release_scratch(jb_context *ctx) {
+  if (!ctx) return fail(JB_ERR_INVALID, "null context");
+  JB_HIP(hipSetDevice(ctx->device));
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->scratch_d) JB_HIP(hipFree(ctx->scratch_d));
+  ctx->scratch_d = nullptr;
+  ctx->scratch_words = 0;
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                                       int64_t events_this_cycle, int32_t *sorted) {
+  if (!ctx || !mesh || !sorted) return fail(JB_ERR_INVALID, "null argument");
+  *sorted = 0;
+  JB_HIP(hipSetDevice(ctx->device));
+  jb_status st = check_swarm(swarm, "jb_defrag_policy");
+  if (st != JB_COMPLETE) return st;
+  // time of this cycle's tracking kernels (the caller has synchronised: it knows the event count)
+  double ms = 0.0;
+  bool ok = !ctx->tev_overflow && ctx->tev_used > 0;
+  for (int q = 0; ok && q + 1 < ctx->tev_used; q += 2) {
+    float t = 0.0f;
+    if (hipEventElapsedTime(&t, ctx->tev[q], ctx->tev[q + 1]) != hipSuccess) ok = false;
+    ms += (double)t;
+  }
+  (void)hipGetLastError();  // (an event that has not completed: not an error of the library's)
+  ctx->tev_used = 0;
+  ctx->tev_overflow = false;
+  if (ctx->sort_timed) {  // what the last sort cost (it was queued behind the previous cycle)
+    float t = 0.0f;
+    if (hipEventElapsedTime(&t, ctx->sort_ev[0], ctx->sort_ev[1]) == hipSuccess && ctx->sort_n > 0)
+      ctx->sort_ms_per_photon = (double)t / (double)ctx->sort_n;
+    (void)hipGetLastError();
+    ctx->sort_timed = false;
+  }
+  if (!ok || events_this_cycle <= 0 || swarm->n < (1ll << 20)) return JB_COMPLETE;
+  const double rate = ms / (double)events_this_cycle;
+  ++ctx->cycles_since_sort;
+  if (ctx->cycles_since_sort == 1 && ctx->rate_before_sort > 0.0) {
+    // the first cycle behind a sort: did it pay?  If the rate came down by less than 3 %, what made
+    // the kernels slower was not the order of the swarm -- wait twice as long before the next one
+    if (rate > 0.97 * ctx->rate_before_sort) ctx->min_interval = ctx->min_interval < 256 ? 2 * ctx->min_interval : 256;
+    else ctx->min_interval = 2;
+    ctx->rate_before_sort = 0.0;
+  }
+  if (ctx->rate_ref == 0.0 || rate < ctx->rate_ref) ctx->rate_ref = rate;
+  ctx->excess_ms += (rate - ctx->rate_ref) * (double)events_this_cycle;
+  // Sort when the time lost to the loosened order since the last sort has added up to what a sort
+  // costs (for a loss that grows linearly from cycle to cycle that is the period which minimises
+  // sort cost + loss per cycle), and only on a slow-down that is no timing noise (3 %).
+  const double sort_ms = ctx->sort_ms_per_photon * (double)swarm->n;
+  if (ctx->cycles_since_sort >= ctx->min_interval && rate > 1.03 * ctx->rate_ref && ctx->excess_ms >= sort_ms) {
+    if (!ctx->sort_ev[0]) {
+      JB_HIP(hipEventCreate(&ctx->sort_ev[0]));
+      JB_HIP(hipEventCreate(&ctx->sort_ev[1]));
+    }
+    (void)hipEventRecord(ctx->sort_ev[0], ctx->stream);
+    st = jb_defrag_particles(ctx, mesh, swarm);
+    if (st == JB_ERR_HIP) {  // (no room for the sort's scratch records: the run goes on unsorted)
+      fprintf(stderr, "jaybenne_amd: DefragParticles skipped (%s)\n", g_err);
+      (void)hipGetLastError();
+      ctx->min_interval = 256;
+      ctx->cycles_since_sort = 0;
+      ctx->excess_ms = 0.0;
+      return JB_COMPLETE;
+    }
+    if (st != JB_COMPLETE) return st;
+    (void)hipEventRecord(ctx->sort_ev[1], ctx->stream);
+    ctx->sort_timed = true;
+    ctx->sort_n = swarm->n;
+    ctx->rate_before_sort = rate;
+    ctx->rate_ref = 0.0;
+    ctx->excess_ms = 0.0;
+    ctx->cycles_since_sort = 0;
+    ++ctx->policy_sorts;
+    *sorted = 1;
+  }
   return JB_COMPLETE;
 }
 

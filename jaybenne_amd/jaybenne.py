@@ -218,7 +218,10 @@ class MeshData:
         # also when this rank holds the whole mesh (nothing moves; its fixed cost becomes visible)
         self.force_exchange = False
         # DefragParticles after every k-th RadiationStep (0: never; the reference schedules none)
-        self.defrag_interval = 0
+        # DefragParticles: -1 (default) on the library's schedule (jb_defrag_policy: when a cycle costs
+        # 10 % more per event than the best one since the last sort), k > 0 after every k-th cycle,
+        # 0 never (the reference: slot order stays what the task list makes it)
+        self.defrag_interval = -1
         self.defrags = 0
         self._steps_since_defrag = 0
         self._make_mesh_handle(owner)
@@ -607,7 +610,14 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
         md.events += after["n_events"] - before["n_events"]
         UpdateFluid(md)
         md._steps_since_defrag += 1
-        if md.defrag_interval > 0 and md._steps_since_defrag >= md.defrag_interval:
+        if md.defrag_interval < 0:
+            sorted_ = C.c_int32(0)
+            _lib.check(md.lib.jb_defrag_policy(pkg.ctx, md.handle, C.byref(md.sv),
+                                               int(after["n_events"] - before["n_events"]), C.byref(sorted_)))
+            if sorted_.value:
+                md.defrags += 1
+                md._steps_since_defrag = 0
+        elif md.defrag_interval > 0 and md._steps_since_defrag >= md.defrag_interval:
             DefragParticles(md)
             md._steps_since_defrag = 0
     return TaskStatus.complete

@@ -205,7 +205,7 @@ class McblockDriver:
         self.md = jb.MeshData(self.pkg, self.mesh, capacity, rank, nranks, comm, halo_rings)
         # (not a parameter of the reference: DefragParticles -- here a sort of the swarm by cell, for
         # the locality of the cell gathers -- after every k-th cycle; 0 = never, as the reference)
-        self.md.defrag_interval = pin.GetOrAddInteger("jaybenne", "defrag_interval", 0)
+        self.md.defrag_interval = pin.GetOrAddInteger("jaybenne", "defrag_interval", -1)
         self.tlim = pin.GetReal("parthenon/time", "tlim")
         self.nlim = pin.GetOrAddInteger("parthenon/time", "nlim", -1)
         self.time = 0.0

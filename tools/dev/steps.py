@@ -1,11 +1,11 @@
 import sys, time, json, os
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, ".")
 import torch
 import bench
 from jaybenne_amd import mcblock
 # usage: steps.py <workload> <particles> <cycles> [defrag_interval]: wall time of every cycle
 wl = sys.argv[1]; n = int(sys.argv[2]); steps = int(sys.argv[3])
-defrag = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+defrag = int(sys.argv[4]) if len(sys.argv) > 4 else -1   # -1: the library's schedule (jb_defrag_policy)
 pin = bench.make_deck(1, n, 64, wl)
 drv = mcblock.McblockDriver(pin, device=torch.device("cuda", 0), capacity_factor=1.5)
 drv.md.defrag_interval = defrag
@@ -14,4 +14,4 @@ for s in range(steps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     drv.Step()
     torch.cuda.synchronize(); out.append(round(1e3 * (time.perf_counter() - t0), 2))
-print(json.dumps({"workload": wl, "particles": n, "defrag_interval": defrag, "ms_per_cycle": out}))
+print(json.dumps({"workload": wl, "particles": n, "defrag_interval": defrag, "sorts": drv.md.defrags, "ms_per_cycle": out}))
