@@ -188,9 +188,51 @@ static void EnsureMeshView(MeshData<Real> *md) {
         for (int i = 0; i < span; ++i)
           leaf_map[((size_t)(l0[2] + k) * v.nleaf[1] + (l0[1] + j)) * v.nleaf[0] + (l0[0] + i)] = g;
   }
-  std::vector<double> xmin(3 * nb), xmax(3 * nb), dxs(3 * nb);
+  // every block of the mesh by global id: corners and level from its logical location
+  std::vector<double> gxmin(3 * (size_t)pm->nbtotal), gxmax(3 * (size_t)pm->nbtotal);
+  std::vector<int32_t> glevel(pm->nbtotal);
+  for (int g = 0; g < pm->nbtotal; ++g) {
+    glevel[g] = locs[g].level() - pm->GetRootLevel();
+    const std::int64_t lx[3] = {locs[g].lx1(), locs[g].lx2(), locs[g].lx3()};
+    for (int d = 0; d < 3; ++d) {
+      const double ext = d < ndim ? (v.gmax[d] - v.gmin[d]) / (double)(nrb[d] << glevel[g]) : v.gmax[d] - v.gmin[d];
+      gxmin[3 * g + d] = d < ndim ? v.gmin[d] + (double)lx[d] * ext : v.gmin[d];
+      gxmax[3 * g + d] = d < ndim ? v.gmin[d] + (double)(lx[d] + 1) * ext : v.gmax[d];
+    }
+  }
+  jaybenne_amd::MeshTopology topo;
+  topo.ndim = ndim;
+  for (int d = 0; d < 3; ++d) { topo.gmin[d] = v.gmin[d]; topo.gmax[d] = v.gmax[d]; topo.nleaf[d] = v.nleaf[d]; }
+  for (int f = 0; f < 6; ++f) topo.periodic[f] = pm->mesh_bcs[f] == BoundaryFlag::periodic;
+  topo.leaf_map = leaf_map.data(); topo.nblocks_total = pm->nbtotal;
+  topo.blk_xmin = gxmin.data(); topo.blk_xmax = gxmax.data(); topo.owner = owner.data(); topo.level = glevel.data();
+  // this rank's blocks (MeshData holds them in ascending global id) + halo copies of the blocks of
+  // other ranks that touch them: a photon that wanders across the rank boundary is tracked on and
+  // handed over once, when its history is over (2 transport iterations per cycle instead of ~80)
+  const jaybenne_amd::HaloPlan halo = Globals::nranks > 1 ? jaybenne_amd::PlanHalo(topo, Globals::my_rank)
+                                                          : jaybenne_amd::HaloPlan{};
+  const int nres = Globals::nranks > 1 ? (int)halo.resident_gids.size() : nb;
+  PARTHENON_REQUIRE(Globals::nranks == 1 || halo.nowned == nb, "MeshData does not hold every block of this rank");
+  st.nowned = nb;
+  st.nhalo = nres - nb;
+  const size_t ntot = (size_t)(v.nx[0] + 2 * v.ng) * (ndim > 1 ? v.nx[1] + 2 * v.ng : 1) *
+                      (ndim > 2 ? v.nx[2] + 2 * v.ng : 1);
+  if (st.nhalo > 0) st.halo_fields = ParArray1D<Real>("jb halo copies", (size_t)st.nhalo * 11 * ntot);
+  gid.resize(nres); level.resize(nres); nbr_lev.resize(6 * (size_t)nres);
+  std::vector<int32_t> owned_flag(nres, 1);
+  std::vector<double> xmin(3 * (size_t)nres), xmax(3 * (size_t)nres), dxs(3 * (size_t)nres);
   std::vector<double *> tab[11];
-  for (auto &t : tab) t.resize(nb);
+  for (auto &t : tab) t.resize(nres);
+  for (int q = nb; q < nres; ++q) {        // the halo copies: geometry from the tree, arrays of the adapter
+    const int g = halo.resident_gids[q];
+    gid[q] = g; local_index[g] = q; level[q] = glevel[g]; owned_flag[q] = 0;
+    for (int d = 0; d < 3; ++d) {
+      xmin[3 * q + d] = gxmin[3 * g + d]; xmax[3 * q + d] = gxmax[3 * g + d];
+      dxs[3 * q + d] = (gxmax[3 * g + d] - gxmin[3 * g + d]) / (double)v.nx[d];
+    }
+    jaybenne_amd::FaceNeighbourLevels(topo, g, &nbr_lev[6 * (size_t)q]);
+    for (int f = 0; f < 11; ++f) tab[f][q] = st.halo_fields.data() + ((size_t)(q - nb) * 11 + f) * ntot;
+  }
   auto vmesh_h = vmesh;   // (device pack: element addresses are taken on the host, not dereferenced)
   for (int b = 0; b < nb; ++b) {
     auto pmb = md->GetBlockData(b)->GetBlockPointer();
@@ -223,7 +265,8 @@ static void EnsureMeshView(MeshData<Real> *md) {
     tab[10][b] = &vmesh_h(b, TopologicalElement::F3, fj::ddmc_face_prob(), 0, 0, 0);
   }
   v.leaf_map = leaf_map.data(); v.owner = owner.data(); v.local_index = local_index.data();
-  v.gid = gid.data(); v.owned = nullptr;     // no halo copies: a rank holds the blocks it owns
+  v.nblocks = nres;
+  v.gid = gid.data(); v.owned = owned_flag.data();
   v.blk_xmin = xmin.data(); v.blk_xmax = xmax.data(); v.blk_dx = dxs.data();
   v.blk_level = level.data(); v.blk_nbr_lev = nbr_lev.data();
   v.rho = tab[0].data(); v.sie = tab[1].data(); v.u = tab[2].data(); v.fleck = tab[3].data();
@@ -231,8 +274,52 @@ static void EnsureMeshView(MeshData<Real> *md) {
   v.P1 = tab[8].data(); v.P2 = tab[9].data(); v.P3 = tab[10].data();
   JB_REQUIRE(jb_mesh_create(st.ctx, &v, &st.mesh));
   st.mesh_generation = pm->nbtotal;
-  if (st.prefix.size() < (size_t)nb * v.nx[0] * v.nx[1] * v.nx[2])
-    st.prefix = ParArray1D<int>("jb prefix", (size_t)nb * v.nx[0] * v.nx[1] * v.nx[2]);
+  if (st.prefix.size() < (size_t)nres * v.nx[0] * v.nx[1] * v.nx[2])
+    st.prefix = ParArray1D<int>("jb prefix", (size_t)nres * v.nx[0] * v.nx[1] * v.nx[2]);
+  if (st.nhalo > 0 || Globals::nranks > 1) {
+    // which cells travel when the halo copies are refreshed: worked out on every rank by itself
+    st.refresh = jaybenne_amd::PlanHaloRefresh(topo, Globals::my_rank, Globals::nranks, v.nx, v.ng);
+    const auto &rp = st.refresh;
+    const size_t ns = rp.serve_blk.size(), nd = rp.dst_blk.size();
+    st.refresh_idx = ParArray1D<int>("jb halo plan", std::max<size_t>(2 * ns + 4 * nd, 1));
+    auto idx_h = Kokkos::create_mirror_view(st.refresh_idx);
+    for (size_t q = 0; q < ns; ++q) { idx_h(q) = rp.serve_blk[q]; idx_h(ns + q) = rp.serve_cell[q]; }
+    for (size_t q = 0; q < nd; ++q) {
+      idx_h(2 * ns + q) = rp.dst_blk[q]; idx_h(2 * ns + nd + q) = rp.dst_cell[q];
+      idx_h(2 * ns + 2 * nd + q) = rp.src_blk[q]; idx_h(2 * ns + 3 * nd + q) = rp.src_cell[q];
+    }
+    Kokkos::deep_copy(st.refresh_idx, idx_h);
+    st.refresh_send = ParArray1D<Real>("jb halo send", std::max<size_t>(ns, 1));
+    st.refresh_recv = ParArray1D<Real>("jb halo recv", std::max<size_t>(nd, 1));
+    RefreshHaloCopies(md);
+  }
+}
+
+// jaybenne_amd.h: jb_gather_cells -> MPI_Alltoallv -> jb_fill_cells, per field (the role Parthenon's
+// boundary exchange plays for ghost zones, mcblock_driver.cpp:58-74, for the halo copies' interiors)
+TaskStatus RefreshHaloCopies(MeshData<Real> *md) {
+  AmdState &st = State(md->GetParentPointer());
+  if (Globals::nranks == 1) return TaskStatus::complete;
+  const auto &rp = st.refresh;
+  const size_t ns = rp.serve_blk.size(), nd = rp.dst_blk.size();
+  const int *idx = st.refresh_idx.data();
+  std::vector<int> sc(Globals::nranks), sd(Globals::nranks), rc(Globals::nranks), rd(Globals::nranks);
+  int so = 0, ro = 0;
+  for (int r = 0; r < Globals::nranks; ++r) {
+    sc[r] = (int)rp.send_counts[r]; sd[r] = so; so += sc[r];
+    rc[r] = (int)rp.recv_counts[r]; rd[r] = ro; ro += rc[r];
+  }
+  for (int field : {JB_FIELD_RHO, JB_FIELD_SIE, JB_FIELD_U}) {
+    JB_REQUIRE(jb_gather_cells(st.ctx, st.mesh, field, (std::int64_t)ns, idx, idx + ns, st.refresh_send.data()));
+    JB_REQUIRE(jb_synchronize(st.ctx));
+    // (device buffers: a GPU-aware MPI; otherwise stage through host mirrors as examples/handoff_mpi.cpp does)
+    PARTHENON_MPI_CHECK(MPI_Alltoallv(st.refresh_send.data(), sc.data(), sd.data(), MPI_PARTHENON_REAL,
+                                      st.refresh_recv.data(), rc.data(), rd.data(), MPI_PARTHENON_REAL,
+                                      MPI_COMM_WORLD));
+    JB_REQUIRE(jb_fill_cells(st.ctx, st.mesh, field, (std::int64_t)nd, 1, idx + 2 * ns, idx + 2 * ns + nd,
+                             idx + 2 * ns + 2 * nd, idx + 2 * ns + 3 * nd, st.refresh_recv.data()));
+  }
+  return TaskStatus::complete;
 }
 
 // pool growth: the role of Swarm::AddEmptyParticles (sourcing.cpp:123-131)
@@ -288,7 +375,8 @@ static void SourceBlocks(Mesh *pm, AmdState &st, SourceType type, const Real t_s
   auto *mesh_md = pm->mesh_data.Get().get();
   EnsureMeshView(mesh_md);
   const int nb = mesh_md->NumBlocks();
-  std::vector<int32_t> nper(nb), gid(nb);
+  const int nres = st.nowned + st.nhalo;   // (the library counts for every resident block: halo copies source nothing)
+  std::vector<int32_t> nper(nres, 0), gid(nres, 0);
   const int src = type == SourceType::thermal ? JB_SOURCE_THERMAL : JB_SOURCE_EMISSION;
   JB_REQUIRE(jb_source_photons_count(st.ctx, st.mesh, src, dt, per_block ? 1 : nb,
                                      jaybenne_amd::SourceEpoch(st.cycle, type == SourceType::thermal
@@ -301,6 +389,7 @@ static void SourceBlocks(Mesh *pm, AmdState &st, SourceType type, const Real t_s
     if (!selected[b]) nper[b] = 0;
     counts[gid[b]] = nper[b];
   }
+  for (int q = nb; q < nres; ++q) nper[q] = 0;   // (gid of a halo copy is not looked at: it sources nothing)
   MPI_Allreduce(counts.data(), all.data(), pm->nbtotal, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
   // (the index arithmetic is the tested one: include/jaybenne_amd.hpp, PlanSource)
   const jaybenne_amd::SourcePlan pl = jaybenne_amd::PlanSource(nper, gid, all, st.next_id, st.sw.n);

@@ -41,6 +41,14 @@ struct AmdState {
   std::vector<int> pending_initial_blocks;   // local ids recorded by InitializeRadiation(mbd)
   bool initial_source_done = false;
   int mesh_generation = -1;          // Mesh::nbtotal / block list stamp the view was built for
+  // halo copies (several ranks): read-only copies of the other ranks' blocks that touch this rank's
+  // (jaybenne_amd::PlanHalo) -- eleven cell arrays each, owned by the adapter -- and the plan that
+  // refreshes their material state from the owners (jaybenne_amd::PlanHaloRefresh)
+  int nowned = 0, nhalo = 0;
+  ParArray1D<Real> halo_fields;      // [nhalo][11][ntot]
+  jaybenne_amd::HaloRefreshPlan refresh;
+  ParArray1D<int> refresh_idx;       // serve_blk | serve_cell | dst_blk | dst_cell | src_blk | src_cell
+  ParArray1D<Real> refresh_send, refresh_recv;
   ~AmdState();
 };
 
@@ -64,6 +72,11 @@ TaskStatus UpdateFluid(MeshData<Real> *md);
 // (reference main.cpp:42) -- ranks hold different numbers of blocks, so the per-block hook itself
 // must not communicate.
 TaskStatus FlushInitialSource(Mesh *pmesh);
+// The halo copies' density / sie / internal energy from their owners (gather -> MPI_Alltoallv ->
+// fill).  Run by the adapter when the mesh view is built; the HOST adds it behind its own update of
+// the material state -- mcblock_driver.cpp:58-74: after the boundary exchange and sie = u / rho of
+// HostUpdateTasks -- whenever do_feedback changes that state.
+TaskStatus RefreshHaloCopies(MeshData<Real> *md);
 
 TaskCollection RadiationStep(Mesh *pmesh, const Real t_start, const Real dt);   // jaybenne.hpp:72
 Real EstimateTimestepMesh(MeshData<Real> *md);                                  // jaybenne.hpp:75

@@ -4,16 +4,23 @@
 // CheckCompletion with its global_sync) as a host would write it around
 // jb_transport_photons / jb_pack_outgoing / jb_unpack_incoming.
 //
-//   mpiexec -n R ./handoff_mpi [cells_per_block] [blocks] [particles] [cycles]
+//   mpiexec -n R ./handoff_mpi [cells_per_block] [blocks] [particles] [cycles] [halo_rings] [dump_prefix]
 //
 // Problem: inputs/stepdiff.in in 1-D (x in [-0.5, 0.5], sigma_s = 1e3, no absorption, T = 1e5 K
 // for x < 0 and 1 K for x >= 0, reflecting walls), `blocks` meshblocks dealt to the R ranks in
-// contiguous runs.  A rank keeps ONLY the blocks it owns (no halo copies): every photon that
-// leaves a rank's blocks comes back from the transport kernel marked JB_ST_OUTGOING with the
-// global id of its destination block, is packed into 104-byte records per destination rank,
-// travels through MPI_Alltoallv (staged through host memory: the MPI of this image is not
-// GPU-aware; with a GPU-aware MPI or RCCL the device buffers go in directly) and is appended to
-// the receiver's swarm.  The loop ends when no rank moved a particle (MPI_Allreduce).
+// contiguous runs.  With halo_rings = 1 (the default) a rank also keeps read-only HALO COPIES of the
+// other ranks' blocks that touch its own (jaybenne_amd::PlanHalo; their material state arrives
+// through the refresh plan PlanHaloRefresh -> jb_gather_cells -> MPI_Alltoallv -> jb_fill_cells): a
+// photon that wanders across the rank boundary is tracked on, and handed to the owner of the block
+// it ends in once -- two transport iterations per cycle.  With halo_rings = 0 a rank keeps ONLY the
+// blocks it owns and every photon that leaves them comes back from the transport kernel at once
+// (one iteration per rank-boundary crossing of the most persistent photon: ~75 per cycle).  Either
+// way an OUTGOING photon carries the global id of its destination block, is packed into 104-byte
+// records per destination rank, travels through MPI_Alltoallv (staged through host memory: the MPI
+// of this image is not GPU-aware; with a GPU-aware MPI or RCCL the device buffers go in directly)
+// and is appended to the receiver's swarm.  The loop ends when no rank moved a particle.
+// dump_prefix: every rank writes its photons (id, x, vx, t, w, stream state; global block, cell) to
+// <dump_prefix>.<rank>.bin at the end -- what tests/test_gpu_multirank.py compares with the oracle.
 //
 // Checks (exit code 0 iff all hold): the photon count and the total weight are conserved over the
 // cycles (sigma_a = 0), every photon ends each cycle exactly at census, and the energy tally
@@ -63,6 +70,8 @@ int main(int argc, char **argv) {
   const int nblocks_total = argc > 2 ? std::atoi(argv[2]) : 8;
   const long long nparticles = argc > 3 ? std::atoll(argv[3]) : 200000;
   const int cycles = argc > 4 ? std::atoi(argv[4]) : 3;
+  const int halo_rings = argc > 5 ? std::atoi(argv[5]) : 1;
+  const char *dump_prefix = argc > 6 ? argv[6] : nullptr;
   if (nblocks_total < nranks) {
     if (rank == 0) std::fprintf(stderr, "need at least one block per rank\n");
     MPI_Finalize();
@@ -74,7 +83,7 @@ int main(int argc, char **argv) {
   HIP_OK(hipSetDevice(device));
 
   // ---- package (jaybenne::Initialize; deck values of inputs/stepdiff.in)
-  const double c = 2.99792458e10, sb = 5.670374419e-5;
+  const double c = 2.99792458e10, sb = 5.670373e-5;  // (CGS, CODATA 2010: jaybenne_amd/constants.py, examples/mcblock_amd.cpp)
   jb_params p{};
   p.num_particles = nparticles;
   p.dt = 3.335641e-11;
@@ -95,28 +104,34 @@ int main(int argc, char **argv) {
   jb_context *ctx = nullptr;
   JB_OK(jb_initialize(&p, &eos, &opac, &scat, device, &ctx));
 
-  // ---- mesh: blocks [b0, b1) belong to this rank; nothing else is resident
+  // ---- mesh: blocks [b0, b1) belong to this rank; resident = those + the halo copies
   const int ng = 2;
-  const int b0 = (int)((long long)nblocks_total * rank / nranks);
-  const int b1 = (int)((long long)nblocks_total * (rank + 1) / nranks);
-  const int nb = b1 - b0;
   const int ni = nx + 2 * ng;
   const double blen = 1.0 / nblocks_total, dx = blen / nx;
-  std::vector<int32_t> leaf_map(nblocks_total), owner(nblocks_total), local_index(nblocks_total, -1),
-      gid(nb), level(nb, 0), nbr_lev(6 * nb, 0);
-  std::vector<double> xmin(3 * nb), xmax(3 * nb), dxs(3 * nb);
+  std::vector<int32_t> leaf_map(nblocks_total), owner(nblocks_total);
+  std::vector<double> gxmin(3 * nblocks_total), gxmax(3 * nblocks_total);
   for (int g = 0; g < nblocks_total; ++g) {
     leaf_map[g] = g;
     int r = 0;
     while ((int)((long long)nblocks_total * (r + 1) / nranks) <= g) ++r;
     owner[g] = r;
+    gxmin[3 * g] = -0.5 + g * blen; gxmax[3 * g] = -0.5 + (g + 1) * blen;
+    for (int d = 1; d < 3; ++d) { gxmin[3 * g + d] = -0.5; gxmax[3 * g + d] = 0.5; }
   }
+  jaybenne_amd::MeshTopology topo;
+  topo.ndim = 1;
+  for (int d = 0; d < 3; ++d) { topo.gmin[d] = -0.5; topo.gmax[d] = 0.5; }
+  topo.nleaf[0] = nblocks_total;
+  topo.leaf_map = leaf_map.data(); topo.nblocks_total = nblocks_total;
+  topo.blk_xmin = gxmin.data(); topo.blk_xmax = gxmax.data(); topo.owner = owner.data();
+  const jaybenne_amd::HaloPlan halo = jaybenne_amd::PlanHalo(topo, rank, halo_rings);
+  const int nb = (int)halo.resident_gids.size(), nowned = halo.nowned;
+  std::vector<int32_t> local_index = halo.local_index, gid = halo.resident_gids, level(nb, 0), nbr_lev(6 * nb, 0);
+  std::vector<double> xmin(3 * nb), xmax(3 * nb), dxs(3 * nb);
   for (int l = 0; l < nb; ++l) {
-    const int g = b0 + l;
-    gid[l] = g;
-    local_index[g] = l;
-    xmin[3 * l] = -0.5 + g * blen; xmax[3 * l] = -0.5 + (g + 1) * blen; dxs[3 * l] = dx;
-    for (int d = 1; d < 3; ++d) { xmin[3 * l + d] = -0.5; xmax[3 * l + d] = 0.5; dxs[3 * l + d] = 1.0; }
+    const int g = gid[l];
+    for (int d = 0; d < 3; ++d) { xmin[3 * l + d] = gxmin[3 * g + d]; xmax[3 * l + d] = gxmax[3 * g + d]; }
+    dxs[3 * l] = dx; dxs[3 * l + 1] = dxs[3 * l + 2] = 1.0;
   }
   // fields: one [ni] array per block and field, filled with the initial condition of mcblock.cpp:187-199
   const char *fields[] = {"rho", "sie", "u", "fleck", "tally", "edelta", "src_ew", "src_num"};
@@ -131,6 +146,8 @@ int main(int argc, char **argv) {
       u[i] = rho[i] * sie[i];
     }
     for (int f = 0; f < 8; ++f) fptr[f][l] = dev_alloc<double>(ni);
+    if (l >= nowned)  // a halo copy: its interior arrives from the owner below (ghost cells: as computed)
+      for (int i = ng; i < ng + nx; ++i) rho[i] = sie[i] = u[i] = 0.0;
     HIP_OK(hipMemcpy(fptr[0][l], rho.data(), ni * sizeof(double), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(fptr[1][l], sie.data(), ni * sizeof(double), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(fptr[2][l], u.data(), ni * sizeof(double), hipMemcpyHostToDevice));
@@ -145,13 +162,47 @@ int main(int argc, char **argv) {
   v.rank = rank;
   for (int d = 0; d < 3; ++d) { v.gmin[d] = -0.5; v.gmax[d] = 0.5; }
   v.leaf_map = leaf_map.data(); v.owner = owner.data(); v.local_index = local_index.data();
-  v.gid = gid.data(); v.owned = nullptr;
+  v.gid = gid.data(); v.owned = halo.owned.data();
   v.blk_xmin = xmin.data(); v.blk_xmax = xmax.data(); v.blk_dx = dxs.data();
   v.blk_level = level.data(); v.blk_nbr_lev = nbr_lev.data();
   v.rho = fptr[0].data(); v.sie = fptr[1].data(); v.u = fptr[2].data(); v.fleck = fptr[3].data();
   v.tally = fptr[4].data(); v.edelta = fptr[5].data(); v.src_ew = fptr[6].data(); v.src_num = fptr[7].data();
   jb_mesh *mesh = nullptr;
   JB_OK(jb_mesh_create(ctx, &v, &mesh));
+
+  // ---- the halo copies' material state: the owners' interior cells (the refresh a host repeats
+  //      after every UpdateFluid when do_feedback is on; here once)
+  {
+    const int nxs[3] = {nx, 1, 1};
+    const jaybenne_amd::HaloRefreshPlan rp = jaybenne_amd::PlanHaloRefresh(topo, rank, nranks, nxs, ng, halo_rings);
+    auto upload = [&](const std::vector<int32_t> &h) {
+      int32_t *d = dev_alloc<int32_t>(h.size());
+      if (!h.empty()) HIP_OK(hipMemcpy(d, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      return d;
+    };
+    int32_t *serve_blk = upload(rp.serve_blk), *serve_cell = upload(rp.serve_cell);
+    int32_t *dst_blk = upload(rp.dst_blk), *dst_cell = upload(rp.dst_cell);
+    int32_t *src_blk = upload(rp.src_blk), *src_cell = upload(rp.src_cell);
+    const size_t nsend = rp.serve_blk.size(), nrecv = rp.dst_blk.size();
+    double *send_dev = dev_alloc<double>(nsend), *recv_dev = dev_alloc<double>(nrecv);
+    std::vector<double> sbuf(nsend + 1), rbuf(nrecv + 1);
+    std::vector<int> hc(nranks), hd(nranks), gc(nranks), gd(nranks);
+    int so = 0, ro = 0;
+    for (int r = 0; r < nranks; ++r) {
+      hc[r] = (int)rp.send_counts[r]; hd[r] = so; so += hc[r];
+      gc[r] = (int)rp.recv_counts[r]; gd[r] = ro; ro += gc[r];
+    }
+    for (int field : {JB_FIELD_RHO, JB_FIELD_SIE, JB_FIELD_U}) {
+      JB_OK(jb_gather_cells(ctx, mesh, field, (int64_t)nsend, serve_blk, serve_cell, send_dev));
+      JB_OK(jb_synchronize(ctx));
+      if (nsend) HIP_OK(hipMemcpy(sbuf.data(), send_dev, nsend * sizeof(double), hipMemcpyDeviceToHost));
+      MPI_Alltoallv(sbuf.data(), hc.data(), hd.data(), MPI_DOUBLE, rbuf.data(), gc.data(), gd.data(), MPI_DOUBLE,
+                    MPI_COMM_WORLD);
+      if (nrecv) HIP_OK(hipMemcpy(recv_dev, rbuf.data(), nrecv * sizeof(double), hipMemcpyHostToDevice));
+      JB_OK(jb_fill_cells(ctx, mesh, field, (int64_t)nrecv, 1, dst_blk, dst_cell, src_blk, src_cell, recv_dev));
+    }
+    JB_OK(jb_synchronize(ctx));
+  }
 
   // ---- swarm: one pool per rank, room for every photon of the problem (they may all come here)
   jb_swarm_view sw{};
@@ -170,12 +221,10 @@ int main(int argc, char **argv) {
   JB_OK(jb_update_derived_transport_fields(ctx, mesh, p.dt));
   JB_OK(jb_source_photons_count(ctx, mesh, JB_SOURCE_THERMAL, 0.0, 1, 0u, nper.data(), prefix));
   std::vector<long long> counts(nblocks_total, 0), all_counts(nblocks_total, 0);
-  for (int l = 0; l < nb; ++l) counts[b0 + l] = nper[l];
+  for (int l = 0; l < nb; ++l) counts[gid[l]] = nper[l];   // (halo copies source nothing: zeros)
   MPI_Allreduce(counts.data(), all_counts.data(), nblocks_total, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
   // (the plan shared with the single-rank tasks and the Parthenon adapter: include/jaybenne_amd.hpp)
-  std::vector<int32_t> gids(nb);
-  for (int l = 0; l < nb; ++l) gids[l] = b0 + l;
-  const jaybenne_amd::SourcePlan plan = jaybenne_amd::PlanSource(nper, gids, all_counts, 0ull, 0);
+  const jaybenne_amd::SourcePlan plan = jaybenne_amd::PlanSource(nper, gid, all_counts, 0ull, 0);
   const long long n_global0 = (long long)plan.next_id;
   JB_OK(jb_source_photons_fill(ctx, mesh, &sw, JB_SOURCE_THERMAL, 0.0, 0.0, nper.data(), prefix,
                                plan.slot_base.data(), plan.id_base.data()));
@@ -249,7 +298,7 @@ int main(int argc, char **argv) {
     MPI_Allreduce(&unf, &unf_g, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
     double tally_local = 0.0, tally_global = 0.0;
     std::vector<double> tl(ni);
-    for (int l = 0; l < nb; ++l) {
+    for (int l = 0; l < nowned; ++l) {
       HIP_OK(hipMemcpy(tl.data(), fptr[4][l], ni * sizeof(double), hipMemcpyDeviceToHost));
       for (int i = ng; i < ng + nx; ++i) tally_local += tl[i] * dx;
     }
@@ -269,9 +318,39 @@ int main(int argc, char **argv) {
   MPI_Allreduce(&ev, &ev_g, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
   MPI_Allreduce(&handed_total, &handed_g, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
   if (rank == 0)
-    std::printf("%d rank(s), %d blocks: %lld events, %lld photons handed between ranks in %lld transport "
-                "iterations  -> %s\n", nranks, nblocks_total, ev_g, handed_g, iterations_total,
+    std::printf("%d rank(s), %d blocks, %d halo ring(s): %lld events, %lld photons handed between ranks in %lld "
+                "transport iterations (%.2f per cycle)  -> %s\n", nranks, nblocks_total, halo_rings, ev_g, handed_g,
+                iterations_total, (double)iterations_total / cycles,
                 ok && (nranks == 1 || handed_g > 0) ? "HANDOFF OK" : "HANDOFF FAILED");
+  if (dump_prefix) {  // this rank's photons: n, then per photon id, x, vx, t, w, rng (8 bytes each), global block, ip (4 + 4)
+    const size_t n = (size_t)sw.n;
+    std::vector<uint64_t> id(n), rng(n);
+    std::vector<double> x(n), vx(n), t(n), w(n);
+    std::vector<int32_t> blk(n), ip(n);
+    if (n) {
+      HIP_OK(hipMemcpy(id.data(), sw.id, n * 8, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(rng.data(), sw.rng, n * 8, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(x.data(), sw.x, n * 8, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(vx.data(), sw.vx, n * 8, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(t.data(), sw.t, n * 8, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(w.data(), sw.w, n * 8, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(blk.data(), sw.blk, n * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(ip.data(), sw.ip, n * 4, hipMemcpyDeviceToHost));
+    }
+    char name[512];
+    std::snprintf(name, sizeof name, "%s.%d.bin", dump_prefix, rank);
+    FILE *fh = std::fopen(name, "wb");
+    if (!fh) { std::fprintf(stderr, "cannot write %s\n", name); MPI_Abort(MPI_COMM_WORLD, 5); }
+    const uint64_t n64 = n;
+    std::fwrite(&n64, 8, 1, fh);
+    for (size_t q = 0; q < n; ++q) {
+      const int32_t g = gid[(size_t)blk[q]];
+      std::fwrite(&id[q], 8, 1, fh); std::fwrite(&x[q], 8, 1, fh); std::fwrite(&vx[q], 8, 1, fh);
+      std::fwrite(&t[q], 8, 1, fh); std::fwrite(&w[q], 8, 1, fh); std::fwrite(&rng[q], 8, 1, fh);
+      std::fwrite(&g, 4, 1, fh); std::fwrite(&ip[q], 4, 1, fh);
+    }
+    std::fclose(fh);
+  }
   const int rcode = ok && (nranks == 1 || handed_g > 0) ? 0 : 1;
   jb_mesh_destroy(mesh);
   jb_finalize(ctx);

@@ -15,6 +15,7 @@
 #define JAYBENNE_AMD_HPP_
 
 #include <cstdint>
+#include <cmath>
 #include <functional>
 #include <memory>
 #include <numeric>
@@ -161,6 +162,149 @@ inline SourcePlan PlanSource(const std::vector<int32_t> &nper_local, const std::
 // (jb_source_photons_count accepts epochs below 2^20: half a million cycles.)
 inline uint32_t SourceEpoch(uint64_t cycle, SourceType st) {
   return (uint32_t)(2u * cycle + (st == SourceType::emission ? 1u : 0u));
+}
+
+// ---- halo copies (several ranks; shared by examples/handoff_mpi.cpp, the Parthenon adapter and,
+// restated in numpy, the Python host: jaybenne_amd/mesh.py Mesh.neighbours, halo.py) -------------
+// A rank keeps read-only copies of the other ranks' blocks that TOUCH one of its own (face, edge or
+// corner, through periodic boundaries too).  A photon that wanders across the rank boundary keeps
+// being tracked in flight and is handed to the owner of the block it ends in ONCE, when its history
+// is over: two transport iterations per cycle instead of one per rank-boundary crossing of the most
+// persistent photon (reference jaybenne.cpp:113-131 iterates ~80 times on BASELINE configs[1]).
+//   Mesh description (what jb_mesh_view holds for ALL blocks of the mesh, by global id):
+//   leaf_map over the finest-level leaf grid nleaf[3], block corners, mesh boundary kinds
+//   (periodic[2 d + side]), owner[g].
+// Result: resident_gids = this rank's blocks (ascending global id) followed by its halo copies
+// (ascending), owned[] for jb_mesh_view::owned, local_index[g] (-1: not resident).
+struct HaloPlan {
+  std::vector<int32_t> resident_gids, owned, local_index;
+  int nowned = 0;
+};
+struct MeshTopology {
+  int ndim = 1;
+  double gmin[3] = {0, 0, 0}, gmax[3] = {1, 1, 1};
+  int nleaf[3] = {1, 1, 1};
+  bool periodic[6] = {false, false, false, false, false, false};
+  const int32_t *leaf_map = nullptr;   // [nleaf[2]][nleaf[1]][nleaf[0]] -> global block id
+  int nblocks_total = 0;
+  const double *blk_xmin = nullptr, *blk_xmax = nullptr;   // [nblocks_total][3]
+  const int32_t *owner = nullptr;                           // [nblocks_total]
+  const int32_t *level = nullptr;                           // [nblocks_total] (FaceNeighbourLevels only)
+};
+// jb_mesh_view::blk_nbr_lev of block g: the level of the block behind each face (2 axis + upper), the
+// block's own level at a mesh boundary that is not periodic and on an inactive axis
+// (jaybenne.cpp:341-351) -- what a host that keeps a HALO COPY of g has to supply for it
+inline void FaceNeighbourLevels(const MeshTopology &T, int g, int32_t out[6]) {
+  for (int f = 0; f < 6; ++f) out[f] = T.level[g];
+  long long l0[3] = {0, 0, 0}, cnt[3] = {1, 1, 1};
+  for (int d = 0; d < T.ndim; ++d) {
+    const double fine = (T.gmax[d] - T.gmin[d]) / (double)T.nleaf[d];
+    l0[d] = (long long)std::llround((T.blk_xmin[3 * g + d] - T.gmin[d]) / fine);
+    cnt[d] = (long long)std::llround((T.blk_xmax[3 * g + d] - T.blk_xmin[3 * g + d]) / fine);
+  }
+  for (int d = 0; d < T.ndim; ++d)
+    for (int up = 0; up < 2; ++up) {
+      long long l[3] = {l0[0], l0[1], l0[2]};   // (any leaf behind the face: 2:1 balance, one level there)
+      l[d] = up ? l0[d] + cnt[d] : l0[d] - 1;
+      if (l[d] < 0) { if (!T.periodic[2 * d]) continue; l[d] += T.nleaf[d]; }
+      else if (l[d] >= T.nleaf[d]) { if (!T.periodic[2 * d + 1]) continue; l[d] -= T.nleaf[d]; }
+      out[2 * d + up] = T.level[T.leaf_map[(l[2] * T.nleaf[1] + l[1]) * T.nleaf[0] + l[0]]];
+    }
+}
+// leaf blocks that touch block b: the blocks under the one-leaf-wide shell of leaves around it
+inline void TouchingBlocks(const MeshTopology &T, int b, std::vector<int32_t> *out) {
+  long long lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // the shell's leaf range per axis, inclusive
+  for (int d = 0; d < 3; ++d) {
+    if (d >= T.ndim) continue;
+    const double fine = (T.gmax[d] - T.gmin[d]) / (double)T.nleaf[d];
+    lo[d] = (long long)std::llround((T.blk_xmin[3 * b + d] - T.gmin[d]) / fine) - 1;
+    hi[d] = (long long)std::llround((T.blk_xmax[3 * b + d] - T.gmin[d]) / fine);
+  }
+  for (long long k = lo[2]; k <= hi[2]; ++k)
+    for (long long j = lo[1]; j <= hi[1]; ++j)
+      for (long long i = lo[0]; i <= hi[0]; ++i) {
+        long long l[3] = {i, j, k};
+        bool inside = true;
+        for (int d = 0; d < T.ndim; ++d) {
+          if (l[d] < 0) { if (T.periodic[2 * d]) l[d] += T.nleaf[d]; else inside = false; }
+          else if (l[d] >= T.nleaf[d]) { if (T.periodic[2 * d + 1]) l[d] -= T.nleaf[d]; else inside = false; }
+        }
+        if (!inside) continue;
+        const int32_t g = T.leaf_map[(l[2] * T.nleaf[1] + l[1]) * T.nleaf[0] + l[0]];
+        if (g != b) out->push_back(g);
+      }
+}
+inline HaloPlan PlanHalo(const MeshTopology &T, int rank, int rings = 1) {
+  HaloPlan pl;
+  std::vector<char> have((size_t)T.nblocks_total, 0), is_halo((size_t)T.nblocks_total, 0);
+  std::vector<int32_t> frontier;
+  for (int g = 0; g < T.nblocks_total; ++g)
+    if (T.owner[g] == rank) { have[g] = 1; frontier.push_back(g); pl.resident_gids.push_back(g); }
+  pl.nowned = (int)pl.resident_gids.size();
+  for (int ring = 0; ring < rings; ++ring) {
+    std::vector<int32_t> touched, next;
+    for (int32_t b : frontier) TouchingBlocks(T, b, &touched);
+    for (int32_t g : touched)
+      if (!have[g]) { have[g] = 1; is_halo[g] = 1; next.push_back(g); }
+    frontier.swap(next);
+  }
+  for (int g = 0; g < T.nblocks_total; ++g)
+    if (is_halo[g]) pl.resident_gids.push_back(g);
+  pl.owned.assign(pl.resident_gids.size(), 0);
+  for (int q = 0; q < pl.nowned; ++q) pl.owned[q] = 1;
+  pl.local_index.assign((size_t)T.nblocks_total, -1);
+  for (size_t q = 0; q < pl.resident_gids.size(); ++q) pl.local_index[(size_t)pl.resident_gids[q]] = (int32_t)q;
+  return pl;
+}
+// The refresh of the halo copies' interior cells after the owner changed a field (UpdateFluid:
+// internal_energy; mcblock_driver.cpp:58-74 runs Parthenon's boundary exchange there): every rank
+// can work out, without talking to anybody, which of its blocks the others keep copies of.
+//   serve_*      (local block, cell) of the cells this rank sends, grouped by destination rank in
+//                rank order -- jb_gather_cells packs them; send_counts[r] cells go to rank r
+//   dst_*, src_* arguments of jb_fill_cells with one sample per destination: interior cell c of halo
+//                copy lb takes element src_cell of the receive buffer (src_blk = -1), which holds
+//                recv_counts[r] values from rank r, in rank order
+// Cells are the interior cells of a block in (k, j, i) order, as flat indices into [nk][nj][ni].
+struct HaloRefreshPlan {
+  std::vector<int32_t> serve_blk, serve_cell, dst_blk, dst_cell, src_blk, src_cell;
+  std::vector<int64_t> send_counts, recv_counts;
+};
+inline HaloRefreshPlan PlanHaloRefresh(const MeshTopology &T, int rank, int nranks, const int nx[3], int ng,
+                                       int rings = 1) {
+  HaloRefreshPlan pl;
+  pl.send_counts.assign((size_t)nranks, 0);
+  pl.recv_counts.assign((size_t)nranks, 0);
+  const int is = ng, js = T.ndim >= 2 ? ng : 0, ks = T.ndim >= 3 ? ng : 0;
+  const int ni = nx[0] + 2 * is, nj = nx[1] + 2 * js;
+  std::vector<int32_t> interior;
+  for (int k = 0; k < nx[2]; ++k)
+    for (int j = 0; j < nx[1]; ++j)
+      for (int i = 0; i < nx[0]; ++i) interior.push_back(((k + ks) * nj + (j + js)) * ni + (i + is));
+  const HaloPlan mine = PlanHalo(T, rank, rings);
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) continue;
+    const HaloPlan theirs = PlanHalo(T, r, rings);
+    for (size_t q = (size_t)theirs.nowned; q < theirs.resident_gids.size(); ++q) {
+      const int32_t g = theirs.resident_gids[q];
+      if (T.owner[g] != rank) continue;          // rank r keeps a copy of MY block g
+      for (int32_t c : interior) { pl.serve_blk.push_back(mine.local_index[(size_t)g]); pl.serve_cell.push_back(c); }
+      pl.send_counts[(size_t)r] += (int64_t)interior.size();
+    }
+  }
+  int64_t off = 0;
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) continue;
+    for (size_t q = (size_t)mine.nowned; q < mine.resident_gids.size(); ++q) {
+      const int32_t g = mine.resident_gids[q];
+      if (T.owner[g] != r) continue;             // my copy of rank r's block g
+      for (int32_t c : interior) {
+        pl.dst_blk.push_back((int32_t)q); pl.dst_cell.push_back(c);
+        pl.src_blk.push_back(-1); pl.src_cell.push_back((int32_t)off++);
+      }
+      pl.recv_counts[(size_t)r] += (int64_t)interior.size();
+    }
+  }
+  return pl;
 }
 
 // ---- tasks (jaybenne.hpp:59-76) ----------------------------------------------------------------

@@ -243,21 +243,55 @@ def test_two_ranks_with_material_feedback(gpu_device, tmp_path):
         np.testing.assert_allclose(p["tally"][sl], O.fields["tally"][p["gids"]][sl], rtol=1e-11)
 
 
-def test_c_level_mpi_handoff(gpu_device):
+def _read_photon_dumps(prefix, nranks):
+    rec = np.dtype([("id", "<u8"), ("x", "<f8"), ("vx", "<f8"), ("t", "<f8"), ("w", "<f8"), ("rng", "<u8"),
+                    ("gblk", "<i4"), ("ip", "<i4")])
+    parts = []
+    for r in range(nranks):
+        with open(f"{prefix}.{r}.bin", "rb") as fh:
+            n = int(np.frombuffer(fh.read(8), dtype="<u8")[0])
+            parts.append(np.frombuffer(fh.read(), dtype=rec, count=n))
+    out = np.concatenate(parts)
+    return out[np.argsort(out["id"])]
+
+
+def test_c_level_mpi_handoff(gpu_device, tmp_path):
     """examples/handoff_mpi.cpp: the hand-off driven from C++ over MPI (no Python, no PyTorch in
-    the rank processes): three ranks that own disjoint runs of blocks and keep no halo copies,
-    so every block-boundary crossing between ranks goes through jb_pack_outgoing ->
-    MPI_Alltoallv -> jb_unpack_incoming; photon count, total weight, census time and the tally
-    integral are checked by the program every cycle."""
+    the rank processes), three ranks.  With halo copies planned by the C++ mirror of the task
+    interface (include/jaybenne_amd.hpp: PlanHalo, PlanHaloRefresh -- what the Parthenon adapter's
+    mesh-view builder uses too) a cycle takes TWO transport iterations and every photon comes out
+    bit-identical to the single-process oracle; without them (halo_rings = 0: a rank keeps only
+    the blocks it owns) every rank-boundary crossing goes through jb_pack_outgoing ->
+    MPI_Alltoallv -> jb_unpack_incoming, dozens of iterations per cycle, the same photons.  Photon
+    count, total weight, census time and the tally integral are checked by the program every
+    cycle."""
+    import re
     import shutil
     import subprocess
+    from oracle import orc
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
     if not os.path.exists(mpiexec) or not os.path.exists("/opt/conda/lib/libmpi.so"):
         pytest.skip("no MPI installation in this image")
     build = subprocess.run(["make", "-C", os.path.join(root, "examples"), "mpi"], capture_output=True, text=True)
     assert build.returncode == 0, build.stdout + build.stderr
-    run = subprocess.run([mpiexec, "-n", "3", os.path.join(root, "examples", "handoff_mpi"), "16", "8",
-                          "200000", "3"], capture_output=True, text=True, timeout=240)
-    assert run.returncode == 0 and "HANDOFF OK" in run.stdout, run.stdout + run.stderr
-    assert run.stdout.count(" ok") == 3
+    ov = {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 16, "jaybenne/num_particles": 200000}
+    O, mesh, _ = make_oracle(load_deck("stepdiff", ov), orc.MATH_PORTABLE)
+    run_oracle_cycles(O, load_deck("stepdiff", ov), 3)
+    order = np.argsort(O.sw["id"][:O.n])
+    per_cycle = {}
+    for rings in (1, 0):
+        prefix = str(tmp_path / f"photons{rings}")
+        run = subprocess.run([mpiexec, "-n", "3", os.path.join(root, "examples", "handoff_mpi"), "16", "8",
+                              "200000", "3", str(rings), prefix], capture_output=True, text=True, timeout=240)
+        assert run.returncode == 0 and "HANDOFF OK" in run.stdout, run.stdout + run.stderr
+        assert run.stdout.count(" ok") == 3
+        per_cycle[rings] = float(re.search(r"\(([0-9.]+) per cycle\)", run.stdout).group(1))
+        g = _read_photon_dumps(prefix, 3)
+        assert len(g) == O.n
+        assert np.array_equal(g["id"], O.sw["id"][:O.n][order])
+        for k in ("x", "vx", "t", "w", "rng", "ip"):
+            assert np.array_equal(g[k], O.sw[k][:O.n][order]), (rings, k)
+        assert np.array_equal(g["gblk"], O.sw["blk"][:O.n][order])
+    assert per_cycle[1] == 2.0            # transport, hand-off of the photons that ended in a halo copy, done
+    assert per_cycle[0] > 20.0            # one iteration per rank-boundary crossing of the most persistent photon
