@@ -121,6 +121,61 @@ def test_shared_source_plan_is_partition_independent(tmp_path):
     assert "jaybenne_amd::PlanSource(" in text and "jaybenne_amd::SourceEpoch(" in text
 
 
+@pytest.mark.parametrize("deck,overrides,nranks", [
+    ("stepdiff_smr", {}, 4),                                        # 2-D, 2 levels, 20 blocks
+    ("stepdiff_smr_hybrid", {"_level2": True}, 5),                   # 2-D, 3 levels, 32 blocks
+    ("stepdiff", {"parthenon/mesh/nx1": 16, "parthenon/mesh/nx2": 16, "parthenon/mesh/nx3": 32,
+                  "parthenon/meshblock/nx1": 4, "parthenon/meshblock/nx2": 4,
+                  "parthenon/meshblock/nx3": 4}, 8),                 # 3-D, periodic in y and z, 128 blocks
+    ("stepdiff", {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 16}, 3),   # examples/handoff_mpi.cpp
+])
+def test_shared_halo_plan_matches_the_python_host(tmp_path, deck, overrides, nranks):
+    """include/jaybenne_amd.hpp: PlanHalo / FaceNeighbourLevels / PlanHaloRefresh -- the halo copies as the
+    C++ hosts (examples/handoff_mpi.cpp, the Parthenon adapter) plan them -- against the Python host's
+    Mesh.neighbours / blk_nbr_lev (tests/test_comm_gloo.py, test_mesh_topology.py) on the reference's meshes."""
+    import shutil
+    import subprocess
+    import numpy as np
+    from jaybenne_amd.deck import load_deck
+    from jaybenne_amd.mesh import BC_PERIODIC, Mesh
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no g++")
+    ov = dict(overrides)
+    level2 = ov.pop("_level2", False)
+    pin = load_deck(deck, ov)
+    if level2:
+        pin.load_string("<parthenon/static_refinement2>\nlevel = 2\nx1min = -0.125\nx1max = 0.125\n"
+                        "x2min = -0.125\nx2max = 0.125\nx3min = -0.25\nx3max = 0.25\n")
+    mesh = Mesh.from_deck(pin)
+    owner = mesh.partition(nranks)
+    lines = [f"{mesh.ndim} {mesh.nblocks} {nranks}"]
+    for d in range(3):
+        lines.append(f"{float(mesh.gmin[d])!r} {float(mesh.gmax[d])!r} {mesh.nleaf[d]} {mesh.nx[d]}")
+    lines.append(" ".join("1" if mesh.mesh_bc[f] == BC_PERIODIC else "0" for f in range(6)))
+    lines.append(" ".join(str(int(v)) for v in np.asarray(mesh.leaf_map).ravel()))
+    for g in range(mesh.nblocks):
+        lines.append(f"{int(owner[g])} {int(mesh.blk_level[g])} " +
+                     " ".join(f"{float(mesh.blk_xmin[g, d])!r} {float(mesh.blk_xmax[g, d])!r}" for d in range(3)))
+    exe = tmp_path / "plan_halo_test"
+    res = subprocess.run([cxx, "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                          os.path.join(ROOT, "tests", "plan_halo_test.cpp"), "-o", str(exe)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    res = subprocess.run([str(exe)], input="\n".join(lines) + "\n", capture_output=True, text=True)
+    assert res.returncode == 0 and "plan_halo ok" in res.stdout, res.stdout[-2000:] + res.stderr
+    halos = {int(l.split()[1]): [int(v) for v in l.split()[3:]] for l in res.stdout.splitlines() if l.startswith("rank ")}
+    for r in range(nranks):
+        mine = np.nonzero(owner == r)[0]
+        assert halos[r] == [int(g) for g in mesh.neighbours(mine, 1)], r
+    for l in res.stdout.splitlines():
+        if l.startswith("nbr "):
+            g, *lev = (int(v) for v in l.split()[1:])
+            assert lev == [int(v) for v in mesh.blk_nbr_lev[g]], g
+    text = open(os.path.join(ROOT, "adapters", "parthenon", "jaybenne_amd_tasks.cpp")).read()
+    assert "jaybenne_amd::PlanHalo(" in text and "jaybenne_amd::PlanHaloRefresh(" in text
+
+
 def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
     """The tracking kernels are tuned for three waves per SIMD (512 / 3 -> 168 vector registers,
     allocated in eights); a change that pushes one of them over the edge silently costs a wave
