@@ -364,9 +364,11 @@ double jb_estimate_timestep(const jb_context *ctx);
 
 /* RadiationStep(pmesh, t_start, dt) for a mesh held by ONE rank -- jaybenne.hpp:72,
  * jaybenne.cpp:68-151: derived fields, emission source, transport to completion, census tally,
- * fluid update.  next_id: first unused stream id (updated); epoch: source-call counter (updated). */
+ * fluid update.  next_id: first unused stream id (updated); cycle: the number of radiation cycles
+ * taken so far (0 after initialisation; incremented at entry) -- the emission source of cycle k keys
+ * its per-cell rounding streams with epoch k, as every host does (jaybenne_amd.hpp: SourceEpoch). */
 jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm, double t_start,
-                            double dt, uint64_t *next_id, uint32_t *epoch, int32_t *prefix_dev);
+                            double dt, uint64_t *next_id, uint32_t *cycle, int32_t *prefix_dev);
 
 /* ---- debug entry points (parity tests drive the device functions directly) ---------------- */
 jb_status jb_debug_philox(jb_context *ctx, const uint32_t ctr[4], const uint32_t key[2],

@@ -104,7 +104,7 @@ class MeshData {
 
   jb_swarm_view swarm{};   // n, capacity and the device arrays
   uint64_t next_id = 0;    // first unused random-stream id
-  uint32_t epoch = 0;      // source-call counter (keys the per-cell rounding streams)
+  uint64_t cycle = 0;      // RadiationStep counter (keys the per-cell rounding streams: SourceEpoch); 0 = initialisation
   int64_t events = 0;      // tracking events so far
   // DefragParticles: -1 (default) when the library's policy asks for it (jb_defrag_policy: a cycle
   // that costs 10 % more per event than the best one since the last sort); k > 0 after every k-th
@@ -157,11 +157,15 @@ inline SourcePlan PlanSource(const std::vector<int32_t> &nper_local, const std::
   return pl;
 }
 // The key of the per-cell rounding streams (`epoch` of jb_source_photons_count) as a function of
-// the cycle and the source type, so that every rank -- whatever the number of blocks it calls the
-// source for -- uses the same one: 0 for the initial thermal source, then 2 cycle + type.
-// (jb_source_photons_count accepts epochs below 2^20: half a million cycles.)
+// the cycle (0 = initialisation, k = the k-th RadiationStep) and the source type, so that every rank
+// of every host -- whatever the number of blocks it calls the source for -- uses the same one: 0 for
+// the initial thermal source, k for the emission source of cycle k -- the order in which a run makes
+// its source calls (jaybenne.cpp:104-105, 570-578); a thermal source inside a cycle, which no task
+// list of the reference makes, gets a key of its own.  (jb_source_photons_count accepts epochs below
+// 2^20: half a million cycles.)
 inline uint32_t SourceEpoch(uint64_t cycle, SourceType st) {
-  return (uint32_t)(2u * cycle + (st == SourceType::emission ? 1u : 0u));
+  if (st == SourceType::emission) return (uint32_t)cycle;
+  return cycle == 0 ? 0u : (uint32_t)((1u << 19) | cycle);
 }
 
 // ---- halo copies (several ranks; shared by examples/handoff_mpi.cpp, the Parthenon adapter and,
@@ -323,9 +327,8 @@ inline TaskStatus SourcePhotons(MeshData *md, SourceType st, const Real t_start,
   const int type = st == SourceType::thermal ? JB_SOURCE_THERMAL : JB_SOURCE_EMISSION;
   const int nb = md->nblocks();
   std::vector<int32_t> nper(nb, 0);
-  Check(jb_source_photons_count(md->ctx(), md->mesh(), type, dt, per_block ? 1 : nb, md->epoch,
-                                nper.data(), md->prefix_dev()));
-  md->epoch += 1;
+  Check(jb_source_photons_count(md->ctx(), md->mesh(), type, dt, per_block ? 1 : nb,
+                                SourceEpoch(md->cycle, st), nper.data(), md->prefix_dev()));
   // (this rank holds the whole mesh: global id = local index, global counts = local counts)
   std::vector<int32_t> gid(nb);
   std::vector<long long> all(nb);
@@ -376,6 +379,7 @@ inline void InitializeRadiation(MeshData *md, bool is_thermal) {
 // jaybenne::RadiationStep(pmesh, t_start, dt) for one rank -- jaybenne.cpp:68-151
 inline TaskStatus RadiationStep(MeshData *md, const Real t_start, const Real dt) {
   const jb_params &p = md->pkg().params();
+  md->cycle += 1;
   UpdateDerivedTransportFields(md, dt);
   SourcePhotons(md, SourceType::emission, t_start, dt);
   Check(jb_zero_energy_tally(md->ctx(), md->mesh()));

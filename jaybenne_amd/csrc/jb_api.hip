@@ -93,6 +93,10 @@ struct jb_mesh {
   const char *last_pair = "";     // ... and the k_ddmc_all launched beside it (gray DDMC), or ""
   const DevMesh *dm_dev = nullptr;  // copy of dm in device memory (k_hybrid reads the view through it)
   const int *nbr_dq = nullptr;      // k_imc_cell: change of the cell's byte offset per (block, face) crossing
+  // "some cell takes IMC steps" (DevMesh::not_all_ddmc) as the host last read it: -1 = not since
+  // UpdateDerivedTransportFields rewrote it (the first DDMC transport call of a cycle reads it back,
+  // one synchronisation; the further transport iterations of a multi-rank cycle reuse the answer)
+  int not_all_ddmc_host = -1;
 };
 
 __global__ void k_rcp_refined(double b, double *out) { *out = m_rcp_refined(b); }
@@ -588,6 +592,7 @@ extern "C" jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh
     if (M.ddmc_cell) {
       // JB_NO_DDMC_ALL=1 keeps the general kernel also on all-DDMC meshes (tests, A/B)
       JB_HIP(hipMemsetAsync(M.not_all_ddmc, ctx->no_ddmc_all ? 1 : 0, sizeof(int), ctx->stream));
+      mesh->not_all_ddmc_host = -1;
       const int gp = grid_for(ctx, cells);
       if (M.ndim == 1) hipLaunchKernelGGL(k_ddmc_pack<1>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
       else if (M.ndim == 2) hipLaunchKernelGGL(k_ddmc_pack<2>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
@@ -744,12 +749,15 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
     // and DDMC cells: k_hybrid.  Both keep the per-block tables in LDS, so meshes with more resident
     // blocks than fit there stay with the general kernel below.
     if (gray && M.ddmc_cell && M.nblocks <= kLdsBlocks) {
-      int *flag_h = (int *)(ctx->counters_h + kCounterWords - 1);
-      *flag_h = 1;
-      (void)hipMemcpyAsync(flag_h, M.not_all_ddmc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-      JB_HIP(hipStreamSynchronize(ctx->stream));
+      if (mesh->not_all_ddmc_host < 0) {
+        int *flag_h = (int *)(ctx->counters_h + kCounterWords - 1);
+        *flag_h = 1;
+        (void)hipMemcpyAsync(flag_h, M.not_all_ddmc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        JB_HIP(hipStreamSynchronize(ctx->stream));
+        mesh->not_all_ddmc_host = *flag_h != 0 ? 1 : 0;
+      }
       const bool noabs_h = ctx->dp.kappa_a == 0.0;
-      if (*flag_h == 0) {
+      if (mesh->not_all_ddmc_host == 0) {
         // The quad-cooperative gather (jb_kernel_ddmc.hpp) addresses the step records with 32-bit byte
         // offsets; it pays once the records no longer sit in the CU's vector L1 (measured, ms per
         // 1e8 histories: 128^3 cells 31.5 -> 27.9, 64^3 7.2 -> 6.9, 32^3 equal, 128 cells in 1-D
@@ -1386,21 +1394,21 @@ extern "C" jb_status jb_fill_cells(jb_context *ctx, jb_mesh *mesh, int field, in
 // RadiationStep for a mesh held entirely by this rank: the task list of jaybenne.cpp:104-138 with
 // the iterate-sublist collapsed to one launch (every block crossing is resolved in flight).
 extern "C" jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm,
-                                       double t_start, double dt, uint64_t *next_id, uint32_t *epoch,
+                                       double t_start, double dt, uint64_t *next_id, uint32_t *cycle,
                                        int32_t *prefix_dev) {
-  if (!ctx || !mesh || !swarm || !next_id || !epoch) return fail(JB_ERR_INVALID, "null argument");
+  if (!ctx || !mesh || !swarm || !next_id || !cycle) return fail(JB_ERR_INVALID, "null argument");
   const DevMesh &M = mesh->dm;
   if (M.nblocks != M.nblocks_total || mesh->nranks_seen != 1)
     return fail(JB_ERR_INVALID, "jb_radiation_step needs the whole mesh on one rank");
+  *cycle += 1;   // (keys the per-cell rounding streams of this cycle's emission source: SourceEpoch)
   jb_status st = jb_update_derived_transport_fields(ctx, mesh, dt);
   if (st != JB_COMPLETE) return st;
   if (ctx->params.do_emission) {
     if (!prefix_dev) return fail(JB_ERR_INVALID, "emission source needs the prefix workspace");
     std::vector<int32_t> nper(M.nblocks);
-    st = jb_source_photons_count(ctx, mesh, JB_SOURCE_EMISSION, dt, M.nblocks, *epoch, nper.data(),
+    st = jb_source_photons_count(ctx, mesh, JB_SOURCE_EMISSION, dt, M.nblocks, *cycle, nper.data(),
                                  prefix_dev);
     if (st != JB_COMPLETE) return st;
-    *epoch += 1;
     std::vector<int64_t> slot(M.nblocks);
     std::vector<uint64_t> ids(M.nblocks);
     int64_t tot = 0;

@@ -99,7 +99,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   // (the LDS tally of a small mesh -- all resident blocks' cells, <= kLdsTally -- and the LDS copy
   // of its step records are dynamic shared memory, sized by the launch: a mesh that uses neither
   // leaves the room to a fourth workgroup per CU)
-  extern __shared__ double lds_dyn[];
+  // (16-byte aligned: the record table carved out of it is read as 32-byte vectors, ds_read_b128)
+  extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
   double *const lds_tally = lds_dyn;
   const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
   const int ncell_all = M.nblocks * (int)M.ntot;

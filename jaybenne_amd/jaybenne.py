@@ -201,7 +201,7 @@ class MeshData:
         self.prefix = torch.zeros(self.nblocks * mesh.ncell, dtype=torch.int32, device=dev)
         self.records: Optional[torch.Tensor] = None
         self.next_id = 0     # first unused stream id (global, kept in step on every rank)
-        self.epoch = 0       # source-call counter (keys the per-cell rounding streams)
+        self.cycle = 0       # RadiationStep counter (keys the per-cell rounding streams: source_epoch); 0 = initialisation
         self.events = 0
         self.kernel_events = None   # set to [] to time every transport launch with HIP events
         self._exchange = None       # halo.FieldExchange, built on first use
@@ -348,6 +348,14 @@ def _global_block_counts(md: MeshData, nper_local: np.ndarray) -> np.ndarray:
     return counts
 
 
+def source_epoch(cycle: int, source_type) -> int:
+    """Key of the per-cell rounding streams of a source call (include/jaybenne_amd.hpp: SourceEpoch,
+    shared by every host): 0 for the initial thermal source, k for the emission source of cycle k."""
+    if int(source_type) == int(SourceType.emission):
+        return int(cycle)
+    return 0 if cycle == 0 else (1 << 19) | int(cycle)
+
+
 def SourcePhotons(md: MeshData, source_type: SourceType, t_start: float, dt: float,
                   per_block: bool = False) -> TaskStatus:
     """``SourcePhotons<T, ST>(md, t_start, dt)`` -- reference sourcing.cpp:25-208.
@@ -362,9 +370,8 @@ def SourcePhotons(md: MeshData, source_type: SourceType, t_start: float, dt: flo
     nper = np.zeros(md.nblocks, dtype=np.int32)
     blocks_in_call = 1 if per_block else md.nowned   # vmesh.GetNBlocks() of this rank's MeshData
     _lib.check(md.lib.jb_source_photons_count(pkg.ctx, md.handle, int(source_type), dt,
-                                              blocks_in_call, md.epoch, nper.ctypes.data,
-                                              md.prefix.data_ptr()))
-    md.epoch += 1
+                                              blocks_in_call, source_epoch(md.cycle, source_type),
+                                              nper.ctypes.data, md.prefix.data_ptr()))
     counts = _global_block_counts(md, nper)
     excl = np.concatenate(([0], np.cumsum(counts)[:-1]))
     id_base = np.ascontiguousarray(md.next_id + excl[md.resident_gids], dtype=np.uint64)
@@ -561,6 +568,7 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
     pkg = md.pkg
     use_ddmc = bool(pkg.Param("use_ddmc"))
     transport = TransportPhotons_DDMC if use_ddmc else TransportPhotons
+    md.cycle += 1
     with _Phase(md, "derived+source"):
         UpdateDerivedTransportFields(md, dt)
         SourcePhotons(md, SourceType.emission, t_start, dt)

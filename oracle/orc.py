@@ -278,7 +278,7 @@ class Oracle:
         self.sw["rng"] = np.zeros(self.cap, dtype=np.uint64)
         self.n = 0
         self.next_id = 0
-        self.epoch = 0
+        self.cycle = 0   # RadiationStep counter: keys the per-cell rounding streams as the hosts do (SourceEpoch)
         self._keep = dict(leaf_map=np.ascontiguousarray(mesh.leaf_map, dtype=np.int32),
                           xmin=np.ascontiguousarray(mesh.blk_xmin), xmax=np.ascontiguousarray(mesh.blk_xmax),
                           dx=np.ascontiguousarray(mesh.blk_dx),
@@ -337,8 +337,8 @@ class Oracle:
         nper = np.zeros(m.nblocks, dtype=np.int32)
         prefix = np.zeros(m.nblocks * m.ncell, dtype=np.int32)
         lib().orc_source_count(C.byref(M), C.byref(self.P), source_type, dt, blocks_in_call,
-                               self.epoch, _i(nper), _i(prefix))
-        self.epoch += 1
+                               (self.cycle if source_type == SRC_EMISSION else (0 if self.cycle == 0 else (1 << 19) | self.cycle)),
+                               _i(nper), _i(prefix))
         tot = int(nper.sum())
         if self.n + tot > self.cap:
             raise MemoryError("oracle swarm capacity exceeded")
@@ -397,6 +397,7 @@ class Oracle:
 
     def RadiationStep(self, t_start: float, dt: float) -> None:
         """Task order of reference jaybenne.cpp:104-138."""
+        self.cycle += 1
         self.UpdateDerivedTransportFields(dt)
         # emission_blocks_in_call: blocks in the calling rank's MeshData (quirk of
         # sourcing.cpp:68-69: the per-cell count scales with 1 / that number); None = whole mesh

@@ -40,10 +40,13 @@ int main() {
       assert(pl.total_local == slot - n_now);
     }
   }
-  // epochs: the same on every rank by construction, distinct per (cycle, type), 0 at initialisation
+  // epochs: the same on every rank by construction, distinct per (cycle, type), 0 at initialisation,
+  // k for the emission source of cycle k (the order a run makes its source calls in)
   assert(SourceEpoch(0, SourceType::thermal) == 0u);
-  assert(SourceEpoch(1, SourceType::emission) == 3u && SourceEpoch(1, SourceType::thermal) == 2u);
+  assert(SourceEpoch(1, SourceType::emission) == 1u && SourceEpoch(2, SourceType::emission) == 2u);
+  assert(SourceEpoch(1, SourceType::thermal) != SourceEpoch(1, SourceType::emission));
   assert(SourceEpoch(7, SourceType::emission) != SourceEpoch(8, SourceType::thermal));
+  assert(SourceEpoch(500000, SourceType::emission) < (1u << 20) && SourceEpoch(500000, SourceType::thermal) < (1u << 20));
   std::puts("plan_source ok");
   return 0;
 }

@@ -770,10 +770,10 @@ def test_c_level_radiation_step(gpu_device):
     a.Step()
     md = b.md
     md._sync_stream()
-    next_id, epoch = C.c_uint64(md.next_id), C.c_uint32(md.epoch)
+    next_id, epoch = C.c_uint64(md.next_id), C.c_uint32(md.cycle)
     _lib.check(md.lib.jb_radiation_step(md.pkg.ctx, md.handle, C.byref(md.sv), 0.0, b.dt,
                                         C.byref(next_id), C.byref(epoch), md.prefix.data_ptr()))
-    assert next_id.value == a.md.next_id and epoch.value == a.md.epoch
+    assert next_id.value == a.md.next_id and epoch.value == a.md.cycle == 1
     ga, gb = a.md.get_swarm(), md.get_swarm()
     oa, ob = np.argsort(ga["id"]), np.argsort(gb["id"])
     assert a.md.n == md.n
