@@ -507,15 +507,6 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
     D.lam_abs = (double *const *)tmp;
     if ((st = upload(m, (const double *const *)ps.data(), (size_t)v->nblocks, &tmp)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
     D.lam_sc = (double *const *)tmp;
-    // ghost cells of the scattering mean free path: which face of the block lies between them and
-    // the interior (k_imc_cell reads "the photon has left its block" off the value it gathers);
-    // UpdateDerivedTransportFields only ever writes interior cells
-    hipLaunchKernelGGL(k_lam_ghost_codes, dim3(grid_for(ctx, (long long)v->nblocks * D.ntot)), dim3(kBlock), 0,
-                       ctx->stream, D, m->nbr_dq);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
-      jb_mesh_destroy(m);
-      return fail(JB_ERR_HIP, "writing the ghost-cell codes of the mean-free-path arrays failed");
-    }
     D.ddmc_cell = nullptr;
     if (ctx->params.use_ddmc) {
       double *pack = nullptr;
@@ -539,6 +530,15 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
       m->owned.push_back(hyb);
       (void)hipMemset(hyb, 0, sizeof(double) * per * (size_t)v->nblocks);
       D.lam_hyb = hyb;
+    }
+    // ghost cells of the scattering mean free path: which face of the block lies between them and
+    // the interior (k_imc_cell reads "the photon has left its block" off the value it gathers);
+    // UpdateDerivedTransportFields only ever writes interior cells
+    hipLaunchKernelGGL(k_lam_ghost_codes, dim3(grid_for(ctx, (long long)v->nblocks * D.ntot)), dim3(kBlock), 0,
+                       ctx->stream, D, m->nbr_dq);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      jb_mesh_destroy(m);
+      return fail(JB_ERR_HIP, "writing the ghost-cell codes of the mean-free-path arrays failed");
     }
   }
   {
@@ -869,16 +869,22 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
 #define JB_PHASE1(T, NA, F, L, LIN)                                                                \
   do {                                                                                             \
     if (!ctx->lean_arith) JB_LAUNCH_H(T, NA, 0, 1, F, L, LIN, list_d, cnt);                        \
+    else if (mesh->exact_geom && !ctx->no_imc_cell) JB_LAUNCH_H(T, NA, 3, 1, F, L, LIN, list_d, cnt);      \
     else if (mesh->exact_geom) JB_LAUNCH_H(T, NA, 2, 1, F, L, LIN, list_d, cnt);                            \
     else JB_LAUNCH_H(T, NA, 1, 1, F, L, LIN, list_d, cnt);                                         \
   } while (0)
-      mesh->last_variant =
-          NDIM == 1 ? (ctx->lean_arith ? (mesh->exact_geom ? "k_hybrid<1, lean, exact geometry>" : "k_hybrid<1, lean>") : "k_hybrid<1, exact>")
-          : NDIM == 2 ? (ctx->lean_arith ? (mesh->exact_geom ? "k_hybrid<2, lean, exact geometry>" : "k_hybrid<2, lean>") : "k_hybrid<2, exact>")
-                      : (ctx->lean_arith ? (mesh->exact_geom ? "k_hybrid<3, lean, exact geometry>" : "k_hybrid<3, lean>") : "k_hybrid<3, exact>");
+      {
+        const bool cell = mesh->exact_geom && !ctx->no_imc_cell;
+        static const char *const hyb_names[3][4] = {
+            {"k_hybrid<1, exact>", "k_hybrid<1, lean>", "k_hybrid<1, lean, exact geometry>", "k_hybrid<1, lean, cell-local>"},
+            {"k_hybrid<2, exact>", "k_hybrid<2, lean>", "k_hybrid<2, lean, exact geometry>", "k_hybrid<2, lean, cell-local>"},
+            {"k_hybrid<3, exact>", "k_hybrid<3, lean>", "k_hybrid<3, lean, exact geometry>", "k_hybrid<3, lean, cell-local>"}};
+        mesh->last_variant = hyb_names[NDIM - 1][!ctx->lean_arith ? 0 : (cell ? 3 : (mesh->exact_geom ? 2 : 1))];
+      }
 #define JB_PHASE0(T, NA, L, LIN)                                                                   \
   do {                                                                                             \
     if (!ctx->lean_arith) JB_LAUNCH_H(T, NA, 0, 0, 0, L, LIN, nullptr, nullptr);                   \
+    else if (mesh->exact_geom && !ctx->no_imc_cell) JB_LAUNCH_H(T, NA, 3, 0, 0, L, LIN, nullptr, nullptr); \
     else if (mesh->exact_geom) JB_LAUNCH_H(T, NA, 2, 0, 0, L, LIN, nullptr, nullptr);                       \
     else JB_LAUNCH_H(T, NA, 1, 0, 0, L, LIN, nullptr, nullptr);                                    \
   } while (0)

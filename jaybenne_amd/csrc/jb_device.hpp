@@ -94,6 +94,23 @@ __device__ __forceinline__ T *g1(T *p) {
   return (T *)(__attribute__((address_space(1))) T *)p;
 }
 
+// Ghost cells of lam_sc hold, instead of a mean free path, what becomes of a photon that steps into
+// them -- a NEGATIVE double whose words are
+//   high: 0xC330'0000 | flags << 16   (sign set, exponent of 2^52: an ordinary negative number)
+//   low : byte offset of the cell the photon is in after the crossing
+// flags bit 3 (kGhostTable): the low word is valid -- the first interior cell of the same-level
+// resident neighbour behind that face or of the block across a periodic boundary, or, with bit
+// 0 / 1 / 2 set, the cell the photon came from at a reflecting wall normal to x / y / z
+// (boundaries.hpp:46-82; position and direction mirrored); bit 3 clear: everything else (edges and
+// corners, level changes, destinations that are not resident, outflow) -- the general relocation.  Built once per
+// mesh from the face table of jb_mesh_create (nbr_ent, nbr_dq); ghost cells of lam_abs: 1 (never
+// looked at).
+// lam_hyb (the hybrid kernel's per-cell datum, 8 ntot bytes per block) carries the same codes with
+// byte offsets of its own layout and, in the low 16 bits of the high word, the destination block
+// (that kernel keeps the block index per lane); a DDMC cell's datum there is negative too, with an
+// ordinary exponent.
+constexpr int kGhostHi = (int)0xC3300000u, kGhostTable = 1 << 19;
+
 enum { ST_ACTIVE = 0, ST_ABSORBED = 1, ST_ESCAPED = 2, ST_OUTGOING = 3, ST_OUTGOING_ABSORBED = 4 };
 enum { BC_PERIODIC = 0, BC_REFLECT = 1, BC_OUTFLOW = 2 };
 
@@ -269,20 +286,7 @@ __device__ __forceinline__ bool on_block(const DevMesh &M, int i, int j, int k) 
   return i >= M.is && i <= M.ie && j >= M.js && j <= M.je && k >= M.ks && k <= M.ke;
 }
 
-// cell index inside one block's [nk][nj][ni] array.  jb_mesh_create checks ni < 2^23 and
-// nj nk < 2^23, so both products are 24-bit multiplications (v_mad_i32_i24, full rate; a
-// general 32-bit multiply-add is a quarter-rate 64-bit one on gfx950).
-// (through inline asm: left to itself the compiler forms k nj + j with v_mad_u64_u32, a
-// quarter-rate instruction, in the tracking loops)
-__device__ __forceinline__ int mad24(int a, int b_uniform, int c) {
-#ifdef JB_NO_MAD24_ASM
-  return __mul24(a, b_uniform) + c;
-#else
-  int d;
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
-  return d;
-#endif
-}
+// cell index inside one block's [nk][nj][ni] array (mad24: jb_math.hpp)
 __device__ __forceinline__ int cidx(const DevMesh &M, int k, int j, int i) {
   return mad24(mad24(k, M.nj, j), M.ni, i);
 }

@@ -29,7 +29,9 @@
 // Same draws, same arithmetic, same bits as the reference's per-step choice (tests/test_gpu_parity.py
 // holds it to the oracle on the 2-D / 3-D SMR hybrid decks, one rank and several); MODE picks the
 // arithmetic of the IMC steps exactly as in the gray IMC kernels: 0 = exact (bit-identical to the
-// oracle), 1 = lean, 2 = lean on exact geometry.  DDMC steps have the exact arithmetic only.
+// oracle), 1 = lean, 2 = lean on exact geometry, 3 = lean on exact geometry in CELL-LOCAL coordinates (the
+// step of k_imc_cell, jb_kernel_imc.hpp: imc_step_cell; block crossings read off the ghost cells of
+// lam_hyb; the default).  DDMC steps have the exact arithmetic only.
 #pragma once
 
 #include "jb_device.hpp"
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
   fill_block_table(M, lds_blocks);
   load_math_tables();  // (ends with a barrier)
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
-  constexpr bool kLean = MODE != 0, kExactG = MODE == 2;
+  constexpr bool kLean = MODE != 0, kExactG = MODE >= 2, kCell = MODE == 3;
   constexpr long long kChunk = JB_HYBRID_CHUNK;
   const double vv = P.c;
   const double t_end = t_start + dt;
@@ -161,11 +163,18 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
   // (bound when the IMC loop is entered: nothing of it is live in the service phase or the DDMC loop)
   DirGeom g;
   double dxp = 0.0, lam_cur = 0.0, lam_a_cur = 0.0;
+  // MODE 3: while in_local, (x, y, z) hold the position relative to the centre of the photon's cell,
+  // qoff the byte offset of that cell in lam_hyb (8 (b ntot + cell)); ip, jp, kp are stale
+  bool in_local = false;
+  unsigned qoff = 0u;
+  CellGeom cg{0, 0, 0, 0, 0, 0, 0};
 
   const unsigned ntot_u = sgpr_copy((unsigned)M.ntot);
   const double *rec_base = sgpr_copy_ptr(M.ddmc_base);
   const double *hyb_base = sgpr_copy_ptr(M.lam_hyb);
   const int l_ni = (int)sgpr_copy((unsigned)M.ni), l_nj = (int)sgpr_copy((unsigned)M.nj);
+  const int l_sy = (int)sgpr_copy(8u * (unsigned)M.ni), l_sz = (int)sgpr_copy(8u * (unsigned)(M.ni * M.nj));
+  const double inv_ni = 1.0 / (double)M.ni, inv_ninj = 1.0 / (double)(M.ni * M.nj);
   const int l_is = (int)sgpr_copy((unsigned)M.is), l_ie = (int)sgpr_copy((unsigned)M.ie);
   const int l_js = (int)sgpr_copy((unsigned)M.js), l_je = (int)sgpr_copy((unsigned)M.je);
   const int l_ks = (int)sgpr_copy((unsigned)M.ks), l_ke = (int)sgpr_copy((unsigned)M.ke);
@@ -196,7 +205,10 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
   // lane keeps the byte offset of its block's part, as the EXACT gray IMC kernels do)
   unsigned hyb_off = 0u;
   auto fetch_lam = [&]() {  // the IMC loop's gather for the lane's cell
-    if constexpr (kExactG) {
+    if constexpr (kCell) {
+      lam_cur = *(gcptr)((const char *)hyb_base + qoff);
+      if constexpr (!NOABS) lam_a_cur = *(gcptr)((const char *)M.lam_base + (qoff + hyb_off));
+    } else if constexpr (kExactG) {
       const unsigned off = ((unsigned)cidx_l(kp, jp, ip) << 3) + hyb_off;
       lam_cur = *(gcptr)((const char *)hyb_base + off);
       if constexpr (!NOABS) lam_a_cur = *(gcptr)((const char *)M.lam_base + (off + hyb_off));
@@ -229,6 +241,31 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
     }
     dxp = dmin(g.dx[0], dmin(g.dx[1], g.dx[2]));
     hyb_off = (unsigned)b * (ntot_u * 8u);
+  };
+  // MODE 3: into the IMC loop's coordinates and back (centre of cell idx: x0 + (idx + 0.5) dx, exact on
+  // this geometry)
+  auto to_local = [&]() {
+    const double d0 = lds_blocks.dx[b][0], d1 = lds_blocks.dx[b][1], d2 = lds_blocks.dx[b][2];
+    cg.hx = 0.5 * d0; cg.hy = 0.5 * d1; cg.hz = 0.5 * d2;
+    cg.mx = cg.hx - kEpsImc * d0; cg.my = cg.hy - kEpsImc * d1; cg.mz = cg.hz - kEpsImc * d2;
+    cg.dxp = dmin(d0, dmin(d1, d2));
+    x -= fma((double)ip + 0.5, d0, lds_x0(M, lds_blocks, b, 0));
+    if (multi_d) y -= fma((double)jp + 0.5, d1, lds_x0(M, lds_blocks, b, 1));
+    if (three_d) z -= fma((double)kp + 0.5, d2, lds_x0(M, lds_blocks, b, 2));
+    hyb_off = (unsigned)b * (ntot_u * 8u);
+    qoff = hyb_off + ((unsigned)cidx_l(kp, jp, ip) << 3);
+    in_local = true;
+  };
+  auto from_local = [&]() {
+    const int q = (int)((qoff - hyb_off) >> 3);
+    kp = three_d ? (int)(((double)q + 0.5) * inv_ninj) : 0;
+    const int r = q - kp * (l_ni * l_nj);
+    jp = multi_d ? (int)(((double)r + 0.5) * inv_ni) : 0;
+    ip = r - jp * l_ni;
+    x += fma((double)ip + 0.5, lds_blocks.dx[b][0], lds_x0(M, lds_blocks, b, 0));
+    if (multi_d) y += fma((double)jp + 0.5, lds_blocks.dx[b][1], lds_x0(M, lds_blocks, b, 1));
+    if (three_d) z += fma((double)kp + 0.5, lds_blocks.dx[b][2], lds_x0(M, lds_blocks, b, 2));
+    in_local = false;
   };
   auto enter_imc = [&]() {
     fresh = false;
@@ -280,6 +317,9 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
 #endif
     // lanes that left the IMC loop of a lean kernel: back to time and velocity (census: the
     // distance left is exactly 0, t = t_end)
+    if constexpr (kCell) {
+      if (in_local && ls != HS_IMC) from_local();
+    }
     if constexpr (kLean) {
       if (in_dir && ls != HS_IMC) {
         t = fma(-t, P.rc, t_end);
@@ -660,13 +700,90 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
     // ================================ IMC EVENTS ==============================
     if constexpr (PHASE != 2) {
       if (ls == HS_IMC) {
-        bind_geometry();
+        if constexpr (kCell) {
+          if (!in_local) to_local();
+        } else {
+          bind_geometry();
+        }
         fetch_lam();
       }
       int waste = 0;
       int nrun = n_imc;
       int thresh = 1;
       while (nrun >= thresh) {
+       if constexpr (kCell) {
+        // ---- the step of k_imc_cell.  A negative datum: the cell entered in the last pass takes DDMC
+        // steps (out of this loop; albedo: service), or it is a ghost cell of the block (k_lam_ghost_codes:
+        // the crossing from its code, or the general relocation of the service phase); the lane sits
+        // this pass out either way
+        const unsigned long long neg_m =
+            __builtin_amdgcn_ballot_w64(ls == HS_IMC) & __builtin_amdgcn_ballot_w64(__double2hiint(lam_cur) < 0);
+        const bool neg = ls == HS_IMC && __double2hiint(lam_cur) < 0;
+        const bool stepping = ls == HS_IMC && !neg;
+        ++c_pass;
+        c_ev += (unsigned int)(nrun - __popcll(neg_m));
+#ifdef JB_HYB_STATS
+        ++st_imc_pass; st_imc_lanes += nrun - __popcll(neg_m);
+#endif
+        if (neg_m != 0ull) {
+          if (neg) {
+            const int code = __double2hiint(lam_cur);
+            if ((code & 0x7ff00000) != (kGhostHi & 0x7ff00000)) {
+              ls = HS_REAL;                      // a DDMC cell of this block
+            } else if ((code & kGhostTable) == 0) {
+              ls = HS_RELOC;                     // level change, another rank's block, outflow, a corner
+            } else {
+              const int fx = (code << 15) & (int)0x80000000u, fy = (code << 14) & (int)0x80000000u,
+                        fz = (code << 13) & (int)0x80000000u;
+              x = __hiloint2double(__double2hiint(x) ^ fx, __double2loint(x));
+              vx = __hiloint2double(__double2hiint(vx) ^ fx, __double2loint(vx));
+              if (multi_d) {
+                y = __hiloint2double(__double2hiint(y) ^ fy, __double2loint(y));
+                vy = __hiloint2double(__double2hiint(vy) ^ fy, __double2loint(vy));
+              }
+              if (three_d) {
+                z = __hiloint2double(__double2hiint(z) ^ fz, __double2loint(z));
+                vz = __hiloint2double(__double2hiint(vz) ^ fz, __double2loint(vz));
+              }
+              qoff = (unsigned)__double2loint(lam_cur);
+              b = code & 0xffff;
+              hyb_off = (unsigned)b * (ntot_u * 8u);
+              if (!(t > 0.0)) ls = HS_DONE;      // (reached census and a block face in one step)
+              else fetch_lam();
+            }
+          }
+        }
+        if (stepping) {
+          bool is_absorbed, is_scattered, hit_any;
+          imc_step_cell<NDIM, NOABS>(cg, l_sy, l_sz, lam_a_cur, lam_cur, rng, t, x, y, z, vx, vy, vz, qoff,
+                                     is_absorbed, is_scattered, hit_any);
+          fetch_lam();  // (for the next pass, ahead of the scatter)
+          const bool census = !(t > 0.0);
+          bool collide = is_absorbed || is_scattered;
+          bool off = false;
+          const bool at_face = hit_any && (collide || census);
+          if (__builtin_amdgcn_ballot_w64(at_face) != 0ull) {
+            // a collision or the census within eps of a cell face: if that face is a block face the
+            // reference relocates the photon first and forgets the collision (transport.cpp:149-155)
+            asm volatile("; collision or census next to a cell face" ::: "memory");
+            if (at_face)
+              off = __double2hiint(lam_cur) < 0 && (__double2hiint(lam_cur) & 0x7ff00000) == (kGhostHi & 0x7ff00000);
+          }
+          collide = collide && !off;
+          if (!NOABS && is_absorbed && collide) {  // transport.cpp:157-163
+            if (lds_blocks.owned[b] != 0) {
+              atomicAdd(&M.edelta[b][(qoff - hyb_off) >> 3], g1(S.w)[n]);
+              status = ST_ABSORBED;
+            } else {
+              status = ST_OUTGOING_ABSORBED;  // deposited by the block's owner
+            }
+            ls = HS_DONE;
+          } else {
+            if (is_scattered && collide) scatter_dir<true>(rng, vx, vy, vz);  // transport.cpp:165-170
+            if (census && !off) ls = HS_DONE;
+          }
+        }
+       } else {
         // the cell entered in the last pass takes DDMC steps: out of this loop (albedo: service)
         if (ls == HS_IMC && __double2hiint(lam_cur) < 0) ls = HS_REAL;
         const int stepping = __popcll(__ballot(ls == HS_IMC));
@@ -736,6 +853,7 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
             if (!done) ls = HS_RELOC;
           }
         }
+       }
         nrun = __popcll(__ballot(ls == HS_IMC));
         waste += n_imc - nrun;
         park_waste += n_virt;

@@ -48,65 +48,6 @@ namespace jb {
 #define JB_IMC_SERVICE_BUDGET 96
 #endif
 
-// Ghost cells of lam_sc hold, instead of a mean free path, what becomes of a photon that steps into
-// them -- a NEGATIVE double whose words are
-//   high: 0xC330'0000 | flags << 16   (sign set, exponent of 2^52: an ordinary negative number)
-//   low : byte offset of the cell the photon is in after the crossing
-// flags bit 3 (kGhostTable): the low word is valid -- the first interior cell of the same-level
-// resident neighbour behind that face or of the block across a periodic boundary, or, with bit
-// 0 / 1 / 2 set, the cell the photon came from at a reflecting wall normal to x / y / z
-// (boundaries.hpp:46-82; position and direction mirrored); bit 3 clear: everything else (edges and
-// corners, level changes, destinations that are not resident, outflow) -- the general relocation.  Built once per
-// mesh from the face table of jb_mesh_create (nbr_ent, nbr_dq); ghost cells of lam_abs: 1 (never
-// looked at).
-constexpr int kGhostHi = (int)0xC3300000u, kGhostTable = 1 << 19;
-__global__ void __launch_bounds__(kBlock) k_lam_ghost_codes(DevMesh M, const int *nbr_dq) {
-  const long long total = (long long)M.nblocks * M.ntot;
-  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
-       c += (long long)gridDim.x * blockDim.x) {
-    const int b = (int)(c / M.ntot);
-    const int q = (int)(c - (long long)b * M.ntot);
-    const int k = q / (M.ni * M.nj), r = q - k * (M.ni * M.nj), j = r / M.ni, i = r - j * M.ni;
-    const int lo[3] = {i < M.is, j < M.js, k < M.ks}, hi[3] = {i > M.ie, j > M.je, k > M.ke};
-    const int nout = lo[0] + hi[0] + lo[1] + hi[1] + lo[2] + hi[2];
-    if (nout == 0) continue;
-    int flags = 0;
-    unsigned dst = 0u;
-    if (nout == 1) {
-      int f = 0;
-      for (int d = 0; d < 3; ++d) {
-        if (lo[d]) f = 2 * d;
-        if (hi[d]) f = 2 * d + 1;
-      }
-      // (only the ghost layer next to the interior is ever entered: a step moves one cell)
-      const int idx[3] = {i, j, k}, first[3] = {M.is, M.js, M.ks}, last[3] = {M.ie, M.je, M.ke};
-      const bool adjacent = (f & 1) ? idx[f >> 1] == last[f >> 1] + 1 : idx[f >> 1] == first[f >> 1] - 1;
-      const int ent = M.nbr_ent[6 * b + f];
-      if (adjacent && ent >= 0) {
-        flags = 8 | ((ent >> 28) == 2 ? 1 << (f >> 1) : 0);
-        dst = 16u * (unsigned)M.ntot * (unsigned)b + 8u * (unsigned)q + (unsigned)nbr_dq[6 * b + f];
-      }
-    }
-    M.lam_sc[b][q] = __hiloint2double(kGhostHi | (flags << 16), (int)dst);
-    M.lam_abs[b][q] = 1.0;
-  }
-}
-
-// p = hit ? -copysign(m, p) : p -- the photon is put eps_imc dx inside the cell beyond the face it
-// reached: one v_bfi_b32 on the high word and two selects, the negation as a source modifier
-__device__ __forceinline__ double nudged(double p, double m, bool hit) {
-#ifdef JB_NO_ASM_NUDGE
-  return hit ? -copysign(m, p) : p;
-#else
-  const unsigned long long mask = __ballot(hit);
-  int chi, hi, lo;
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(chi) : "s"(0x7fffffff), "v"(__double2hiint(m)), "v"(__double2hiint(p)));
-  asm("v_cndmask_b32_e64 %0, %1, -%2, %3" : "=v"(hi) : "v"(__double2hiint(p)), "v"(chi), "s"(mask));
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(p)), "v"(__double2loint(m)), "s"(mask));
-  return __hiloint2double(hi, lo);
-#endif
-}
-
 // the kernel's argument list as the kernel-argument segment holds it
 struct ImcArgs {
   const DevMesh *Mp;
@@ -403,61 +344,17 @@ __global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
         }
       }
       if (stepping) {
-        // ---- transport_utils.hpp:118-134: distances to collision, census, cell faces
-        double dx_abs = 0.0;
-        if constexpr (NOABS) rng.skip();
-        else dx_abs = -lam_a * m_log_lean<true>(rng.drand());
-        const double dx_sc = -lam_s * m_log_lean<true>(rng.drand());
-        double dx_push = m_min(dxp, drem);
-        double rx, ry = 0.0, rz = 0.0;
-        if constexpr (three_d) {
-          // the three reciprocals from ONE hardware reciprocal, of the product (imc_step_dir)
-          const double pxy = ox * oy, q = pxy * oz;
-          if (fabs(q) > 1.0e-250) {
-            const double r = m_rcp_once(q);
-            const double roz = r * oz;
-            rz = r * pxy; rx = roz * oy; ry = roz * ox;
-          } else {
-            rx = m_rcp_once(ox); ry = m_rcp_once(oy); rz = m_rcp_once(oz);
-          }
-        } else {
-          rx = m_rcp_once(ox);
-          if (multi_d) ry = m_rcp_once(oy);
-        }
-        // (a direction component that is exactly zero: NaN, which minNum ignores -- the reference's
-        // third branch)
-        dx_push = m_min(dx_push, m_fnma(px, rx, hx * fabs(rx)));
-        if (multi_d) dx_push = m_min(dx_push, m_fnma(py, ry, hy * fabs(ry)));
-        if (three_d) dx_push = m_min(dx_push, m_fnma(pz, rz, hz * fabs(rz)));
-        const bool is_absorbed = NOABS ? false : (dx_abs < dx_push) && (dx_abs < dx_sc);
-        const bool is_scattered = !is_absorbed && (dx_sc < dx_push);
-        const double dx_move =
-            NOABS ? m_min(dx_push, dx_sc) : (is_absorbed ? dx_abs : (is_scattered ? dx_sc : dx_push));
-        // ---- :136-159 move, nudge; transport.cpp:146 Xtoijk
-        drem -= dx_move;  // (exactly zero when the step ends at census)
-        px = fma(ox, dx_move, px);
-        if (multi_d) py = fma(oy, dx_move, py);
-        if (three_d) pz = fma(oz, dx_move, pz);
-        const bool hit_x = fabs(px) > mx;
-        const bool hit_y = multi_d && fabs(py) > my;
-        const bool hit_z = three_d && fabs(pz) > mz;
-        // (+-1 by the side of the cell the photon left through, times the stride: one multiply-add per
-        // axis onto the offset, the strides as scalar operands)
-        qoff = (unsigned)mad24(hit_x ? (px < 0.0 ? -1 : 1) : 0, sx, (int)qoff);
-        px = nudged(px, mx, hit_x);
-        if (multi_d) {
-          qoff = (unsigned)mad24(hit_y ? (py < 0.0 ? -1 : 1) : 0, sy, (int)qoff);
-          py = nudged(py, my, hit_y);
-        }
-        if (three_d) {
-          qoff = (unsigned)mad24(hit_z ? (pz < 0.0 ? -1 : 1) : 0, sz, (int)qoff);
-          pz = nudged(pz, mz, hit_z);
+        bool is_absorbed, is_scattered, hit_any;
+        {
+          const CellGeom cg{hx, hy, hz, mx, my, mz, dxp};
+          imc_step_cell<NDIM, NOABS>(cg, sy, sz, lam_a, lam_s, rng, drem, px, py, pz, ox, oy, oz, qoff,
+                                     is_absorbed, is_scattered, hit_any);
         }
         fetch_lam();  // (for the next pass, ahead of the scatter)
         const bool census = !(drem > 0.0);
         bool collide = is_absorbed || is_scattered;
         bool off = false;
-        const bool at_face = (hit_x || hit_y || hit_z) && (collide || census);
+        const bool at_face = hit_any && (collide || census);
         if (__builtin_amdgcn_ballot_w64(at_face) != 0ull) {
           // a collision or the census within eps of a cell face (one event in ~1e8): if that face is
           // a block face the reference relocates the photon first (and forgets the collision,

@@ -92,6 +92,46 @@ __global__ void __launch_bounds__(kBlock) k_fleck(DevMesh M, DevParams P, double
   }
 }
 
+// ghost-cell codes of the mean-free-path arrays (jb_device.hpp: kGhostHi), once per mesh
+__global__ void __launch_bounds__(kBlock) k_lam_ghost_codes(DevMesh M, const int *nbr_dq) {
+  const long long total = (long long)M.nblocks * M.ntot;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+       c += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(c / M.ntot);
+    const int q = (int)(c - (long long)b * M.ntot);
+    const int k = q / (M.ni * M.nj), r = q - k * (M.ni * M.nj), j = r / M.ni, i = r - j * M.ni;
+    const int lo[3] = {i < M.is, j < M.js, k < M.ks}, hi[3] = {i > M.ie, j > M.je, k > M.ke};
+    const int nout = lo[0] + hi[0] + lo[1] + hi[1] + lo[2] + hi[2];
+    if (nout == 0) continue;
+    int flags = 0, dest = 0;
+    unsigned dst = 0u, dst_h = 0u;
+    if (nout == 1) {
+      int f = 0;
+      for (int d = 0; d < 3; ++d) {
+        if (lo[d]) f = 2 * d;
+        if (hi[d]) f = 2 * d + 1;
+      }
+      // (only the ghost layer next to the interior is ever entered: a step moves one cell)
+      const int idx[3] = {i, j, k}, first[3] = {M.is, M.js, M.ks}, last[3] = {M.ie, M.je, M.ke};
+      const bool adjacent = (f & 1) ? idx[f >> 1] == last[f >> 1] + 1 : idx[f >> 1] == first[f >> 1] - 1;
+      const int ent = M.nbr_ent[6 * b + f];
+      if (adjacent && ent >= 0) {
+        flags = 8 | ((ent >> 28) == 2 ? 1 << (f >> 1) : 0);
+        dest = ent & 0x0fffffff;
+        const unsigned dq = (unsigned)nbr_dq[6 * b + f];   // (in lam_sc's layout: 16 ntot bytes per block)
+        dst = 16u * (unsigned)M.ntot * (unsigned)b + 8u * (unsigned)q + dq;
+        dst_h = 8u * (unsigned)M.ntot * (unsigned)b + 8u * (unsigned)q + dq - 8u * (unsigned)M.ntot * (unsigned)(dest - b);
+      }
+    }
+    M.lam_sc[b][q] = __hiloint2double(kGhostHi | (flags << 16), (int)dst);
+    M.lam_abs[b][q] = 1.0;
+    if (M.lam_hyb != nullptr && dest < (1 << 16))
+      M.lam_hyb[(long long)b * M.ntot + q] = __hiloint2double(kGhostHi | (flags << 16) | dest, (int)dst_h);
+    else if (M.lam_hyb != nullptr)
+      M.lam_hyb[(long long)b * M.ntot + q] = __hiloint2double(kGhostHi, 0);
+  }
+}
+
 template <int D>
 __global__ void __launch_bounds__(kBlock) k_face_prob(DevMesh M, DevParams P) {
   // faces normal to D: interior cells plus one extra layer in D

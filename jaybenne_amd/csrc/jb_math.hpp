@@ -78,6 +78,20 @@ __device__ __forceinline__ double m_min(double a, double b) {
   return d;
 }
 
+// cell index inside one block's [nk][nj][ni] array.  jb_mesh_create checks ni < 2^23 and
+// nj nk < 2^23, so both products are 24-bit multiplications (v_mad_i32_i24, full rate; a
+// general 32-bit multiply-add is a quarter-rate 64-bit one on gfx950).
+// (through inline asm: left to itself the compiler forms k nj + j with v_mad_u64_u32, a
+// quarter-rate instruction, in the tracking loops)
+__device__ __forceinline__ int mad24(int a, int b_uniform, int c) {
+#ifdef JB_NO_MAD24_ASM
+  return __mul24(a, b_uniform) + c;
+#else
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+  return d;
+#endif
+}
 __shared__ double lds_log_tab[JB_LOG_N][4];  // {1/c, log c hi, log c lo, -}: 32-byte rows, one address serves both reads
 __shared__ double lds_log2_tab[JB_LOG_N][2];  // {1/c, log c as one double}: the lean logarithm's row
 __shared__ double lds_sc_tab[JB_SC_N + 1][2];

@@ -402,6 +402,93 @@ __device__ __forceinline__ void imc_step_dir(DirGeom &g, double dx_push0, double
   }
 }
 
+// p = hit ? -copysign(m, p) : p -- the photon is put eps_imc dx inside the cell beyond the face it
+// reached: one v_bfi_b32 on the high word and two selects, the negation as a source modifier
+__device__ __forceinline__ double nudged(double p, double m, bool hit) {
+#ifdef JB_NO_ASM_NUDGE
+  return hit ? -copysign(m, p) : p;
+#else
+  const unsigned long long mask = __ballot(hit);
+  int chi, hi, lo;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(chi) : "s"(0x7fffffff), "v"(__double2hiint(m)), "v"(__double2hiint(p)));
+  asm("v_cndmask_b32_e64 %0, %1, -%2, %3" : "=v"(hi) : "v"(__double2hiint(p)), "v"(chi), "s"(mask));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(p)), "v"(__double2loint(m)), "s"(mask));
+  return __hiloint2double(hi, lo);
+#endif
+}
+
+// The lean tracking step of transport_utils.hpp:118-159 + Xtoijk (transport.cpp:146) in CELL-LOCAL
+// coordinates (jb_kernel_imc.hpp states the representation: p = x - cell centre per axis, unit
+// direction omega, distance left to census, byte offset of the cell with byte strides 8 / sy / sz per
+// axis; geometry: half cell widths h, h - eps_imc dx, smallest cell width).  2 draws.
+//   distance to the face ahead   (h - sgn(omega) p) / |omega| = fma(-p, 1/omega, h |1/omega|)
+//   move                         p = fma(omega, d, p)
+//   nudge + Xtoijk               |p| > h - eps_imc dx  ->  p = -+(h - eps_imc dx), offset +- stride
+// hit_any: the photon was put through a cell face (the caller then knows that a collision or the
+// census of this step may have happened next to a BLOCK face).
+struct CellGeom {
+  double hx, hy, hz, mx, my, mz, dxp;
+};
+template <int NDIM, bool NOABS, class Rng>
+__device__ __forceinline__ void imc_step_cell(const CellGeom &g, int sy, int sz, double lam_a, double lam_s,
+                                              Rng &rng, double &drem, double &px, double &py, double &pz,
+                                              double ox, double oy, double oz, unsigned &qoff,
+                                              bool &is_absorbed, bool &is_scattered, bool &hit_any) {
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  constexpr int sx = 8;
+  // ---- transport_utils.hpp:118-134: distances to collision, census, cell faces
+  double dx_abs = 0.0;
+  if constexpr (NOABS) rng.skip();
+  else dx_abs = -lam_a * m_log_lean<true>(rng.drand());
+  const double dx_sc = -lam_s * m_log_lean<true>(rng.drand());
+  double dx_push = m_min(g.dxp, drem);
+  double rx, ry = 0.0, rz = 0.0;
+  if constexpr (three_d) {
+    // the three reciprocals from ONE hardware reciprocal, of the product (imc_step_dir)
+    const double pxy = ox * oy, q = pxy * oz;
+    if (fabs(q) > 1.0e-250) {
+      const double r = m_rcp_once(q);
+      const double roz = r * oz;
+      rz = r * pxy; rx = roz * oy; ry = roz * ox;
+    } else {
+      rx = m_rcp_once(ox); ry = m_rcp_once(oy); rz = m_rcp_once(oz);
+    }
+  } else {
+    rx = m_rcp_once(ox);
+    if (multi_d) ry = m_rcp_once(oy);
+  }
+  // (a direction component that is exactly zero: NaN, which minNum ignores -- the reference's
+  // third branch)
+  dx_push = m_min(dx_push, m_fnma(px, rx, g.hx * fabs(rx)));
+  if (multi_d) dx_push = m_min(dx_push, m_fnma(py, ry, g.hy * fabs(ry)));
+  if (three_d) dx_push = m_min(dx_push, m_fnma(pz, rz, g.hz * fabs(rz)));
+  is_absorbed = NOABS ? false : (dx_abs < dx_push) && (dx_abs < dx_sc);
+  is_scattered = !is_absorbed && (dx_sc < dx_push);
+  const double dx_move =
+      NOABS ? m_min(dx_push, dx_sc) : (is_absorbed ? dx_abs : (is_scattered ? dx_sc : dx_push));
+  // ---- :136-159 move, nudge; transport.cpp:146 Xtoijk
+  drem -= dx_move;  // (exactly zero when the step ends at census)
+  px = fma(ox, dx_move, px);
+  if (multi_d) py = fma(oy, dx_move, py);
+  if (three_d) pz = fma(oz, dx_move, pz);
+  const bool hit_x = fabs(px) > g.mx;
+  const bool hit_y = multi_d && fabs(py) > g.my;
+  const bool hit_z = three_d && fabs(pz) > g.mz;
+  // (+-1 by the side of the cell the photon left through, times the stride: one multiply-add per
+  // axis onto the offset, the strides as scalar operands)
+  qoff = (unsigned)mad24(hit_x ? (px < 0.0 ? -1 : 1) : 0, sx, (int)qoff);
+  px = nudged(px, g.mx, hit_x);
+  if (multi_d) {
+    qoff = (unsigned)mad24(hit_y ? (py < 0.0 ? -1 : 1) : 0, sy, (int)qoff);
+    py = nudged(py, g.my, hit_y);
+  }
+  if (three_d) {
+    qoff = (unsigned)mad24(hit_z ? (pz < 0.0 ? -1 : 1) : 0, sz, (int)qoff);
+    pz = nudged(pz, g.mz, hit_z);
+  }
+  hit_any = hit_x || hit_y || hit_z;
+}
+
 // scattering.hpp:21-29 in direction space: the new unit direction (2 draws)
 template <bool SC = false, class Rng>
 __device__ __forceinline__ void scatter_dir(Rng &rng, double &ox, double &oy, double &oz) {
