@@ -102,14 +102,25 @@ __device__ __forceinline__ T *g1(T *p) {
 // resident neighbour behind that face or of the block across a periodic boundary, or, with bit
 // 0 / 1 / 2 set, the cell the photon came from at a reflecting wall normal to x / y / z
 // (boundaries.hpp:46-82; position and direction mirrored); bit 3 clear: everything else (edges and
-// corners, level changes, destinations that are not resident, outflow) -- the general relocation.  Built once per
-// mesh from the face table of jb_mesh_create (nbr_ent, nbr_dq); ghost cells of lam_abs: 1 (never
-// looked at).
+// corners, destinations that are not resident, outflow) -- the general relocation.
+// A face to a resident block one level COARSER or FINER (bits 8 / 9 of the high word, with bit 3):
+//   coarser: the low word is the coarse cell that contains the ghost cell; the cell-local position
+//     moves by -+ h_fine per axis (bits 10 / 11 / 12 set: minus), the lane's geometry doubles;
+//   finer: the low word is the lowest of the 2 (2-D) or 4 (3-D) fine cells behind the coarse ghost
+//     cell, in the layer next to the face; bits 10-11 name the face's axis, bit 12 its side (set: the
+//     photon left through the lower face).  At run time every transverse axis adds its stride when
+//     the local coordinate is >= 0 (Xtoijk's floor) and the coordinate moves by -+ h_fine; the normal
+//     one moves by +- h_fine; the lane's geometry halves.
+//   (in cell-local coordinates a level change is these few additions: no boundary conditions, no
+//   leaf-map lookup, no Xtoijk -- SampleDDMCBlockFace does not act on a photon with a velocity).
+// Built once per mesh (k_lam_ghost_codes) from the face table of jb_mesh_create (nbr_ent, nbr_dq)
+// and the block geometry; ghost cells of lam_abs: 1 (never looked at).
 // lam_hyb (the hybrid kernel's per-cell datum, 8 ntot bytes per block) carries the same codes with
-// byte offsets of its own layout and, in the low 16 bits of the high word, the destination block
-// (that kernel keeps the block index per lane); a DDMC cell's datum there is negative too, with an
-// ordinary exponent.
+// byte offsets of its own layout and, in the low 8 bits of the high word, the destination block
+// (that kernel keeps the block index per lane, at most kLdsBlocks = 128 resident blocks); a DDMC
+// cell's datum there is negative too, with an ordinary exponent.
 constexpr int kGhostHi = (int)0xC3300000u, kGhostTable = 1 << 19;
+constexpr int kGhostCoarser = 1 << 8, kGhostFiner = 1 << 9;
 
 enum { ST_ACTIVE = 0, ST_ABSORBED = 1, ST_ESCAPED = 2, ST_OUTGOING = 3, ST_OUTGOING_ABSORBED = 4 };
 enum { BC_PERIODIC = 0, BC_REFLECT = 1, BC_OUTFLOW = 2 };

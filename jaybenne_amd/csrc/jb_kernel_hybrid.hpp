@@ -746,7 +746,9 @@ __global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 
                 vz = __hiloint2double(__double2hiint(vz) ^ fz, __double2loint(vz));
               }
               qoff = (unsigned)__double2loint(lam_cur);
-              b = code & 0xffff;
+              if (code & (kGhostCoarser | kGhostFiner))  // a resident block one level up or down
+                qoff = cross_level<NDIM>(code, qoff, l_sy, l_sz, cg, x, y, z);
+              b = code & 0xff;
               hyb_off = (unsigned)b * (ntot_u * 8u);
               if (!(t > 0.0)) ls = HS_DONE;      // (reached census and a block face in one step)
               else fetch_lam();

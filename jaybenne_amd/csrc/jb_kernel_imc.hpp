@@ -121,9 +121,8 @@ __global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
   double px = 0, py = 0, pz = 0;            // position relative to the cell centre
   double ox = 0, oy = 0, oz = 0;            // unit direction (IS_DONE_RAW: the velocity as loaded)
   double drem = 0;                          // distance left to census (IS_DONE_RAW: the time as loaded)
-  double hx = 0, hy = 0, hz = 0;            // half cell widths of the block
-  double mx = 0, my = 0, mz = 0;            // h - eps_imc dx
-  double dxp = 0;                           // min cell width of the block (transport.cpp:75-78)
+  // half cell widths of the block, h - eps_imc dx, min cell width of the block (transport.cpp:75-78)
+  CellGeom cg{0, 0, 0, 0, 0, 0, 0};
   double lam_a = 0.0, lam_s = 0.0;          // mean free paths of the photon's cell, or the ghost code
 
   auto fetch_lam = [&]() {
@@ -133,9 +132,9 @@ __global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
   auto bind_block = [&](int blk) {
     const double d0 = ((gcptr)M.blk_dx)[3 * blk], d1 = ((gcptr)M.blk_dx)[3 * blk + 1],
                  d2 = ((gcptr)M.blk_dx)[3 * blk + 2];
-    hx = 0.5 * d0; hy = 0.5 * d1; hz = 0.5 * d2;
-    mx = hx - kEpsImc * d0; my = hy - kEpsImc * d1; mz = hz - kEpsImc * d2;
-    dxp = dmin(d0, dmin(d1, d2));
+    cg.hx = 0.5 * d0; cg.hy = 0.5 * d1; cg.hz = 0.5 * d2;
+    cg.mx = cg.hx - kEpsImc * d0; cg.my = cg.hy - kEpsImc * d1; cg.mz = cg.hz - kEpsImc * d2;
+    cg.dxp = dmin(d0, dmin(d1, d2));
   };
   // the resident block the byte offset lies in (formed where a consumer appears: the loop does not
   // carry it) -- offsets are multiples of 8, so (qoff + 4) / blk_bytes is >= 4 / blk_bytes away from
@@ -238,7 +237,7 @@ __global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
       if (status == ST_ACTIVE) {
         ++c_census;
         if constexpr (TALLY) {  // jaybenne.cpp:547-561
-          const double dv = (8.0 * hx) * hy * hz;  // dx dy dz: powers of two, exact in any order
+          const double dv = (8.0 * cg.hx) * cg.hy * cg.hz;  // dx dy dz: powers of two, exact in any order
           const int q = (int)((qoff - (unsigned)b * blk_bytes) >> 3);
           if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + q], g1(S.w)[n] / dv);
           else atomicAdd(&M.tally[b][q], g1(S.w)[n] / dv);
@@ -338,6 +337,8 @@ __global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
               oz = __hiloint2double(__double2hiint(oz) ^ fz, __double2loint(oz));
             }
             qoff = (unsigned)__double2loint(lam_s);
+            if (code & (kGhostCoarser | kGhostFiner))  // a resident block one level up or down
+              qoff = cross_level<NDIM>(code, qoff, sy, sz, cg, px, py, pz);
             fetch_lam();
             if (!(drem > 0.0)) ls = IS_DONE;  // (reached census and a block face in one step)
           }
@@ -345,11 +346,8 @@ __global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
       }
       if (stepping) {
         bool is_absorbed, is_scattered, hit_any;
-        {
-          const CellGeom cg{hx, hy, hz, mx, my, mz, dxp};
-          imc_step_cell<NDIM, NOABS>(cg, sy, sz, lam_a, lam_s, rng, drem, px, py, pz, ox, oy, oz, qoff,
-                                     is_absorbed, is_scattered, hit_any);
-        }
+        imc_step_cell<NDIM, NOABS>(cg, sy, sz, lam_a, lam_s, rng, drem, px, py, pz, ox, oy, oz, qoff,
+                                   is_absorbed, is_scattered, hit_any);
         fetch_lam();  // (for the next pass, ahead of the scatter)
         const bool census = !(drem > 0.0);
         bool collide = is_absorbed || is_scattered;

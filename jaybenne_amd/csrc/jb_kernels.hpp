@@ -95,40 +95,88 @@ __global__ void __launch_bounds__(kBlock) k_fleck(DevMesh M, DevParams P, double
 // ghost-cell codes of the mean-free-path arrays (jb_device.hpp: kGhostHi), once per mesh
 __global__ void __launch_bounds__(kBlock) k_lam_ghost_codes(DevMesh M, const int *nbr_dq) {
   const long long total = (long long)M.nblocks * M.ntot;
+  const int first[3] = {M.is, M.js, M.ks}, last[3] = {M.ie, M.je, M.ke};
+  const unsigned stride8[3] = {8u, 8u * (unsigned)M.ni, 8u * (unsigned)(M.ni * M.nj)};
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
        c += (long long)gridDim.x * blockDim.x) {
     const int b = (int)(c / M.ntot);
     const int q = (int)(c - (long long)b * M.ntot);
     const int k = q / (M.ni * M.nj), r = q - k * (M.ni * M.nj), j = r / M.ni, i = r - j * M.ni;
+    const int idx[3] = {i, j, k};
     const int lo[3] = {i < M.is, j < M.js, k < M.ks}, hi[3] = {i > M.ie, j > M.je, k > M.ke};
     const int nout = lo[0] + hi[0] + lo[1] + hi[1] + lo[2] + hi[2];
     if (nout == 0) continue;
-    int flags = 0, dest = 0;
-    unsigned dst = 0u, dst_h = 0u;
+    int bits = 0, dest = 0;            // bits: what goes into the high word next to kGhostHi
+    unsigned dcell = 0u;               // cell (flat index) in block dest
     if (nout == 1) {
       int f = 0;
       for (int d = 0; d < 3; ++d) {
         if (lo[d]) f = 2 * d;
         if (hi[d]) f = 2 * d + 1;
       }
+      const int n = f >> 1;
       // (only the ghost layer next to the interior is ever entered: a step moves one cell)
-      const int idx[3] = {i, j, k}, first[3] = {M.is, M.js, M.ks}, last[3] = {M.ie, M.je, M.ke};
-      const bool adjacent = (f & 1) ? idx[f >> 1] == last[f >> 1] + 1 : idx[f >> 1] == first[f >> 1] - 1;
+      const bool adjacent = (f & 1) ? idx[n] == last[n] + 1 : idx[n] == first[n] - 1;
       const int ent = M.nbr_ent[6 * b + f];
-      if (adjacent && ent >= 0) {
-        flags = 8 | ((ent >> 28) == 2 ? 1 << (f >> 1) : 0);
+      if (adjacent && ent >= 0) {      // same-level neighbour, periodic image or reflecting wall
+        bits = kGhostTable | ((ent >> 28) == 2 ? 0x10000 << n : 0);
         dest = ent & 0x0fffffff;
-        const unsigned dq = (unsigned)nbr_dq[6 * b + f];   // (in lam_sc's layout: 16 ntot bytes per block)
-        dst = 16u * (unsigned)M.ntot * (unsigned)b + 8u * (unsigned)q + dq;
-        dst_h = 8u * (unsigned)M.ntot * (unsigned)b + 8u * (unsigned)q + dq - 8u * (unsigned)M.ntot * (unsigned)(dest - b);
+        // (nbr_dq: in lam_sc's layout, 16 ntot bytes per block)
+        dcell = (unsigned)q + (unsigned)((nbr_dq[6 * b + f] - 16 * (int)M.ntot * (dest - b)) / 8);
+      } else if (adjacent && M.exact) {
+        // a neighbour of another level?  centre of the ghost cell, through a periodic boundary if need be
+        double xg[3];
+        bool inside = true;
+        for (int d = 0; d < 3; ++d) {
+          const double dx = M.blk_dx[3 * b + d];
+          xg[d] = M.blk_xmin[3 * b + d] + ((double)(idx[d] - first[d]) + 0.5) * dx;
+          if (d >= M.ndim) continue;
+          if (xg[d] < M.gmin[d]) { if (M.bc[2 * d] == BC_PERIODIC) xg[d] += M.gmax[d] - M.gmin[d]; else inside = false; }
+          if (xg[d] > M.gmax[d]) { if (M.bc[2 * d + 1] == BC_PERIODIC) xg[d] -= M.gmax[d] - M.gmin[d]; else inside = false; }
+        }
+        int li = -1;
+        if (inside) {
+          long long l[3] = {0, 0, 0};
+          for (int d = 0; d < M.ndim; ++d) {
+            long long v = (long long)floor((xg[d] - M.gmin[d]) * M.inv_leaf_len[d]);
+            l[d] = v < 0 ? 0 : (v > M.nleaf[d] - 1 ? M.nleaf[d] - 1 : v);
+          }
+          li = M.local_index[M.leaf_map[(l[2] * M.nleaf[1] + l[1]) * M.nleaf[0] + l[0]]];
+        }
+        if (li >= 0 && M.blk_level[li] == M.blk_level[b] - 1) {
+          // COARSER: the coarse cell that contains the ghost cell; per axis: is the fine centre below the coarse one?
+          bits = kGhostTable | kGhostCoarser;
+          int cc[3] = {M.is, M.js, M.ks};
+          for (int d = 0; d < M.ndim; ++d) {
+            const double dxc = M.blk_dx[3 * li + d];
+            cc[d] = (int)floor((xg[d] - M.blk_xmin[3 * li + d]) / dxc) + first[d];
+            const double centre = M.blk_xmin[3 * li + d] + ((double)(cc[d] - first[d]) + 0.5) * dxc;
+            if (xg[d] < centre) bits |= 0x400 << d;
+          }
+          dest = li;
+          dcell = (unsigned)((cc[2] * M.nj + cc[1]) * M.ni + cc[0]);
+        } else if (li >= 0 && M.blk_level[li] == M.blk_level[b] + 1) {
+          // FINER: the lowest of the fine cells behind the ghost cell, in the layer next to the face
+          bits = kGhostTable | kGhostFiner | (n << 10) | ((f & 1) ? 0 : 0x1000);
+          int cc[3] = {M.is, M.js, M.ks};
+          for (int d = 0; d < M.ndim; ++d) {
+            const double dxf = M.blk_dx[3 * li + d];
+            if (d == n) cc[d] = (f & 1) ? first[d] : last[d];
+            else cc[d] = (int)floor((xg[d] - 0.5 * dxf - M.blk_xmin[3 * li + d]) / dxf) + first[d];
+          }
+          dest = li;
+          dcell = (unsigned)((cc[2] * M.nj + cc[1]) * M.ni + cc[0]);
+        }
       }
     }
-    M.lam_sc[b][q] = __hiloint2double(kGhostHi | (flags << 16), (int)dst);
+    const unsigned ntot = (unsigned)M.ntot;
+    M.lam_sc[b][q] = __hiloint2double(kGhostHi | bits, (int)(16u * ntot * (unsigned)dest + 8u * dcell));
     M.lam_abs[b][q] = 1.0;
-    if (M.lam_hyb != nullptr && dest < (1 << 16))
-      M.lam_hyb[(long long)b * M.ntot + q] = __hiloint2double(kGhostHi | (flags << 16) | dest, (int)dst_h);
-    else if (M.lam_hyb != nullptr)
-      M.lam_hyb[(long long)b * M.ntot + q] = __hiloint2double(kGhostHi, 0);
+    if (M.lam_hyb != nullptr)  // (the destination block in the low 8 bits: <= kLdsBlocks resident blocks there)
+      M.lam_hyb[(long long)b * M.ntot + q] =
+          dest < 256 ? __hiloint2double(kGhostHi | bits | dest, (int)(8u * ntot * (unsigned)dest + 8u * dcell))
+                     : __hiloint2double(kGhostHi, 0);
+    (void)stride8;
   }
 }
 

@@ -489,6 +489,48 @@ __device__ __forceinline__ void imc_step_cell(const CellGeom &g, int sy, int sz,
   hit_any = hit_x || hit_y || hit_z;
 }
 
+// A crossing into a resident block one level coarser or finer, in cell-local coordinates
+// (jb_device.hpp: kGhostCoarser / kGhostFiner; `code` = high word of the ghost cell's datum, `dst` =
+// its low word).  Returns the byte offset of the photon's cell; position and geometry are updated.
+template <int NDIM>
+__device__ __forceinline__ unsigned cross_level(int code, unsigned dst, int sy, int sz, CellGeom &g, double &px,
+                                                double &py, double &pz) {
+  constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
+  if (code & 0x100) {  // to the coarser block: its cell widths are twice this block's
+    px += (code & 0x400) ? -g.hx : g.hx;
+    if (multi_d) py += (code & 0x800) ? -g.hy : g.hy;
+    if (three_d) pz += (code & 0x1000) ? -g.hz : g.hz;
+    g.hx *= 2.0; g.mx *= 2.0;   // (active axes only: an inactive one keeps the extent of the domain)
+    if (multi_d) { g.hy *= 2.0; g.my *= 2.0; }
+    if (three_d) { g.hz *= 2.0; g.mz *= 2.0; }
+    g.dxp = dmin(2.0 * g.hx, dmin(2.0 * g.hy, 2.0 * g.hz));
+    return dst;
+  }
+  // to a finer block: half the cell widths; which of the fine cells behind the coarse ghost cell
+  g.hx *= 0.5; g.mx *= 0.5;
+  if (multi_d) { g.hy *= 0.5; g.my *= 0.5; }
+  if (three_d) { g.hz *= 0.5; g.mz *= 0.5; }
+  g.dxp = dmin(2.0 * g.hx, dmin(2.0 * g.hy, 2.0 * g.hz));
+  const int naxis = (code >> 10) & 3;
+  const bool lower = (code & 0x1000) != 0;  // left through the lower face: the last fine layer
+  {
+    const bool up = !(px < 0.0);
+    if (naxis == 0) px += lower ? -g.hx : g.hx;
+    else { px += up ? -g.hx : g.hx; dst += up ? 8u : 0u; }
+  }
+  if (multi_d) {
+    const bool up = !(py < 0.0);
+    if (naxis == 1) py += lower ? -g.hy : g.hy;
+    else { py += up ? -g.hy : g.hy; dst += up ? (unsigned)sy : 0u; }
+  }
+  if (three_d) {
+    const bool up = !(pz < 0.0);
+    if (naxis == 2) pz += lower ? -g.hz : g.hz;
+    else { pz += up ? -g.hz : g.hz; dst += up ? (unsigned)sz : 0u; }
+  }
+  return dst;
+}
+
 // scattering.hpp:21-29 in direction space: the new unit direction (2 draws)
 template <bool SC = false, class Rng>
 __device__ __forceinline__ void scatter_dir(Rng &rng, double &ox, double &oy, double &oz) {
