@@ -5,7 +5,7 @@ worker that dies, a backend that refuses to come up or a collective that never r
 in a labelled fallback or a diagnostic and a non-zero exit, never in a hang.  The worker's process
 group life cycle is exercised here on CPU (JB_BENCH_FAKE_WORKER=1: rendezvous over gloo, one
 barrier per step, failures injected through the environment); the real worker runs on the GPU box
-(tools/dev/r04_rehearse.sh, profiles/r04_rehearsal_*).
+(tools/dev/rehearse.sh, profiles/r04_rehearsal_*).
 """
 import json
 import os

@@ -1,5 +1,5 @@
 # usage: pmc2.sh <workload> <particles> <item> ...   (items as in ab2.sh)
-# three --pmc passes per item over `bench.py --steps 1 --warmup 0`; summaries by tools/pmc_summary2.py
+# three --pmc passes per item over `bench.py --steps 1 --warmup 0`; summaries by tools/pmc_summary.py
 set -e
 mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 w=$1; n=$2; shift 2
@@ -22,5 +22,5 @@ for item in "$@"; do
     echo "pmc pass $p of $item done"
   done
   for e in $envs; do unset ${e%%=*}; done
-  python3 tools/pmc_summary2.py $w $name
+  python3 tools/pmc_summary.py $w $name
 done

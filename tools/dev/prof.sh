@@ -1,8 +1,11 @@
-# The command list behind profiles/r03_*: kernel stats of the default bench under rocprofv3, one
-# --pmc pass per counter group for the headline (c2) and the DDMC (c3) workloads, and the bench
-# lines of every workload.  tools/collect_profiles3.py turns gpurun_out/r03prof/ into profiles/.
+# usage: prof.sh <tag>   (e.g. r04)
+# The command list behind profiles/<tag>_*: kernel stats of the default bench under rocprofv3, one
+# --pmc pass per counter group for the headline (c2), DDMC (c3), SMR (c4) and hybrid (c5) workloads,
+# and the bench lines of every workload.  `python tools/collect_profiles.py <tag>` turns
+# gpurun_out/<tag>prof/ into profiles/<tag>_*.
 set -e
-O=gpurun_out/r03prof
+TAG=${1:-r04}
+O=gpurun_out/${TAG}prof
 mkdir -p $O && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 C2="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
 C3="python3 bench.py --workload c3 --particles-per-gpu 100000000 --steps 1 --warmup 0 --no-cpu-baseline"
