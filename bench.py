@@ -522,7 +522,7 @@ def main() -> None:
         # counters of this very command under rocprofv3 (separate --pmc passes), if a committed
         # summary matches workload and size: labelled as read from that file, not measured now
         pmc, pmc_file = None, None
-        for rnd in ("r03", "r03_exact", "r02", "r02_exact", "r01_g"):
+        for rnd in ("r04", "r04_exact", "r03", "r03_exact", "r02", "r02_exact", "r01_g"):
             f = os.path.join(ROOT, "profiles", f"{rnd.split('_exact')[0]}_pmc_summary_{args.workload}"
                                                f"{'_exact' if rnd.endswith('_exact') else ''}.json")
             try:
@@ -531,7 +531,7 @@ def main() -> None:
                 # arguments = a kernel from before the lean variant existed, i.e. exact arithmetic)
                 kargs = tr.get("kernel", "").split("<")[-1].rstrip("> ").split(",")
                 tr_lean = len(kargs) == 6 and kargs[-1].strip() == "true"
-                tr_lean = tr_lean or kargs[-1].strip() == "lean"
+                tr_lean = tr_lean or "k_imc_cell" in tr.get("kernel", "") or "cell-local" in tr.get("kernel", "")
                 same_arith = tr_lean == variant.endswith(("true>", "lean>")) or "k_ddmc_all" in tr.get("kernel", "")
                 if (tr["workload"] == args.workload and tr["particles_per_gpu"] == args.particles_per_gpu
                         and args.block_nx == 64 and args.gpus == 1 and same_arith):
@@ -587,6 +587,16 @@ def main() -> None:
                     "l2_served_GBps": l2_gbs,
                     "l2_served_definition": "168 B per history + 24 B of cell gathers per event / "
                                             "kernel time: almost all served by L2, NOT an HBM rate"}
+        if pmc and "valu_issue_frac" in pmc:
+            # the bounds the counters themselves support (the 200-flop figure above is the
+            # survey's convention): read from the committed summary of this command, not measured now
+            roof["valu_issue_frac"] = pmc["valu_issue_frac"]
+            roof["fp64_counter_frac"] = pmc["fp64_counter_frac"]
+            roof["valu_issue_definition"] = ("share of the SIMDs' cycles spent issuing VALU instructions "
+                                             "(SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES): how close the "
+                                             "kernel is to the issue limit for the instruction stream it executes; "
+                                             "fp64_counter_frac = FP64 flop the counters saw (fma 2, add / mul 1, x lanes "
+                                             "in use) / launch time / 78.6 TF/s; both from " + pmc_file)
         roof.update({"kernel": variant, "kernel_ms_avg": 1e3 * k_time / max(len(kt), 1),
                      "launches": len(kt), "events_per_launch": k_events / max(len(kt), 1),
                      "algorithmic_bytes_per_history": BYTES_PER_HISTORY + per_event * ev_per_hist})

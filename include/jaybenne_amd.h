@@ -220,27 +220,31 @@ jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swa
  *     correctly rounded quotients, the reference's unfused position update -- and the particles
  *     come out bit-identical to it.
  *   JB_ARITH_LEAN (default): while a lane follows a photon it carries the unit direction v / c and
- *     the distance left to census c (t_end - t) instead of v and t; distance to a face as
- *     (face - x) times a once-refined reciprocal of the direction component (within 2^-48, ~20 ulp,
- *     of the correctly rounded quotient; in 3-D the three reciprocals come from one, of the product
- *     of the components: 1 / ox = oy oz / (ox oy oz), to the same accuracy), position update as one
- *     fused multiply-add per axis,
- *     logarithm without its compensated sum (<= 3 ulp), square root of 1 - mu^2 with one residual
- *     correction (<= 2 ulp) -- every operation within 4e-15 (relative) of the exact variant's; and,
- *     per axis, only the face the photon moves TOWARDS is tested for the nudge of
- *     transport_utils.hpp:151-159 (the face behind is >= eps_imc dx away unless the photon has
- *     moved less than the rounding error of its position since it entered the cell: ~1e-13 per
- *     event).  ~25 % fewer instructions per event than the exact variant.
+ *     the distance left to census c (t_end - t) instead of v and t, and -- on meshes with the exact
+ *     geometry (jb_mesh_exact_geometry: power-of-two cell widths; every stepdiff deck) -- the
+ *     position RELATIVE TO THE CENTRE OF ITS CELL instead of x, with the cell as one byte offset into
+ *     the per-cell arrays (k_imc_cell); distance to a face as
+ *     (h - sgn(omega) p) / |omega| with a once-refined reciprocal of the direction component (within
+ *     2^-48, ~20 ulp, of the correctly rounded quotient; in 3-D the three reciprocals come from one,
+ *     of the product of the components, to the same accuracy), position update as one fused
+ *     multiply-add per axis, logarithm without its compensated sum (<= 3 ulp), square root of
+ *     1 - mu^2 with one residual correction (<= 2 ulp) -- every operation within 4e-15 (relative) of
+ *     the exact variant's, the cell-local position carrying ~8 bits MORE than the absolute one the
+ *     exact variant (and the reference) round at every event.  Both faces of an axis are tested for
+ *     the nudge of transport_utils.hpp:151-159, as in the reference.  (Meshes without the exact
+ *     geometry: the x-space form of round 3, which tests only the face ahead.)  ~40 % fewer
+ *     instructions per event than the exact variant.
  *     Stated tolerance (tests/test_gpu_lean.py, tests/test_gpu_accuracy.py):
- *       - after ONE or TWO full cycles every floating-point attribute of every photon is within
- *         1e-9 of the exact variant's and of the oracle's (positions relative to the domain size,
- *         velocities to c, times to dt), integer attributes and stream states equal;
+ *       - after ONE full cycle every floating-point attribute of every photon is within 1e-9 of the
+ *         exact variant's and of the oracle's (positions relative to the domain size, velocities to
+ *         c, times to dt), after TWO within 1e-8; integer attributes and stream states equal;
  *       - beyond that the two roundings of a history separate like nearby trajectories of any
- *         chaotic system -- measured: largest position difference over 1e5 photons 5e-13 of the
- *         domain after one cycle, 7e-11 after two, then about a decade per cycle, 2.5e-4 after ten
+ *         chaotic system -- measured: largest position difference over 1e5 photons 5e-12 of the
+ *         domain after one cycle, 1.3e-9 after two, then about a decade per cycle, 1e-4 after ten
  *         (the oracle's own libm / portable flavours, <= 1 ulp apart in log and sincos, separate
- *         at the same rate) -- and a photon changes its sequence of events only where a
- *         difference flips a comparison: 7 of 1e5 photons in ten cycles, ~1e-8 per history-event;
+ *         at the same rate; what the lean variant differs by from the exact one is mostly the exact
+ *         variant's own rounding of x to the absolute grid) -- and a photon changes its sequence of
+ *         events only where a difference flips a comparison: 20 of 1e5 photons in ten cycles;
  *       - at any length: the energy tally within 6 sigma of each cell's Monte Carlo noise of the
  *         libm-arithmetic CPU path on the same streams (measured 3e-13 sigma on BASELINE
  *         configs[0], 0.016 sigma per x-plane on configs[1]'s geometry) and the reference's error

@@ -225,12 +225,32 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         "hybrid, 3-D, IMC phase, lean on exact geometry": "k_hybridILi3ELb1ELb1ELi2ELi1E",
         "hybrid, 3-D, DDMC phase": "k_hybridILi3ELb1ELb1ELi0ELi2E",
     }
+    def scratch_in_inner_loops(kernel):
+        """scratch_load / scratch_store instructions inside a loop nested in the kernel's outer
+        (service / event) loop: the event loop itself."""
+        body = text[text.index(kernel + ":"):]
+        body = body[:body.index("s_endpgm")]
+        depth, hits = 0, []
+        for line in body.split("\n"):
+            m = re.search(r"Depth=(\d+)", line)
+            if re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", line):
+                depth = int(m.group(1)) if m else 0
+            elif "scratch_" in line and depth >= 2:
+                hits.append(line.strip())
+        return hits
+
     for what, key in hot.items():
         names = [n for n in found if key in n]
         assert len(names) == 1, (what, names)
         vgpr, scratch = found[names[0]]
         assert vgpr <= 168, f"{what}: {vgpr} vector registers (> 168: two waves per SIMD)"
-        assert scratch == 0, f"{what}: {scratch} bytes of scratch per lane (register spills)"
+        if "k_imc_cell" in key:
+            # four waves per SIMD (128 registers): the 3-D kernels may park service-phase values in
+            # scratch memory around the event loop, never inside it
+            assert vgpr <= 128, f"{what}: {vgpr} vector registers (> 128: three waves per SIMD)"
+            assert scratch <= 128 and not scratch_in_inner_loops(names[0]), (what, scratch, scratch_in_inner_loops(names[0])[:4])
+        else:
+            assert scratch == 0, f"{what}: {scratch} bytes of scratch per lane (register spills)"
     # the all-DDMC kernel is bound by the latency of its gathers and runs FOUR waves per SIMD:
     # 128 registers, and at most 40 KB of LDS per workgroup (its LDS tally is dynamic shared memory)
     # (static LDS + the most dynamic LDS a launch can ask for -- the tally of <= kLdsTally = 1024 cells,

@@ -162,12 +162,14 @@ def test_lean_against_exact_over_ten_cycles(gpu_device):
     own test runs 10: tst/stepdiff.py).  Every scatter turns a position difference into a
     direction-dependent path difference, so two roundings of the same history separate like any
     two nearby trajectories of a chaotic system -- measured on this deck (3-D, 1e5 photons), largest
-    position difference over all photons, relative to the domain: 5e-13 after one cycle, 7e-11
-    after two, then about a decade per cycle, 2.5e-4 after ten; 7 of the 1e5 photons had a
-    comparison flipped on the way (a different sequence of events from there on).  The oracle's own
+    position difference over all photons, relative to the domain: 5e-12 after one cycle, 1.3e-9
+    after two, then about a decade per cycle, 1e-4 after ten; 20 of the 1e5 photons had a
+    comparison flipped on the way (a different sequence of events from there on).  (Round 3's
+    x-space lean step: 5e-13 / 7e-11 / 7 photons -- it rounded x to the same absolute grid as the
+    exact variant at every event; the cell-local step carries more bits than either.)  The oracle's own
     two flavours (libm / portable: two correct statements of the reference, <= 1 ulp apart in log
     and sincos) separate at the same rate.  Stated and asserted (include/jaybenne_amd.h): attributes
-    within 1e-9 for <= 2 cycles; after 10 cycles every photon whose event sequence was not flipped
+    within 1e-9 after one cycle, 1e-8 after two; after 10 cycles every photon whose event sequence was not flipped
     sits in the same cell as its exact twin with positions within 1e-2 of the domain, the flipped
     ones are < 1e-3 of the photons, and the energy tally -- what the reference's acceptance test
     reads -- is within 1e-9 of its largest value plus the weight of the photons that changed cell."""
