@@ -93,6 +93,7 @@ struct jb_mesh {
   const char *last_pair = "";     // ... and the k_ddmc_all launched beside it (gray DDMC), or ""
   const DevMesh *dm_dev = nullptr;  // copy of dm in device memory (k_hybrid reads the view through it)
   const int *nbr_dq = nullptr;      // k_imc_cell: change of the cell's byte offset per (block, face) crossing
+  bool uniform_geom = false;        // every resident block has the cell widths of block 0 (k_imc_cell<.., UNIFORM>)
   // "some cell takes IMC steps" (DevMesh::not_all_ddmc) as the host last read it: -1 = not since
   // UpdateDerivedTransportFields rewrote it (the first DDMC transport call of a cycle reads it back,
   // one synchronisation; the further transport iterations of a multi-rank cycle reuse the answer)
@@ -355,6 +356,9 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
     // (the EXACT tracking kernels also address the mean-free-path arrays of all resident blocks
     // with 32-bit byte offsets: 16 bytes per cell)
     m->exact_geom = exact && 16ull * (unsigned long long)D.ntot * (unsigned long long)v->nblocks < (1ull << 32);
+    m->uniform_geom = true;
+    for (int b = 1; b < v->nblocks; ++b)
+      for (int d = 0; d < 3; ++d) m->uniform_geom = m->uniform_geom && v->blk_dx[3 * b + d] == v->blk_dx[d];
   }
   int maxrank = 0;
   for (int g = 0; g < v->nblocks_total; ++g) maxrank = v->owner[g] > maxrank ? v->owner[g] : maxrank;
@@ -715,17 +719,22 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
       {{"k_imc_cell<3, false, false, lean>", "k_imc_cell<3, false, true, lean>"},
        {"k_imc_cell<3, true, false, lean>", "k_imc_cell<3, true, true, lean>"}}};
   (void)imc_cell_names;
-#define JB_LAUNCH_CELL(T, NA)                                                                      \
+#define JB_LAUNCH_CELL_U(T, NA, U)                                                                 \
   do {                                                                                             \
     static int occ = 0;                                                                            \
     if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(                                  \
-                        &occ, k_imc_cell<NDIM, T, NA>, kBlock, 0) != hipSuccess || occ < 1))       \
+                        &occ, k_imc_cell<NDIM, T, NA, U>, kBlock, 0) != hipSuccess || occ < 1))    \
       occ = 3;                                                                                     \
     const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : occ);                  \
-    hipLaunchKernelGGL((k_imc_cell<NDIM, T, NA>), dim3(g), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, \
+    hipLaunchKernelGGL((k_imc_cell<NDIM, T, NA, U>), dim3(g), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, \
                        ctx->dp, S, t_start, dt, first, last, ctx->counters_d, mesh->nbr_dq);       \
     /* (variant string: NDIM, TALLY, NOABS, and the arithmetic) */                                 \
     mesh->last_variant = imc_cell_names[NDIM - 1][(T) ? 1 : 0][(NA) ? 1 : 0];                      \
+  } while (0)
+#define JB_LAUNCH_CELL(T, NA)                                                                      \
+  do {                                                                                             \
+    if (mesh->uniform_geom) JB_LAUNCH_CELL_U(T, NA, true);                                         \
+    else JB_LAUNCH_CELL_U(T, NA, false);                                                           \
   } while (0)
 #define JB_LAUNCH(T, G)                                                                            \
   do {                                                                                             \
@@ -922,6 +931,7 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
   else JB_LAUNCH(false, 0);
 #undef JB_LAUNCH
 #undef JB_LAUNCH_CELL
+#undef JB_LAUNCH_CELL_U
 #undef JB_LAUNCH_X
   return JB_COMPLETE;
 }

@@ -267,6 +267,15 @@ __device__ __forceinline__ unsigned sgpr_copy(unsigned v) {
   asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"((unsigned)__builtin_amdgcn_readfirstlane((int)v)));
   return r;
 }
+// a wave-uniform double in a scalar register pair of its own
+__device__ __forceinline__ double uniform_f64(double v) {
+  const unsigned long long q = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(q >> 32));
+  unsigned long long r;
+  asm volatile("s_mov_b64 %0, %1" : "=s"(r) : "s"(((unsigned long long)hi << 32) | lo));
+  return __longlong_as_double((long long)r);
+}
 __device__ __forceinline__ const double *sgpr_copy_ptr(const double *p) {
   const unsigned long long q = (unsigned long long)p;
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q);

@@ -42,11 +42,17 @@
 namespace jb {
 
 // Waves per SIMD the register allocator is held to.  The 2-D and 1-D kernels need < 128 registers
-// anyway (four waves).  The 3-D kernel takes 140 when left alone; held to 128 it parks 33 of the
-// service phase's values in scratch memory at the event loop's entry and exit -- nothing inside the
-// loop (tests/test_cabi.py reads the ISA) -- and the fourth wave buys 2.4 % (A/B on one box, twice).
+// anyway (four waves).  The 3-D kernel takes 140 with the block geometry per lane (blocks of several
+// sizes: SMR) and stays at three waves; on a mesh whose resident blocks all have ONE cell size
+// (UNIFORM: BASELINE configs[1]) the geometry is wave-uniform -- seven scalar register pairs instead
+// of fourteen vector registers -- and the kernel fits 128 registers without spilling: four waves,
+// 2.4 % (A/B on one box, twice).  (Held to 128 with per-lane geometry it parks 33 service-phase
+// values in scratch memory around the loop: the same 2.4 %, and 8 GB of scratch traffic per launch.)
+#ifndef JB_IMC_WAVES_PER_SIMD_UNIFORM
+#define JB_IMC_WAVES_PER_SIMD_UNIFORM 4
+#endif
 #ifndef JB_IMC_WAVES_PER_SIMD
-#define JB_IMC_WAVES_PER_SIMD 4
+#define JB_IMC_WAVES_PER_SIMD 3
 #endif
 #ifndef JB_IMC_SERVICE_BUDGET
 #define JB_IMC_SERVICE_BUDGET 96
@@ -66,8 +72,8 @@ struct ImcArgs {
 enum { IS_IDLE = 0, IS_RUN = 1, IS_DONE = 2, IS_DONE_RAW = 3 };
 
 
-template <int NDIM, bool TALLY, bool NOABS>
-__global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
+template <int NDIM, bool TALLY, bool NOABS, bool UNIFORM>
+__global__ void __launch_bounds__(kBlock, (UNIFORM || NDIM < 3) ? JB_IMC_WAVES_PER_SIMD_UNIFORM : JB_IMC_WAVES_PER_SIMD)
     k_imc_cell(const DevMesh *__restrict__, DevParams, DevSwarm, double, double, long long, long long,
                unsigned long long *, const int *) {
   // The arguments are read where they are used, from the kernel-argument segment (scalar loads), and
@@ -125,8 +131,15 @@ __global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
   double px = 0, py = 0, pz = 0;            // position relative to the cell centre
   double ox = 0, oy = 0, oz = 0;            // unit direction (IS_DONE_RAW: the velocity as loaded)
   double drem = 0;                          // distance left to census (IS_DONE_RAW: the time as loaded)
-  // half cell widths of the block, h - eps_imc dx, min cell width of the block (transport.cpp:75-78)
+  // half cell widths of the block, h - eps_imc dx, min cell width of the block (transport.cpp:75-78):
+  // per lane, or (UNIFORM: every resident block has the cell size of block 0) once per wave
   CellGeom cg{0, 0, 0, 0, 0, 0, 0};
+  if constexpr (UNIFORM) {
+    const double d0 = uniform_f64(M.blk_dx[0]), d1 = uniform_f64(M.blk_dx[1]), d2 = uniform_f64(M.blk_dx[2]);
+    cg.hx = 0.5 * d0; cg.hy = 0.5 * d1; cg.hz = 0.5 * d2;
+    cg.mx = cg.hx - kEpsImc * d0; cg.my = cg.hy - kEpsImc * d1; cg.mz = cg.hz - kEpsImc * d2;
+    cg.dxp = dmin(d0, dmin(d1, d2));
+  }
   double lam_a = 0.0, lam_s = 0.0;          // mean free paths of the photon's cell, or the ghost code
 
   auto fetch_lam = [&]() {
@@ -134,6 +147,7 @@ __global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
     lam_s = *(gcptr)(lam_sc0 + qoff);
   };
   auto bind_block = [&](int blk) {
+    if constexpr (UNIFORM) return;
     const double d0 = ((gcptr)M.blk_dx)[3 * blk], d1 = ((gcptr)M.blk_dx)[3 * blk + 1],
                  d2 = ((gcptr)M.blk_dx)[3 * blk + 2];
     cg.hx = 0.5 * d0; cg.hy = 0.5 * d1; cg.hz = 0.5 * d2;
@@ -341,8 +355,10 @@ __global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
               oz = __hiloint2double(__double2hiint(oz) ^ fz, __double2loint(oz));
             }
             qoff = (unsigned)__double2loint(lam_s);
-            if (code & (kGhostCoarser | kGhostFiner))  // a resident block one level up or down
-              qoff = cross_level<NDIM>(code, qoff, sy, sz, cg, px, py, pz);
+            if constexpr (!UNIFORM) {
+              if (code & (kGhostCoarser | kGhostFiner))  // a resident block one level up or down
+                qoff = cross_level<NDIM>(code, qoff, sy, sz, cg, px, py, pz);
+            }
             fetch_lam();
             if (!(drem > 0.0)) ls = IS_DONE;  // (reached census and a block face in one step)
           }
@@ -350,8 +366,8 @@ __global__ void __launch_bounds__(kBlock, JB_IMC_WAVES_PER_SIMD)
       }
       if (stepping) {
         bool is_absorbed, is_scattered, hit_any;
-        imc_step_cell<NDIM, NOABS>(cg, sy, sz, lam_a, lam_s, rng, drem, px, py, pz, ox, oy, oz, qoff,
-                                   is_absorbed, is_scattered, hit_any);
+        imc_step_cell<NDIM, NOABS, UNIFORM>(cg, sy, sz, lam_a, lam_s, rng, drem, px, py, pz, ox, oy, oz, qoff,
+                                            is_absorbed, is_scattered, hit_any);
         fetch_lam();  // (for the next pass, ahead of the scatter)
         const bool census = !(drem > 0.0);
         bool collide = is_absorbed || is_scattered;

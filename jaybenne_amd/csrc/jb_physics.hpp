@@ -404,10 +404,14 @@ __device__ __forceinline__ void imc_step_dir(DirGeom &g, double dx_push0, double
 
 // p = hit ? -copysign(m, p) : p -- the photon is put eps_imc dx inside the cell beyond the face it
 // reached: one v_bfi_b32 on the high word and two selects, the negation as a source modifier
+template <bool M_UNIFORM = false>
 __device__ __forceinline__ double nudged(double p, double m, bool hit) {
 #ifdef JB_NO_ASM_NUDGE
   return hit ? -copysign(m, p) : p;
 #else
+#ifdef JB_UNIFORM_NUDGE_CXX
+  if constexpr (M_UNIFORM) return hit ? -copysign(m, p) : p;
+#endif
   const unsigned long long mask = __ballot(hit);
   int chi, hi, lo;
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(chi) : "s"(0x7fffffff), "v"(__double2hiint(m)), "v"(__double2hiint(p)));
@@ -429,7 +433,7 @@ __device__ __forceinline__ double nudged(double p, double m, bool hit) {
 struct CellGeom {
   double hx, hy, hz, mx, my, mz, dxp;
 };
-template <int NDIM, bool NOABS, class Rng>
+template <int NDIM, bool NOABS, bool UNIFORM = false, class Rng>
 __device__ __forceinline__ void imc_step_cell(const CellGeom &g, int sy, int sz, double lam_a, double lam_s,
                                               Rng &rng, double &drem, double &px, double &py, double &pz,
                                               double ox, double oy, double oz, unsigned &qoff,
@@ -477,14 +481,14 @@ __device__ __forceinline__ void imc_step_cell(const CellGeom &g, int sy, int sz,
   // (+-1 by the side of the cell the photon left through, times the stride: one multiply-add per
   // axis onto the offset, the strides as scalar operands)
   qoff = (unsigned)mad24(hit_x ? (px < 0.0 ? -1 : 1) : 0, sx, (int)qoff);
-  px = nudged(px, g.mx, hit_x);
+  px = nudged<UNIFORM>(px, g.mx, hit_x);
   if (multi_d) {
     qoff = (unsigned)mad24(hit_y ? (py < 0.0 ? -1 : 1) : 0, sy, (int)qoff);
-    py = nudged(py, g.my, hit_y);
+    py = nudged<UNIFORM>(py, g.my, hit_y);
   }
   if (three_d) {
     qoff = (unsigned)mad24(hit_z ? (pz < 0.0 ? -1 : 1) : 0, sz, (int)qoff);
-    pz = nudged(pz, g.mz, hit_z);
+    pz = nudged<UNIFORM>(pz, g.mz, hit_z);
   }
   hit_any = hit_x || hit_y || hit_z;
 }

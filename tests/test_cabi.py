@@ -209,10 +209,11 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
         found[name] = (vgpr, scratch)
     hot = {
-        "IMC, 3-D, exact geometry, lean arithmetic in cell-local coordinates (BASELINE configs[1])": "k_imc_cellILi3ELb1ELb1E",
-        "IMC, 2-D, the same (configs[3])": "k_imc_cellILi2ELb1ELb1E",
-        "IMC, 1-D, the same (configs[0])": "k_imc_cellILi1ELb1ELb1E",
-        "IMC, 3-D, the same, absorbing material": "k_imc_cellILi3ELb1ELb0E",
+        "IMC, 3-D, exact geometry, lean arithmetic in cell-local coordinates, one cell size (BASELINE configs[1])": "k_imc_cellILi3ELb1ELb1ELb1E",
+        "IMC, 3-D, the same, blocks of several sizes": "k_imc_cellILi3ELb1ELb1ELb0E",
+        "IMC, 2-D, the same (configs[3])": "k_imc_cellILi2ELb1ELb1ELb0E",
+        "IMC, 1-D, one cell size (configs[0])": "k_imc_cellILi1ELb1ELb1ELb1E",
+        "IMC, 3-D, one cell size, absorbing material": "k_imc_cellILi3ELb1ELb0ELb1E",
         "IMC, 3-D, exact geometry, lean arithmetic in x-space (JB_NO_IMC_CELL=1)": "k_transportILi3ELb0ELb1ELi2ELb1ELb1E",
         "IMC, 3-D, exact geometry, exact arithmetic": "k_transportILi3ELb0ELb1ELi2ELb1ELb0E",
         "IMC, 2-D, exact geometry, lean arithmetic (configs[3])": "k_transportILi2ELb0ELb1ELi2ELb1ELb1E",
@@ -244,13 +245,10 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         assert len(names) == 1, (what, names)
         vgpr, scratch = found[names[0]]
         assert vgpr <= 168, f"{what}: {vgpr} vector registers (> 168: two waves per SIMD)"
-        if "k_imc_cell" in key:
-            # four waves per SIMD (128 registers): the 3-D kernels may park service-phase values in
-            # scratch memory around the event loop, never inside it
+        if "k_imc_cell" in key and "several sizes" not in what:
+            # four waves per SIMD (128 registers) without a spill: wave-uniform geometry, or fewer than three axes
             assert vgpr <= 128, f"{what}: {vgpr} vector registers (> 128: three waves per SIMD)"
-            assert scratch <= 128 and not scratch_in_inner_loops(names[0]), (what, scratch, scratch_in_inner_loops(names[0])[:4])
-        else:
-            assert scratch == 0, f"{what}: {scratch} bytes of scratch per lane (register spills)"
+        assert scratch == 0 and not scratch_in_inner_loops(names[0]), f"{what}: {scratch} bytes of scratch per lane (register spills)"
     # the all-DDMC kernel is bound by the latency of its gathers and runs FOUR waves per SIMD:
     # 128 registers, and at most 40 KB of LDS per workgroup (its LDS tally is dynamic shared memory)
     # (static LDS + the most dynamic LDS a launch can ask for -- the tally of <= kLdsTally = 1024 cells,

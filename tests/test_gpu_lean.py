@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 
 from helpers import load_deck, make_oracle, run_oracle_cycles
-from test_gpu_parity import C5_LEVEL2, SMR_OVERRIDES, _gpu_problem
+from test_gpu_parity import C5_LEVEL2, SMR3D, SMR_OVERRIDES, _gpu_problem
 
 pytestmark = [pytest.mark.gpu, pytest.mark.lean]
 
@@ -39,6 +39,10 @@ CASES = [
                   "jaybenne/num_particles": 20000}, 1),                        # absorbing (GRAY = 1)
     ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 30000}, 1),            # hybrid: IMC steps lean
     ("stepdiff_smr_hybrid", dict(C5_LEVEL2, **{"jaybenne/num_particles": 30000}), 1),   # ... 3 levels
+    # 3-D SMR: level changes through the ghost-cell codes with four fine cells behind a coarse ghost cell
+    ("stepdiff_smr", dict(SMR3D, **{"jaybenne/num_particles": 20000}), 1),             # pure IMC (k_imc_cell<3>)
+    ("stepdiff_smr_hybrid", dict(SMR3D, **{"jaybenne/num_particles": 30000,
+                                           "jaybenne/tau_ddmc": 20.0}), 1),            # coarse DDMC / fine IMC
     # cell widths that are not powers of two: the lean step on general geometry
     ("stepdiff", {"parthenon/mesh/nx1": 24, "parthenon/mesh/nx2": 12, "parthenon/mesh/nx3": 12,
                   "parthenon/meshblock/nx1": 12, "parthenon/meshblock/nx2": 6,
