@@ -638,6 +638,8 @@ def main() -> None:
                        "blocks_per_gpu": md.nowned, "halo_blocks_per_gpu": md.nblocks - md.nowned,
                        "particles_per_gpu": args.particles_per_gpu,
                        "defrag_interval": int(args.defrag_interval),
+                       "defrag_sorts_in_run": int(md.defrags),
+                       "kernel_ms_by_step": [round(1e3 * t, 2) for t, _ in kt][:64],
                        "parallelism": f"meshblocks over {args.gpus} rank(s), "
                                       f"{'RCCL' if backend == 'nccl' else backend} particle hand-off"},
             "events_per_s": events / wall,

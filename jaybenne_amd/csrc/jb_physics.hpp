@@ -478,16 +478,18 @@ __device__ __forceinline__ void imc_step_cell(const CellGeom &g, int sy, int sz,
   const bool hit_x = fabs(px) > g.mx;
   const bool hit_y = multi_d && fabs(py) > g.my;
   const bool hit_z = three_d && fabs(pz) > g.mz;
-  // (+-1 by the side of the cell the photon left through, times the stride: one multiply-add per
-  // axis onto the offset, the strides as scalar operands)
-  qoff = (unsigned)mad24(hit_x ? (px < 0.0 ? -1 : 1) : 0, sx, (int)qoff);
+  // (+-1 by the side of the cell the photon left through -- sign word of p, shifted down and ORed
+  // with 1: two plain 32-bit operations -- times the stride: one multiply-add per axis onto the
+  // offset, the strides as scalar operands)
+  auto side = [](double p) { return (__double2hiint(p) >> 31) | 1; };
+  qoff = (unsigned)mad24(hit_x ? side(px) : 0, sx, (int)qoff);
   px = nudged<UNIFORM>(px, g.mx, hit_x);
   if (multi_d) {
-    qoff = (unsigned)mad24(hit_y ? (py < 0.0 ? -1 : 1) : 0, sy, (int)qoff);
+    qoff = (unsigned)mad24(hit_y ? side(py) : 0, sy, (int)qoff);
     py = nudged<UNIFORM>(py, g.my, hit_y);
   }
   if (three_d) {
-    qoff = (unsigned)mad24(hit_z ? (pz < 0.0 ? -1 : 1) : 0, sz, (int)qoff);
+    qoff = (unsigned)mad24(hit_z ? side(pz) : 0, sz, (int)qoff);
     pz = nudged<UNIFORM>(pz, g.mz, hit_z);
   }
   hit_any = hit_x || hit_y || hit_z;
