@@ -4,15 +4,21 @@ RCCL (backend "nccl") on xGMI, or gloo on CPU for tests.
 The reference's only communication on this path is (i) the neighbour hand-off of particles that
 left a rank's blocks (``MeshSend`` / ``MeshReceive``, reference jaybenne.cpp:36-61) and (ii) the
 global completion test of the iterate-sublist (``TQ::global_sync | TQ::completion``,
-jaybenne.cpp:130-131).  Both are expressed here as two small collectives per transport iteration:
+jaybenne.cpp:130-131).  Both are expressed here as at most two small collectives per transport
+iteration (``jaybenne._exchange``):
 
-* ``exchange_records``: an all-to-all of the per-destination record counts followed by one
-  all-to-all-v of fixed-size particle records (13 x 8 bytes).  xGMI is a full point-to-point
-  mesh, so every rank pair moves its share over its own link concurrently;
-* ``allreduce_sum_int64``: one integer ("particles that changed rank this iteration").
+* ``gather_count_matrix``: ONE all-gather of every rank's per-destination record counts -- the
+  rank x rank matrix carries each rank's receive sizes and the global total that decides
+  termination (the completion test needs no collective of its own);
+* ``exchange_records`` (only if something moved): one all-to-all-v of fixed-size particle records
+  (13 x 8 bytes), sized from the matrix.  xGMI is a full point-to-point mesh, so every rank pair
+  moves its share over its own link concurrently.
 
-There is no collective inside the tracking kernel and none on the field data: each rank owns its
-blocks' fields outright.
+``exchange_counts`` (an all-to-all of counts) is the fallback of ``exchange_records`` for callers that
+have no matrix; ``allreduce_sum_int64`` serves the source (global per-block photon counts, one per
+source call) and the bench's statistics.  With material feedback the halo copies' fields are
+refreshed once per cycle (``halo.py``: one all-to-all-v of cell values); there is no collective
+inside the tracking kernel.
 """
 from __future__ import annotations
 
