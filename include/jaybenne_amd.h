@@ -318,9 +318,15 @@ jb_status jb_defrag_particles(jb_context *ctx, jb_mesh *mesh, const jb_swarm_vie
  * kernels needed: the minimum distance between sorts doubles (2, 4, .. 256 cycles) until one pays
  * again.  Slot order only affects speed, never results; defrag_interval = 0 in the hosts keeps the
  * order of the reference (never sorted), k > 0 sorts after every k-th cycle.
- * The caller must have synchronised the stream since the cycle's last transport call. */
+ * The caller must have synchronised the stream since the cycle's last transport call.
+ * mode: JB_DEFRAG_DECIDE_AND_SORT for a host that holds the whole swarm.  Several ranks sort
+ * TOGETHER (a cycle is as long as its slowest rank: a sort on one rank per cycle, in turn, would be
+ * paid every cycle): every rank calls with JB_DEFRAG_DECIDE (*sorted = 1: this rank would sort),
+ * the host reduces that over the ranks (max) and, if any rank asked, every rank calls again with
+ * JB_DEFRAG_SORT_NOW. */
+enum { JB_DEFRAG_DECIDE_AND_SORT = 0, JB_DEFRAG_DECIDE = 1, JB_DEFRAG_SORT_NOW = 2 };
 jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
-                           int64_t events_this_cycle, int32_t *sorted);
+                           int64_t events_this_cycle, int32_t mode, int32_t *sorted);
 /* Gives the library's scratch memory back (synchronises the stream first).  The scratch buffer
  * grows on demand and is otherwise kept for the life of the context: 128 bytes per photon after a
  * DefragParticles (sized exactly), a few bytes per photon for the hole / hand-off lists.  If it cannot

@@ -398,7 +398,8 @@ inline TaskStatus RadiationStep(MeshData *md, const Real t_start, const Real dt)
   // (not in the reference's task list: DefragParticles on the library's schedule, or every k-th cycle)
   if (md->defrag_interval < 0) {
     int32_t sorted = 0;
-    Check(jb_defrag_policy(md->ctx(), md->mesh(), &md->swarm, after.n_events - before.n_events, &sorted));
+    Check(jb_defrag_policy(md->ctx(), md->mesh(), &md->swarm, after.n_events - before.n_events,
+                           JB_DEFRAG_DECIDE_AND_SORT, &sorted));
     md->defrags += sorted;
   } else if (md->defrag_interval > 0 && ++md->steps_since_defrag >= md->defrag_interval) {
     DefragParticles(md);

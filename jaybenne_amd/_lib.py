@@ -124,7 +124,7 @@ PROTOTYPES = {
     "jb_remove_marked_particles": (_int, [_vp, C.POINTER(SwarmView)]),
     "jb_defrag_particles": (_int, [_vp, _vp, C.POINTER(SwarmView)]),
     "jb_release_scratch": (_int, [_vp]),
-    "jb_defrag_policy": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, C.POINTER(C.c_int32)]),
+    "jb_defrag_policy": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, C.c_int32, C.POINTER(C.c_int32)]),
     "jb_pack_outgoing": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, _i64, _int, _vp, _i64, _vp]),
     "jb_unpack_incoming": (_int, [_vp, _vp, C.POINTER(SwarmView), _vp, _i64]),
     "jb_gather_cells": (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp]),

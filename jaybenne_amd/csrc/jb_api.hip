@@ -68,6 +68,7 @@ struct jb_context {
   double rate_ref = 0.0;             // lowest ms per event seen since the last sort (0: none yet)
   double rate_before_sort = 0.0;     // ... the rate of the cycle that triggered the last sort
   double excess_ms = 0.0;            // time spent above rate_ref since the last sort
+  double last_rate = 0.0;            // ms per event of the cycle the policy looked at last
   double sort_ms_per_photon = 1.5e-7;  // cost of a sort: 15 ms per 1e8 photons until one has been timed
   hipEvent_t sort_ev[2] = {nullptr, nullptr};
   bool sort_timed = false;           // sort_ev brackets a sort whose time has not been read yet
@@ -1206,6 +1207,35 @@ extern "C" jb_status jb_defrag_particles(jb_context *ctx, jb_mesh *mesh, const j
   return JB_COMPLETE;
 }
 
+// the sort of jb_defrag_policy, timed, and the policy's state behind it
+static jb_status defrag_now(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm, double rate, int32_t *sorted) {
+  if (!ctx->sort_ev[0]) {
+    JB_HIP(hipEventCreate(&ctx->sort_ev[0]));
+    JB_HIP(hipEventCreate(&ctx->sort_ev[1]));
+  }
+  (void)hipEventRecord(ctx->sort_ev[0], ctx->stream);
+  jb_status st = jb_defrag_particles(ctx, mesh, swarm);
+  if (st == JB_ERR_HIP) {  // (no room for the sort's scratch records: the run goes on unsorted)
+    fprintf(stderr, "jaybenne_amd: DefragParticles skipped (%s)\n", g_err);
+    (void)hipGetLastError();
+    ctx->min_interval = 256;
+    ctx->cycles_since_sort = 0;
+    ctx->excess_ms = 0.0;
+    return JB_COMPLETE;
+  }
+  if (st != JB_COMPLETE) return st;
+  (void)hipEventRecord(ctx->sort_ev[1], ctx->stream);
+  ctx->sort_timed = true;
+  ctx->sort_n = swarm->n;
+  ctx->rate_before_sort = rate;
+  ctx->rate_ref = 0.0;
+  ctx->excess_ms = 0.0;
+  ctx->cycles_since_sort = 0;
+  ++ctx->policy_sorts;
+  *sorted = 1;
+  return JB_COMPLETE;
+}
+
 extern "C" jb_status jb_release_scratch(jb_context *ctx) {
   if (!ctx) return fail(JB_ERR_INVALID, "null context");
   JB_HIP(hipSetDevice(ctx->device));
@@ -1217,9 +1247,16 @@ extern "C" jb_status jb_release_scratch(jb_context *ctx) {
 }
 
 extern "C" jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
-                                       int64_t events_this_cycle, int32_t *sorted) {
+                                       int64_t events_this_cycle, int32_t mode, int32_t *sorted) {
   if (!ctx || !mesh || !sorted) return fail(JB_ERR_INVALID, "null argument");
+  if (mode < JB_DEFRAG_DECIDE_AND_SORT || mode > JB_DEFRAG_SORT_NOW) return fail(JB_ERR_INVALID, "unknown mode");
   *sorted = 0;
+  if (mode == JB_DEFRAG_SORT_NOW) {  // (the ranks have agreed: the cycle's times were taken by the DECIDE call)
+    JB_HIP(hipSetDevice(ctx->device));
+    jb_status st2 = check_swarm(swarm, "jb_defrag_policy");
+    if (st2 != JB_COMPLETE) return st2;
+    return defrag_now(ctx, mesh, swarm, ctx->last_rate, sorted);
+  }
   JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_defrag_policy");
   if (st != JB_COMPLETE) return st;
@@ -1256,32 +1293,14 @@ extern "C" jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_s
   // Sort when the time lost to the loosened order since the last sort has added up to what a sort
   // costs (for a loss that grows linearly from cycle to cycle that is the period which minimises
   // sort cost + loss per cycle), and only on a slow-down that is no timing noise (3 %).
+  ctx->last_rate = rate;
   const double sort_ms = ctx->sort_ms_per_photon * (double)swarm->n;
   if (ctx->cycles_since_sort >= ctx->min_interval && rate > 1.03 * ctx->rate_ref && ctx->excess_ms >= sort_ms) {
-    if (!ctx->sort_ev[0]) {
-      JB_HIP(hipEventCreate(&ctx->sort_ev[0]));
-      JB_HIP(hipEventCreate(&ctx->sort_ev[1]));
-    }
-    (void)hipEventRecord(ctx->sort_ev[0], ctx->stream);
-    st = jb_defrag_particles(ctx, mesh, swarm);
-    if (st == JB_ERR_HIP) {  // (no room for the sort's scratch records: the run goes on unsorted)
-      fprintf(stderr, "jaybenne_amd: DefragParticles skipped (%s)\n", g_err);
-      (void)hipGetLastError();
-      ctx->min_interval = 256;
-      ctx->cycles_since_sort = 0;
-      ctx->excess_ms = 0.0;
+    if (mode == JB_DEFRAG_DECIDE) {
+      *sorted = 1;  // (this rank would sort: the host asks the others, then calls again with SORT_NOW)
       return JB_COMPLETE;
     }
-    if (st != JB_COMPLETE) return st;
-    (void)hipEventRecord(ctx->sort_ev[1], ctx->stream);
-    ctx->sort_timed = true;
-    ctx->sort_n = swarm->n;
-    ctx->rate_before_sort = rate;
-    ctx->rate_ref = 0.0;
-    ctx->excess_ms = 0.0;
-    ctx->cycles_since_sort = 0;
-    ++ctx->policy_sorts;
-    *sorted = 1;
+    return defrag_now(ctx, mesh, swarm, rate, sorted);
   }
   return JB_COMPLETE;
 }

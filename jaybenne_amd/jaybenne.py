@@ -620,8 +620,16 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
         md._steps_since_defrag += 1
         if md.defrag_interval < 0:
             sorted_ = C.c_int32(0)
-            _lib.check(md.lib.jb_defrag_policy(pkg.ctx, md.handle, C.byref(md.sv),
-                                               int(after["n_events"] - before["n_events"]), C.byref(sorted_)))
+            events = int(after["n_events"] - before["n_events"])
+            if md.nranks == 1:
+                _lib.check(md.lib.jb_defrag_policy(pkg.ctx, md.handle, C.byref(md.sv), events, 0, C.byref(sorted_)))
+            else:
+                # the ranks sort together: a cycle is as long as its slowest rank (jaybenne_amd.h)
+                _lib.check(md.lib.jb_defrag_policy(pkg.ctx, md.handle, C.byref(md.sv), events, 1, C.byref(sorted_)))
+                if md.comm.allreduce_max_float(float(sorted_.value)) > 0.0:
+                    _lib.check(md.lib.jb_defrag_policy(pkg.ctx, md.handle, C.byref(md.sv), events, 2, C.byref(sorted_)))
+                else:
+                    sorted_.value = 0
             if sorted_.value:
                 md.defrags += 1
                 md._steps_since_defrag = 0
