@@ -945,3 +945,56 @@ def test_empty_and_ragged_inputs(gpu_device):
     # all holes
     drv.md.swarm["status"][:drv.md.n] = 1
     assert jb.RemoveMarkedParticles(drv.md) == 0
+
+
+def test_defrag_policy_modes_and_results_independent_of_slot_order(gpu_device):
+    """jb_defrag_policy (the default schedule of DefragParticles, include/jaybenne_amd.h): below 2^20
+    photons it never sorts; DECIDE never sorts; SORT_NOW sorts (the swarm comes out ordered by block
+    and cell) and counts; and a run on the default schedule ends, photon by photon (by creation id),
+    with the bits of a run that never sorts -- slot order only affects speed."""
+    import ctypes as C
+    from jaybenne_amd import _lib
+    ov = {"parthenon/mesh/nx1": 32, "parthenon/mesh/nx2": 32, "parthenon/mesh/nx3": 32,
+          "parthenon/meshblock/nx1": 16, "parthenon/meshblock/nx2": 16, "parthenon/meshblock/nx3": 16,
+          "jaybenne/num_particles": 1100000}
+    runs = {}
+    for interval in (-1, 0):
+        drv = _gpu_problem(load_deck("stepdiff_ddmc", ov), gpu_device)
+        drv.md.defrag_interval = interval
+        for _ in range(6):
+            drv.Step()
+        runs[interval] = (drv.md.get_swarm(), drv.md.n, drv.md.events, drv.md.defrags)
+        if interval == -1:
+            md = drv.md
+            md._sync_stream()
+            flag = C.c_int32(7)
+            # DECIDE: an answer, no sort; an unknown mode is refused
+            before = md.defrags
+            _lib.check(md.lib.jb_defrag_policy(md.pkg.ctx, md.handle, C.byref(md.sv), 1000, 1, C.byref(flag)))
+            assert flag.value in (0, 1)
+            assert md.lib.jb_defrag_policy(md.pkg.ctx, md.handle, C.byref(md.sv), 1000, 5, C.byref(flag)) == _lib.JB_ERR_INVALID
+            # SORT_NOW: sorted by (block, cell)
+            _lib.check(md.lib.jb_defrag_policy(md.pkg.ctx, md.handle, C.byref(md.sv), 1000, 2, C.byref(flag)))
+            assert flag.value == 1 and md.defrags == before
+            g = md.get_swarm()
+            m = drv.mesh
+            b = g["blk"].astype(np.int64)
+            cell = np.zeros(len(b), dtype=np.int64)
+            stride = 1
+            for d, name in enumerate("xyz"):
+                idx = np.floor((g[name] - m.blk_xmin[b, d]) * (1.0 / m.blk_dx[b, d])).astype(np.int64) + m.is_[d]
+                cell += stride * idx
+                stride *= m.field_shape[3 - d]
+            assert np.all(np.diff(b * int(np.prod(m.field_shape[1:])) + cell) >= 0)
+            runs[interval] = (g, md.n, md.events, md.defrags)
+        del drv
+    (g, n, ev, sorts), (h, m_, ev2, sorts0) = runs[-1], runs[0]
+    assert n == m_ and ev == ev2 and sorts0 == 0
+    og, oh = np.argsort(g["id"], kind="stable"), np.argsort(h["id"], kind="stable")
+    for k in g:
+        assert np.array_equal(g[k][og], h[k][oh]), k
+    # a small swarm is left alone whatever its timings say
+    small = _gpu_problem(load_deck("stepdiff_ddmc", {"jaybenne/num_particles": 20000}), gpu_device)
+    for _ in range(8):
+        small.Step()
+    assert small.md.defrag_interval == -1 and small.md.defrags == 0
