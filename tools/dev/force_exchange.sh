@@ -7,7 +7,7 @@ timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ot
 python - <<'P'
 import json
 for f in ("nccl", "gloo", "none"):
-    try: d = json.load(open(f"gpurun_out/fx_{f}.json"))
+    try: d = json.loads([l for l in open(f"gpurun_out/fx_{f}.json") if l.startswith("{")][-1])   # (RCCL prints its banner on stdout)
     except Exception as e: print(f, "failed", e); continue
     print(f, "ms/step", round(d["ms_per_step"], 3), "kernel", round(d["roofline"]["kernel_ms_avg"], 3), "iter/step", d["transport_iterations_per_step"],
           "exchange ms", round(d["handoff"]["exchange_ms_per_step_max_rank"], 3), "coll ms", round(d["handoff"]["collectives_ms_per_step_max_rank"], 3))
