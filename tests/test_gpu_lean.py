@@ -50,6 +50,15 @@ CASES = [
     ("stepdiff_smr_hybrid", {"parthenon/mesh/nx1": 120, "parthenon/mesh/nx2": 60,
                              "parthenon/meshblock/nx1": 30, "parthenon/meshblock/nx2": 30,
                              "jaybenne/num_particles": 30000}, 1),   # (sigma dx = 8.3 coarse, 4.2 fine)
+    # photons leaving through `outflow` swarm boundaries (status ESCAPED, absolute position kept): 1-D,
+    # and 3-D with every face of the box open
+    ("stepdiff", {"parthenon/swarm/ix1_bc": "outflow", "parthenon/swarm/ox1_bc": "outflow",
+                  "jaybenne/num_particles": 20000, "mcblock/scattering_constant_value": 20.0}, 2),
+    ("stepdiff", dict({f"parthenon/swarm/{s}x{a}_bc": "outflow" for s in "io" for a in "123"},
+                      **{"parthenon/mesh/nx2": 8, "parthenon/mesh/nx3": 8, "parthenon/mesh/nx1": 16,
+                         "parthenon/meshblock/nx1": 8, "parthenon/meshblock/nx2": 4,
+                         "parthenon/meshblock/nx3": 4, "jaybenne/num_particles": 20000,
+                         "mcblock/scattering_constant_value": 20.0}), 2),
 ]
 
 
@@ -58,19 +67,19 @@ def _close(a, b, scale, what, tol=1e-9):
     assert not bad.any(), (what, int(bad.sum()), a[bad][:3], b[bad][:3])
 
 
-def _compare_within_tolerance(g, ref, n, mesh, dt, by_id=False):
+def _compare_within_tolerance(g, ref, n, mesh, dt, by_id=False, tol=1e-9):
     og = np.argsort(g["id"]) if by_id else slice(None)
     orf = np.argsort(ref["id"][:n]) if by_id else slice(None)
     for k in ("id", "rng", "ip", "jp", "kp", "blk", "status"):
         assert np.array_equal(g[k][og], ref[k][:n][orf]), k
     size = float(np.max(np.asarray(mesh.gmax) - np.asarray(mesh.gmin)))
     for k in ("x", "y", "z"):
-        _close(g[k][og], ref[k][:n][orf], size, k)
+        _close(g[k][og], ref[k][:n][orf], size, k, tol)
     for k in ("vx", "vy", "vz"):
-        _close(g[k][og], ref[k][:n][orf], C_LIGHT, k)
-    _close(g["t"][og], ref["t"][:n][orf], dt, "t")
+        _close(g[k][og], ref[k][:n][orf], C_LIGHT, k, tol)
+    _close(g["t"][og], ref["t"][:n][orf], dt, "t", tol)
     for k in ("w", "e"):
-        _close(g[k][og], ref[k][:n][orf], np.abs(ref[k][:n][orf]), k)
+        _close(g[k][og], ref[k][:n][orf], np.abs(ref[k][:n][orf]), k, tol)
 
 
 def test_lean_operations_against_the_exact_ones(gpu_device):
@@ -130,8 +139,11 @@ def test_lean_arithmetic_within_stated_tolerance_of_the_oracle(gpu_device, deck,
         assert variant.endswith(("true>", "lean>")), variant   # k_transport<..., LEAN = true> / k_imc_cell<..., lean>
     assert drv.md.n == O.n and drv.md.events == O.events
     absorbing = "mcblock/opacity_constant_value" in overrides
+    outflow = "parthenon/swarm/ix1_bc" in overrides
+    if outflow:
+        assert drv.md.stats()["n_escaped"] > 100
     _compare_within_tolerance(drv.md.get_swarm(), O.sw, O.n, mesh, pin.GetReal("jaybenne", "dt"),
-                              by_id=absorbing)
+                              by_id=absorbing or outflow, tol=1e-8 if cycles > 1 and outflow else 1e-9)
     sl = mesh.interior()
     a, b = drv.md.get_field("tally")[sl], O.fields["tally"][drv.md.gids][sl]
     assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max()
