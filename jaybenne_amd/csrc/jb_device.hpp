@@ -93,6 +93,13 @@ template <class T>
 __device__ __forceinline__ T *g1(T *p) {
   return (T *)(__attribute__((address_space(1))) T *)p;
 }
+// The mesh view as the kernels' argument structs name it: a pointer to CONSTANT memory -- written
+// by the host before the launch, never by a kernel.  Read through this type (the struct is overlaid
+// on the kernel-argument segment) its fields arrive by scalar loads, counted by lgkmcnt; as global
+// loads each was a vector-memory instruction with its s_waitcnt vmcnt(0) behind it, i.e. a wait
+// for every store and every particle request the wave had in flight -- six to ten times per
+// service phase.  (A cast to this address space and back on a generic pointer is folded away.)
+typedef const __attribute__((address_space(4))) struct DevMesh *MeshConstPtr;
 
 // Ghost cells of lam_sc hold, instead of a mean free path, what becomes of a photon that steps into
 // them -- a NEGATIVE double whose words are

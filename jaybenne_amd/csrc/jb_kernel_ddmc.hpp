@@ -41,12 +41,15 @@ namespace jb {
 #ifndef JB_DDMC_ALL_CHUNK
 #define JB_DDMC_ALL_CHUNK 128
 #endif
+#ifndef JB_DDMC_ALL_WINDOW   // 1: GATHER == 2 keeps the next 64 slots of the swarm requested ahead (see PF below)
+#define JB_DDMC_ALL_WINDOW 1
+#endif
 
 enum { DS_IDLE = 0, DS_VIRT = 1, DS_PARK = 2, DS_DONE = 3, DS_RELOC = 4 };
 
 // the kernel's argument list as the kernel-argument segment holds it (natural alignment, in order)
 struct DdmcAllArgs {
-  const DevMesh *Mp;
+  MeshConstPtr Mp;
   DevParams P;
   DevSwarm S;
   double t_start, dt;
@@ -89,13 +92,23 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   // registers instead.  The mesh view (~120 dwords) is behind a pointer for the same reason.
   const DdmcAllArgs &A = *(const DdmcAllArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   if (*A.not_all_ddmc != 0) return;  // (uniform) some cell takes IMC steps: k_hybrid runs instead
-  const DevMesh &M = *A.Mp;
+  const DevMesh &M = *(const DevMesh *)A.Mp;
   const DevParams &P = A.P;
   const DevSwarm &S = A.S;
   const double t_start = A.t_start, dt = A.dt;
   const long long first = A.first, last = A.last;
   unsigned long long *const counters = g1(A.counters);
   constexpr bool COOP = GATHER == 1 || GATHER == 3;   // (3: COOP with 64-bit addresses, records >= 4 GiB)
+  // PF (records in LDS: the event loop issues no vector-memory load, so one requested before it is
+  // not waited for until it is needed -- the counter of outstanding loads completes in order):
+  // the wave keeps a WINDOW of the next 64 slots of the swarm it will hand to its lanes, requested
+  // one service phase ahead.  Lane l holds the window's entry at position (l - win_head) mod 64;
+  // lanes that need a particle take the first entries through the lane crossbar (ds_bpermute) and
+  // exactly those entries are requested again for the slots behind the window -- consecutive lanes,
+  // consecutive slots, every particle read once.  Without it a service phase waited for its own
+  // requests: 54 % of the waves' time on BASELINE configs[2] as shipped, SIMDs 57 % busy.
+  // (1-D: with the index registers of a second and third axis the window does not fit 128 registers)
+  constexpr bool PF = GATHER == 2 && NDIM == 1 && JB_DDMC_ALL_WINDOW != 0;
   // (the LDS tally of a small mesh -- all resident blocks' cells, <= kLdsTally -- and the LDS copy
   // of its step records are dynamic shared memory, sized by the launch: a mesh that uses neither
   // leaves the room to a fourth workgroup per CU)
@@ -157,6 +170,13 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     u1 = at_leak.drand();
     u2 = at_leak.drand();
   };
+  double wgt_l = 0.0;     // (PF) the weight, requested when the particle is taken (else read at the tally)
+  // (PF) the window: per lane one requested slot of the swarm and what the kernel reads of it
+  int win_head = 0, win_count = 0;
+  long long pf_slot = -1;
+  int pf_st = ST_ABSORBED, pf_b = 0;
+  unsigned long long pf_rng = 0ull;
+  double pf_t = 0.0, pf_x = 0.0, pf_y = 0.0, pf_z = 0.0, pf_vx = 0.0, pf_vy = 0.0, pf_vz = 0.0;
   bool resample = false;  // reached census in a DDMC step: position / direction to be resampled
   bool fresh = false;     // loaded and not touched since: handing it over needs no write-back
   // ---- state that exists only between two points of one service phase
@@ -235,6 +255,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
 #ifdef JB_TIMING
     ph_mark = __builtin_readcyclecounter();
 #endif
+    // (PF: the window's requests are a whole event loop old; saying so here, before this phase
+    // issues stores, keeps the wait for them from being placed behind those stores)
+    if constexpr (PF) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     // -- 1. block crossings: the comm phase of the reference for one particle in flight
     if (ls == DS_RELOC) {
       fresh = false;
@@ -310,7 +333,18 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     int st_in = ST_ABSORBED, b_in = 0;
     unsigned long long rng_in = 0ull;
     double t_in = 0.0, x_in = 0.0, y_in = 0.0, z_in = 0.0, vx_in = 0.0, vy_in = 0.0, vz_in = 0.0;
-    {
+    // (PF: who takes which entry of the window is settled here, the entries move in 3b -- behind the
+    // write-back, so that through it a lane holds one set of particle registers, not two)
+    bool pf_mine = false;
+    int pf_src = 0, pf_give = 0;
+    if constexpr (PF) {
+      const unsigned long long need = __ballot(ls == DS_IDLE || ls == DS_DONE);
+      const int want = __popcll(need);
+      pf_give = want < win_count ? want : win_count;
+      const int rank = __popcll(need & ((1ull << lane) - 1ull));
+      pf_mine = ((need >> lane) & 1ull) != 0ull && rank < pf_give;
+      pf_src = (win_head + rank) & 63;
+    } else {
       unsigned long long need = __ballot(ls == DS_IDLE || ls == DS_DONE);
       while (need != 0ull && more) {
         if (chunk_pos >= chunk_end) {
@@ -387,7 +421,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           if constexpr (TALLY) {  // jaybenne.cpp:547-561
             const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
             // (the weight is read here, once per history, rather than carried through the event loop)
-            const double wgt = g1(S.w)[n];
+            const double wgt = PF ? wgt_l : g1(S.w)[n];
             if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
             else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], wgt / dv);
           }
@@ -415,6 +449,70 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     }
     JB_PH(2)
     // -- 3b. the lanes that claimed a slot in 2a take their new particle
+    if constexpr (PF) {
+      // (every lane takes part in the exchange: a lane outside the execution mask supplies nothing)
+      const long long c = __shfl(pf_slot, pf_src, 64);
+      st_in = __shfl(pf_st, pf_src, 64); b_in = __shfl(pf_b, pf_src, 64);
+      rng_in = __shfl(pf_rng, pf_src, 64);
+      t_in = __shfl(pf_t, pf_src, 64);
+      x_in = __shfl(pf_x, pf_src, 64); y_in = __shfl(pf_y, pf_src, 64); z_in = __shfl(pf_z, pf_src, 64);
+      vx_in = __shfl(pf_vx, pf_src, 64); vy_in = __shfl(pf_vy, pf_src, 64); vz_in = __shfl(pf_vz, pf_src, 64);
+      if (pf_mine) {
+        cand = c;
+        // (the weight is not part of the window: asked for now, read when the history ends)
+        wgt_l = g1(S.w)[c];
+      }
+      win_head = (win_head + pf_give) & 63;
+      win_count -= pf_give;
+      // ... and the window is filled up again: the entries just taken (and, at the start, all of
+      // them) are requested for the next slots of the wave's chunk -- needed one event loop from now.
+      // The free entries take what is left of the current chunk, then the head of the next one (a
+      // chunk holds two windows; a queue's short tail may leave entries free until the next phase);
+      // the requests themselves are one straight-line block.
+      const int free_n = 64 - win_count;
+      long long seg_first[2] = {0, 0};
+      int seg_n[2] = {0, 0};
+      int got = 0;
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        while (got < free_n && more && chunk_pos >= chunk_end) {
+          const long long q_first = first + (long long)cur * per_q;
+          long long q_last = q_first + per_q;
+          if (q_last > last) q_last = last;
+          unsigned long long base = 0;
+          if (lane == 0) base = atomicAdd(&queue[cur], (unsigned long long)kChunk);
+          chunk_pos = q_first + (long long)uniform_u64(base);
+          chunk_end = chunk_pos + kChunk < q_last ? chunk_pos + kChunk : q_last;
+          if (chunk_pos >= q_last) {  // this queue is drained: move on
+            chunk_pos = chunk_end = 0;
+            cur = (cur + 1) % kQueues;
+            if (++tried == kQueues) more = false;
+          }
+        }
+        if (got < free_n && chunk_pos < chunk_end) {
+          const long long avail = chunk_end - chunk_pos;
+          const int give = (long long)(free_n - got) < avail ? free_n - got : (int)avail;
+          seg_first[sg] = chunk_pos;
+          seg_n[sg] = give;
+          chunk_pos += give;
+          got += give;
+        }
+      }
+      {
+        const int pos = (lane - win_head - win_count) & 63;  // this lane's place among the free entries
+        if (pos < got) {
+          const long long q = pos < seg_n[0] ? seg_first[0] + pos : seg_first[1] + (pos - seg_n[0]);
+          pf_slot = q;
+          pf_st = g1(S.status)[q];
+          pf_rng = g1(S.rng)[q];
+          pf_b = g1(S.blk)[q];
+          pf_t = g1(S.t)[q];
+          pf_x = g1(S.x)[q]; pf_y = g1(S.y)[q]; pf_z = g1(S.z)[q];
+          pf_vx = g1(S.vx)[q]; pf_vy = g1(S.vy)[q]; pf_vz = g1(S.vz)[q];
+        }
+        win_count += got;
+      }
+    }
     if (ls == DS_IDLE && cand >= 0 && st_in == ST_ACTIVE) {
       n = cand;
       rng.s = rng_in;
@@ -458,7 +556,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     if (__ballot(ls == DS_DONE || ls == DS_RELOC) != 0ull) continue;
     const int running = __popcll(__ballot(ls == DS_VIRT));
     if (running == 0) {
-      if (more) continue;
+      if (more || win_count > 0) continue;   // (PF: the window still holds requested slots)
       break;
     }
     int waste = 0;
@@ -548,7 +646,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           }
         } else if (is_absorbed) {  // transport.cpp:157-163
           if (lds_blocks.owned[b] != 0) {
-            atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], g1(S.w)[n]);
+            atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], PF ? wgt_l : g1(S.w)[n]);
             status = ST_ABSORBED;
           } else {
             status = ST_OUTGOING_ABSORBED;
