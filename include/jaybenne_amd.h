@@ -310,12 +310,15 @@ jb_status jb_defrag_particles(jb_context *ctx, jb_mesh *mesh, const jb_swarm_vie
  * calls at the end of a cycle, after it has read the cycle's event count): the library times the
  * tracking kernels of every jb_transport_photons* call and every sort with HIP events on the
  * context's stream.  It keeps the lowest time per event seen since the last sort and adds up what
- * the cycles since have cost above it; when that loss reaches the cost of a sort (measured; 15 ms
- * per 1e8 photons until one has been) -- the period that minimises loss + sort cost per cycle for a
- * loss growing linearly -- and the current cycle is at least 3 % slower than the best one, at least
- * 2 cycles after the last sort and with at least 2^20 photons in the swarm, the swarm is sorted
- * (*sorted = 1).  A sort after which the next cycle is not at least 3 % faster was not what the
- * kernels needed: the minimum distance between sorts doubles (2, 4, .. 256 cycles) until one pays
+ * the cycles since have cost above it (the loss L); the swarm is sorted (*sorted = 1) when one more
+ * cycle in the present order would cost more than a cycle has cost on average since the last sort,
+ * the sort included -- e(p + 1) >= (S + L) / p with p cycles behind the sort, S the cost of a sort
+ * (measured; 15 ms per 1e8 photons until one has been) and e(p + 1) this cycle's loss extrapolated
+ * linearly: the period with the lowest cost per cycle for a loss that keeps growing -- and the current
+ * cycle is at least 1.5 % slower than the best one, at least 2 cycles after the last sort and with
+ * at least 2^20 photons in the swarm.  A sort after which the next cycle is not at least 1 % faster
+ * was not what the kernels needed: the minimum distance between sorts doubles (2, 4, .. 256 cycles)
+ * until one pays
  * again.  Slot order only affects speed, never results; defrag_interval = 0 in the hosts keeps the
  * order of the reference (never sorted), k > 0 sorts after every k-th cycle.
  * The caller must have synchronised the stream since the cycle's last transport call.

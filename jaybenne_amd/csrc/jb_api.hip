@@ -1282,20 +1282,27 @@ extern "C" jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_s
   const double rate = ms / (double)events_this_cycle;
   ++ctx->cycles_since_sort;
   if (ctx->cycles_since_sort == 1 && ctx->rate_before_sort > 0.0) {
-    // the first cycle behind a sort: did it pay?  If the rate came down by less than 3 %, what made
-    // the kernels slower was not the order of the swarm -- wait twice as long before the next one
-    if (rate > 0.97 * ctx->rate_before_sort) ctx->min_interval = ctx->min_interval < 256 ? 2 * ctx->min_interval : 256;
+    // the first cycle behind a sort: did it pay?  If the rate came down by less than 1 % (timing
+    // noise between cycles is ~0.3 %), what made the kernels slower was not the order of the swarm
+    // -- wait twice as long before the next one
+    if (rate > 0.99 * ctx->rate_before_sort) ctx->min_interval = ctx->min_interval < 256 ? 2 * ctx->min_interval : 256;
     else ctx->min_interval = 2;
     ctx->rate_before_sort = 0.0;
   }
   if (ctx->rate_ref == 0.0 || rate < ctx->rate_ref) ctx->rate_ref = rate;
-  ctx->excess_ms += (rate - ctx->rate_ref) * (double)events_this_cycle;
-  // Sort when the time lost to the loosened order since the last sort has added up to what a sort
-  // costs (for a loss that grows linearly from cycle to cycle that is the period which minimises
-  // sort cost + loss per cycle), and only on a slow-down that is no timing noise (3 %).
+  const double excess_now = (rate - ctx->rate_ref) * (double)events_this_cycle;
+  ctx->excess_ms += excess_now;
+  // Sort when one more cycle in this order would cost more than a cycle has cost on average since
+  // the last sort, the sort included: with p cycles behind the sort, loss L so far and a sort that
+  // costs S, that is  e(p + 1) >= (S + L) / p  -- for a loss per cycle that keeps growing, the period
+  // with the lowest (S + L) / p.  e(p + 1) is extrapolated from this cycle's loss, e(p) p / (p - 1)
+  // (linear growth from zero in the first cycle).  Only on a slow-down that is no timing noise (1.5 %).
   ctx->last_rate = rate;
   const double sort_ms = ctx->sort_ms_per_photon * (double)swarm->n;
-  if (ctx->cycles_since_sort >= ctx->min_interval && rate > 1.03 * ctx->rate_ref && ctx->excess_ms >= sort_ms) {
+  const int p = ctx->cycles_since_sort;
+  const double excess_next = p > 1 ? excess_now * (double)p / (double)(p - 1) : excess_now;
+  if (p >= ctx->min_interval && rate > 1.015 * ctx->rate_ref &&
+      excess_next * (double)p >= sort_ms + ctx->excess_ms) {
     if (mode == JB_DEFRAG_DECIDE) {
       *sorted = 1;  // (this rank would sort: the host asks the others, then calls again with SORT_NOW)
       return JB_COMPLETE;
