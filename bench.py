@@ -352,8 +352,8 @@ def fake_worker(args) -> int:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--particles-per-gpu", type=int, default=10_000_000,
                     help="10000000 = BASELINE configs[1] per GPU (default); 12500000 = north_star's "
                          "target invocation (1e8 particles on 8 GPUs)")
