@@ -41,6 +41,12 @@ namespace jb {
 #ifndef JB_HYBRID_WAVES_PER_SIMD
 #define JB_HYBRID_WAVES_PER_SIMD 3
 #endif
+#ifndef JB_HYBRID_CELL_WAVES_PER_SIMD   // the cell-local IMC phase (MODE 3, PHASE 1) in 1-D / 2-D, see below
+#define JB_HYBRID_CELL_WAVES_PER_SIMD 4
+#endif
+#ifndef JB_HYBRID_REMAINDER_WAVES_PER_SIMD
+#define JB_HYBRID_REMAINDER_WAVES_PER_SIMD 3
+#endif
 #ifndef JB_HYBRID_IMC_BUDGET      // idle lane-passes (lanes that left the IMC loop) that buy a service phase
 #define JB_HYBRID_IMC_BUDGET 96
 #endif
@@ -87,8 +93,14 @@ template <int NDIM, bool TALLY, bool NOABS, int MODE, int PHASE>
 // The exact-arithmetic IMC phase in 3-D or with an absorption opacity, and the lean one in 3-D with
 // an absorption opacity, do not fit 168 registers either (parity-test and absorbing-material
 // configurations; the stepdiff decks run none of them).
-__global__ void __launch_bounds__(kBlock, (PHASE == 0 || (PHASE == 1 && MODE == 0 && (NDIM == 3 || !NOABS)) ||
-                                           (PHASE == 1 && NDIM == 3 && !NOABS)) ? 2 : JB_HYBRID_WAVES_PER_SIMD)
+// Round 4: the cell-local IMC phase in 1-D / 2-D runs FOUR waves per SIMD: 128 registers cost it
+// 4 - 18 dwords of scratch, all of them stored and reloaded around the event loops (none inside:
+// tests/test_cabi.py), and the loop is bound by instruction issue -- BASELINE configs[4] 60.1 -> 57.0 ms.
+__global__ void __launch_bounds__(kBlock, PHASE == 0 ? JB_HYBRID_REMAINDER_WAVES_PER_SIMD
+                                          : ((PHASE == 1 && MODE == 0 && (NDIM == 3 || !NOABS)) ||
+                                             (PHASE == 1 && NDIM == 3 && !NOABS)) ? 2
+                                          : (PHASE == 1 && MODE == 3 && NDIM < 3) ? JB_HYBRID_CELL_WAVES_PER_SIMD
+                                                                                  : JB_HYBRID_WAVES_PER_SIMD)
     k_hybrid(const DevMesh *__restrict__, DevParams, DevSwarm, double, double, long long, long long,
              unsigned long long *, const unsigned *, unsigned *, unsigned long long *,
              const unsigned long long *) {

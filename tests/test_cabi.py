@@ -221,9 +221,13 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         "all-DDMC, 3-D, quad-cooperative gather (configs[2] in 3-D)": "k_ddmc_allILi3ELb1ELi1E",
         "all-DDMC, 3-D, small mesh": "k_ddmc_allILi3ELb1ELi0E",
         "all-DDMC, 1-D, records in LDS (configs[2] as shipped)": "k_ddmc_allILi1ELb1ELi2E",
-        "hybrid, 2-D, IMC phase, lean on exact geometry (configs[4])": "k_hybridILi2ELb1ELb1ELi2ELi1E",
+        "hybrid, 2-D, IMC phase in cell-local coordinates (configs[4])": "k_hybridILi2ELb1ELb1ELi3ELi1E",
+        "hybrid, 1-D, IMC phase in cell-local coordinates": "k_hybridILi1ELb1ELb1ELi3ELi1E",
+        "hybrid, 3-D, IMC phase in cell-local coordinates": "k_hybridILi3ELb1ELb1ELi3ELi1E",
+        "hybrid, 2-D, remainder (both loops), cell-local (configs[4])": "k_hybridILi2ELb1ELb1ELi3ELi0E",
+        "hybrid, 2-D, IMC phase, lean in x-space (JB_NO_IMC_CELL=1)": "k_hybridILi2ELb1ELb1ELi2ELi1E",
         "hybrid, 2-D, DDMC phase (configs[4])": "k_hybridILi2ELb1ELb1ELi0ELi2E",
-        "hybrid, 3-D, IMC phase, lean on exact geometry": "k_hybridILi3ELb1ELb1ELi2ELi1E",
+        "hybrid, 3-D, IMC phase, lean in x-space": "k_hybridILi3ELb1ELb1ELi2ELi1E",
         "hybrid, 3-D, DDMC phase": "k_hybridILi3ELb1ELb1ELi0ELi2E",
     }
     def scratch_in_inner_loops(kernel):
@@ -248,7 +252,15 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         if "k_imc_cell" in key and "several sizes" not in what:
             # four waves per SIMD (128 registers) without a spill: wave-uniform geometry, or fewer than three axes
             assert vgpr <= 128, f"{what}: {vgpr} vector registers (> 128: three waves per SIMD)"
-        assert scratch == 0 and not scratch_in_inner_loops(names[0]), f"{what}: {scratch} bytes of scratch per lane (register spills)"
+        if "cell-local" in what and "hybrid" in what and "3-D" not in what:
+            # The cell-local IMC phase of the hybrid kernel runs four waves per SIMD in 1-D / 2-D and the
+            # remainder launch three: the registers they give up are stored and reloaded AROUND the
+            # event loops (BASELINE configs[4]: 60.1 -> 55.8 ms), never inside one
+            if "remainder" not in what:
+                assert vgpr <= 128, f"{what}: {vgpr} vector registers (> 128: three waves per SIMD)"
+            assert not scratch_in_inner_loops(names[0]), f"{what}: register spills inside an event loop"
+        else:
+            assert scratch == 0 and not scratch_in_inner_loops(names[0]), f"{what}: {scratch} bytes of scratch per lane (register spills)"
     # the all-DDMC kernel is bound by the latency of its gathers and runs FOUR waves per SIMD:
     # 128 registers, and at most 40 KB of LDS per workgroup (its LDS tally is dynamic shared memory)
     # (static LDS + the most dynamic LDS a launch can ask for -- the tally of <= kLdsTally = 1024 cells,
@@ -260,9 +272,10 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         assert vgpr <= 128 and scratch == 0, (n, vgpr, scratch)
         lds = int(re.search(r"\.amdhsa_kernel %s.*?\.amdhsa_group_segment_fixed_size (\d+)" % re.escape(n), text, re.S).group(1))
         assert lds <= 65536 - max_dynamic_lds, (n, lds)
-    # no launch of the hybrid IMC/DDMC path touches scratch memory (the remainder kernel, PHASE 0,
-    # and the exact / absorbing 3-D variants of the IMC phase take two waves per SIMD instead)
+    # no launch of the hybrid IMC/DDMC path touches scratch memory inside an event loop (the IMC and DDMC
+    # phases in x-space fit 168 registers outright; the cell-local IMC phase and the remainder launch
+    # trade registers that are dead across the loops for a wave per SIMD: above)
     hybrid = {n: v for n, v in found.items() if "k_hybrid" in n}
     assert len(hybrid) > 0
-    spilling = {n: v for n, v in hybrid.items() if v[1] != 0}
-    assert not spilling, spilling
+    spilling = {n: scratch_in_inner_loops(n) for n in hybrid if hybrid[n][1] != 0}
+    assert not any(spilling.values()), {n: h[:2] for n, h in spilling.items() if h}
