@@ -54,6 +54,12 @@ namespace jb {
 #ifndef JB_IMC_WAVES_PER_SIMD
 #define JB_IMC_WAVES_PER_SIMD 3
 #endif
+// 1-D / 2-D: five waves per SIMD (96 registers); what does not fit is stored and reloaded around the
+// event loop, never inside it (tests/test_cabi.py) -- BASELINE configs[3] 43.6 -> 43.0 ms; six: 43.3.
+// (The 3-D kernel at five waves loses: 57.3 -> 59.9 ms on configs[1].)
+#ifndef JB_IMC_WAVES_PER_SIMD_LOWD
+#define JB_IMC_WAVES_PER_SIMD_LOWD 5
+#endif
 #ifndef JB_IMC_SERVICE_BUDGET
 #define JB_IMC_SERVICE_BUDGET 96
 #endif
@@ -73,7 +79,8 @@ enum { IS_IDLE = 0, IS_RUN = 1, IS_DONE = 2, IS_DONE_RAW = 3 };
 
 
 template <int NDIM, bool TALLY, bool NOABS, bool UNIFORM>
-__global__ void __launch_bounds__(kBlock, (UNIFORM || NDIM < 3) ? JB_IMC_WAVES_PER_SIMD_UNIFORM : JB_IMC_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(kBlock, NDIM < 3 ? JB_IMC_WAVES_PER_SIMD_LOWD
+                                          : UNIFORM ? JB_IMC_WAVES_PER_SIMD_UNIFORM : JB_IMC_WAVES_PER_SIMD)
     k_imc_cell(const DevMesh *__restrict__, DevParams, DevSwarm, double, double, long long, long long,
                unsigned long long *, const int *) {
   // The arguments are read where they are used, from the kernel-argument segment (scalar loads), and

@@ -249,8 +249,14 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         assert len(names) == 1, (what, names)
         vgpr, scratch = found[names[0]]
         assert vgpr <= 168, f"{what}: {vgpr} vector registers (> 168: two waves per SIMD)"
+        if "k_imc_cell" in key and "3-D" not in what:
+            # 1-D / 2-D: five waves per SIMD (96 registers); registers that do not fit are stored and
+            # reloaded around the event loop (BASELINE configs[3]: 43.6 -> 43.0 ms), never inside it
+            assert vgpr <= 96, f"{what}: {vgpr} vector registers (> 96: four waves per SIMD)"
+            assert not scratch_in_inner_loops(names[0]), f"{what}: register spills inside the event loop"
+            continue
         if "k_imc_cell" in key and "several sizes" not in what:
-            # four waves per SIMD (128 registers) without a spill: wave-uniform geometry, or fewer than three axes
+            # four waves per SIMD (128 registers) without a spill: wave-uniform geometry
             assert vgpr <= 128, f"{what}: {vgpr} vector registers (> 128: three waves per SIMD)"
         if "cell-local" in what and "hybrid" in what and "3-D" not in what:
             # The cell-local IMC phase of the hybrid kernel runs four waves per SIMD in 1-D / 2-D and the
