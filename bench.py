@@ -69,9 +69,23 @@ def make_deck(ngpus: int, particles_per_gpu: int, block_nx: int = 64, workload: 
             ov[f"parthenon/meshblock/nx{d + 1}"] = bnx
         return load_deck("stepdiff_ddmc", ov)
     if workload == "c4":     # stepdiff_smr.in as shipped: 2-D, 20 blocks of 32^2, 2 levels, pure IMC
-        return load_deck("stepdiff_smr", {"jaybenne/num_particles": particles_per_gpu * ngpus})
+        ov = {"jaybenne/num_particles": particles_per_gpu * ngpus}
+        # (development knob, tools/dev: JB_BENCH_C4_MESH="nx1,nx2,nx3,block_nx" runs the deck in 3-D)
+        if os.environ.get("JB_BENCH_C4_MESH"):
+            n1, n2, n3, bnx = (int(v) for v in os.environ["JB_BENCH_C4_MESH"].split(","))
+            for d, nd in enumerate((n1, n2, n3)):
+                ov[f"parthenon/mesh/nx{d + 1}"] = nd
+                ov[f"parthenon/meshblock/nx{d + 1}"] = bnx
+        return load_deck("stepdiff_smr", ov)
     if workload == "c5":     # stepdiff_smr_hybrid.in + a nested level-2 region
-        pin = load_deck("stepdiff_smr_hybrid", {"jaybenne/num_particles": particles_per_gpu * ngpus})
+        ov = {"jaybenne/num_particles": particles_per_gpu * ngpus}
+        # (development knob, tools/dev: JB_BENCH_C5_MESH="nx1,nx2,nx3,block_nx" runs the deck in 3-D)
+        if os.environ.get("JB_BENCH_C5_MESH"):
+            n1, n2, n3, bnx = (int(v) for v in os.environ["JB_BENCH_C5_MESH"].split(","))
+            for d, nd in enumerate((n1, n2, n3)):
+                ov[f"parthenon/mesh/nx{d + 1}"] = nd
+                ov[f"parthenon/meshblock/nx{d + 1}"] = bnx
+        pin = load_deck("stepdiff_smr_hybrid", ov)
         pin.load_string("<parthenon/static_refinement2>\nlevel = 2\nx1min = -0.125\nx1max = 0.125\n"
                         "x2min = -0.125\nx2max = 0.125\nx3min = -0.25\nx3max = 0.25\n")
         return pin

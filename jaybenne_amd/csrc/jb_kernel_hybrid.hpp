@@ -44,6 +44,9 @@ namespace jb {
 #ifndef JB_HYBRID_CELL_WAVES_PER_SIMD   // the cell-local IMC phase (MODE 3, PHASE 1) in 1-D / 2-D, see below
 #define JB_HYBRID_CELL_WAVES_PER_SIMD 4
 #endif
+#ifndef JB_HYBRID_CELL3D_WAVES_PER_SIMD   // ... in 3-D
+#define JB_HYBRID_CELL3D_WAVES_PER_SIMD 3
+#endif
 #ifndef JB_HYBRID_REMAINDER_WAVES_PER_SIMD
 #define JB_HYBRID_REMAINDER_WAVES_PER_SIMD 3
 #endif
@@ -100,7 +103,8 @@ __global__ void __launch_bounds__(kBlock, PHASE == 0 ? JB_HYBRID_REMAINDER_WAVES
                                           : ((PHASE == 1 && MODE == 0 && (NDIM == 3 || !NOABS)) ||
                                              (PHASE == 1 && NDIM == 3 && !NOABS)) ? 2
                                           : (PHASE == 1 && MODE == 3 && NDIM < 3) ? JB_HYBRID_CELL_WAVES_PER_SIMD
-                                                                                  : JB_HYBRID_WAVES_PER_SIMD)
+                                          : (PHASE == 1 && MODE == 3) ? JB_HYBRID_CELL3D_WAVES_PER_SIMD
+                                                                      : JB_HYBRID_WAVES_PER_SIMD)
     k_hybrid(const DevMesh *__restrict__, DevParams, DevSwarm, double, double, long long, long long,
              unsigned long long *, const unsigned *, unsigned *, unsigned long long *,
              const unsigned long long *) {

@@ -255,9 +255,13 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
             assert vgpr <= 96, f"{what}: {vgpr} vector registers (> 96: four waves per SIMD)"
             assert not scratch_in_inner_loops(names[0]), f"{what}: register spills inside the event loop"
             continue
-        if "k_imc_cell" in key and "several sizes" not in what:
-            # four waves per SIMD (128 registers) without a spill: wave-uniform geometry
+        if "k_imc_cell" in key:
+            # four waves per SIMD (128 registers): without a spill on wave-uniform geometry, with
+            # a few registers stored around the event loop on blocks of several sizes
             assert vgpr <= 128, f"{what}: {vgpr} vector registers (> 128: three waves per SIMD)"
+            if "several sizes" in what:
+                assert not scratch_in_inner_loops(names[0]), f"{what}: register spills inside the event loop"
+                continue
         if "cell-local" in what and "hybrid" in what and "3-D" not in what:
             # The cell-local IMC phase of the hybrid kernel runs four waves per SIMD in 1-D / 2-D and the
             # remainder launch three: the registers they give up are stored and reloaded AROUND the
