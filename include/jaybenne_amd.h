@@ -319,7 +319,9 @@ jb_status jb_defrag_particles(jb_context *ctx, jb_mesh *mesh, const jb_swarm_vie
  * at least 2^20 photons in the swarm.  A sort after which the next cycle is not at least 1 % faster
  * was not what the kernels needed: the minimum distance between sorts doubles (2, 4, .. 256 cycles)
  * until one pays
- * again.  Slot order only affects speed, never results; defrag_interval = 0 in the hosts keeps the
+ * again.  The sort's scratch records (128 bytes per photon) are allocated at the first call with
+ * at least 2^20 photons, not in the cycle that first sorts; jb_release_scratch returns them.
+ * Slot order only affects speed, never results; defrag_interval = 0 in the hosts keeps the
  * order of the reference (never sorted), k > 0 sorts after every k-th cycle.
  * The caller must have synchronised the stream since the cycle's last transport call.
  * mode: JB_DEFRAG_DECIDE_AND_SORT for a host that holds the whole swarm.  Several ranks sort

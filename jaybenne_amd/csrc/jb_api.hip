@@ -76,6 +76,7 @@ struct jb_context {
   int cycles_since_sort = 0;
   int min_interval = 2;              // cycles between two sorts (doubles when a sort bought nothing)
   int policy_sorts = 0;
+  bool sort_scratch_tried = false;   // the sort's scratch records have been asked for (first policy call)
 };
 constexpr int kTransportEventPairs = 64;
 constexpr int kCounterWords = 1024;  // CNT_N.. | 16..17 cursors | 32.. per-rank counts (<= 480 ranks)
@@ -1279,6 +1280,23 @@ extern "C" jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_s
     ctx->sort_timed = false;
   }
   if (!ok || events_this_cycle <= 0 || swarm->n < (1ll << 20)) return JB_COMPLETE;
+  // The sort's scratch records (128 bytes per photon; a fresh allocation costs ~30 ms per GB) are
+  // asked for at the FIRST call, not in the cycle that first sorts: a run pays for them at its start,
+  // and one that has no room for them learns so there (the schedule is then off, as below).
+  if (!ctx->sort_scratch_tried) {
+    ctx->sort_scratch_tried = true;
+    const DevMesh &M0 = mesh->dm;
+    const unsigned long long nbins0 = (unsigned long long)M0.nblocks * (unsigned long long)M0.ntot + 1ull;
+    const unsigned long long ntiles0 = (nbins0 + kScanTile - 1) / kScanTile;
+    if (swarm->n < (1ll << 32) && nbins0 < (1ull << 32)) {
+      const size_t words = (size_t)kSortRecWords * (size_t)swarm->n + (size_t)((nbins0 + ntiles0 + swarm->n) / 2 + 16);
+      if (ensure_scratch(ctx, words, /*slack=*/false) != JB_COMPLETE) {
+        fprintf(stderr, "jaybenne_amd: no room for the scratch records of DefragParticles (%s): the swarm stays unsorted\n", g_err);
+        (void)hipGetLastError();
+        ctx->min_interval = 256;
+      }
+    }
+  }
   const double rate = ms / (double)events_this_cycle;
   ++ctx->cycles_since_sort;
   if (ctx->cycles_since_sort == 1 && ctx->rate_before_sort > 0.0) {
