@@ -220,10 +220,12 @@ jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swa
  *     correctly rounded quotients, the reference's unfused position update -- and the particles
  *     come out bit-identical to it.
  *   JB_ARITH_LEAN (default): while a lane follows a photon it carries the unit direction v / c and
- *     the distance left to census c (t_end - t) instead of v and t, and -- on meshes with the exact
- *     geometry (jb_mesh_exact_geometry: power-of-two cell widths; every stepdiff deck) -- the
- *     position RELATIVE TO THE CENTRE OF ITS CELL instead of x, with the cell as one byte offset into
- *     the per-cell arrays (k_imc_cell); distance to a face as
+ *     the distance left to census c (t_end - t) instead of v and t, and the position RELATIVE TO
+ *     THE CENTRE OF ITS CELL instead of x, with the cell as one byte offset into the per-cell arrays
+ *     (k_imc_cell; any cell widths: only the conversion from and to the
+ *     swarm's coordinates, when a photon is loaded and written back, depends on them -- exact where
+ *     they are powers of two, jb_mesh_exact_geometry, an ulp of the position elsewhere; the
+ *     per-cell arrays of the resident blocks must lie within 4 GiB); distance to a face as
  *     (h - sgn(omega) p) / |omega| with a once-refined reciprocal of the direction component (within
  *     2^-48, ~20 ulp, of the correctly rounded quotient; in 3-D the three reciprocals come from one,
  *     of the product of the components, to the same accuracy), position update as one fused
@@ -231,9 +233,9 @@ jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swa
  *     1 - mu^2 with one residual correction (<= 2 ulp) -- every operation within 4e-15 (relative) of
  *     the exact variant's, the cell-local position carrying ~8 bits MORE than the absolute one the
  *     exact variant (and the reference) round at every event.  Both faces of an axis are tested for
- *     the nudge of transport_utils.hpp:151-159, as in the reference.  (Meshes without the exact
- *     geometry: the x-space form of round 3, which tests only the face ahead.)  ~40 % fewer
- *     instructions per event than the exact variant.
+ *     the nudge of transport_utils.hpp:151-159, as in the reference.  (More than 4 GiB of per-cell
+ *     arrays, or JB_NO_IMC_CELL=1: the x-space form of round 3, which tests only the face ahead.)
+ *     ~40 % fewer instructions per event than the exact variant.
  *     Stated tolerance (tests/test_gpu_lean.py, tests/test_gpu_accuracy.py):
  *       - after ONE full cycle every floating-point attribute of every photon is within 1e-9 of the
  *         exact variant's and of the oracle's (positions relative to the domain size, velocities to

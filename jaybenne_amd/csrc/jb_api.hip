@@ -91,6 +91,9 @@ struct jb_mesh {
   // every resident block: power-of-two cell widths, lower corner a whole number of them (the
   // cell-face arithmetic is then exact; k_transport<..., EXACT>)
   bool exact_geom = false;
+  // the mean-free-path arrays of all resident blocks lie within 4 GiB (32-bit byte offsets): what
+  // the cell-local IMC kernel needs of a mesh, whatever its cell widths
+  bool offsets32 = false;
   const char *last_variant = "";  // the k_transport instantiation launched last
   const char *last_pair = "";     // ... and the k_ddmc_all launched beside it (gray DDMC), or ""
   const DevMesh *dm_dev = nullptr;  // copy of dm in device memory (k_hybrid reads the view through it)
@@ -357,7 +360,8 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
     D.exact = exact ? 1 : 0;
     // (the EXACT tracking kernels also address the mean-free-path arrays of all resident blocks
     // with 32-bit byte offsets: 16 bytes per cell)
-    m->exact_geom = exact && 16ull * (unsigned long long)D.ntot * (unsigned long long)v->nblocks < (1ull << 32);
+    m->offsets32 = 16ull * (unsigned long long)D.ntot * (unsigned long long)v->nblocks < (1ull << 32);
+    m->exact_geom = exact && m->offsets32;
     m->uniform_geom = true;
     for (int b = 1; b < v->nblocks; ++b)
       for (int d = 0; d < 3; ++d) m->uniform_geom = m->uniform_geom && v->blk_dx[3 * b + d] == v->blk_dx[d];
@@ -468,7 +472,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
           if (!same || li >= (1 << 28)) continue;
           ent[6 * (size_t)b + f] = (kind << 28) | li;
           x0[6 * (size_t)b + f] = v->blk_xmin[3 * li + d] - (double)first[d] * v->blk_dx[3 * li + d];
-          if (m->exact_geom)  // (offsets below 4 GiB: the difference fits 32 bits, as a wrapping sum)
+          if (m->offsets32)  // (offsets below 4 GiB: the difference fits 32 bits, as a wrapping sum)
             dq[6 * (size_t)b + f] = (int32_t)(uint32_t)(16ll * D.ntot * ((long long)li - b) +
                                                         (up ? -stride8[d] : stride8[d]) * v->nx[d]);
         }
@@ -746,7 +750,10 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         else if (ctx->lean_arith) JB_LAUNCH_X(T, G, true, true);                                   \
         else JB_LAUNCH_X(T, G, true, false);                                                       \
       } else {                                                                                     \
-        if (ctx->lean_arith) JB_LAUNCH_X(T, G, false, true);                                       \
+        /* (the cell-local step does not care what the cell widths are: only its conversions to and \
+           from the swarm's coordinates round, by an ulp of the position) */                       \
+        if (ctx->lean_arith && !ctx->no_imc_cell && mesh->offsets32) JB_LAUNCH_CELL(T, (G == 2));  \
+        else if (ctx->lean_arith) JB_LAUNCH_X(T, G, false, true);                                  \
         else JB_LAUNCH_X(T, G, false, false);                                                      \
       }                                                                                            \
     } else {                                                                                       \

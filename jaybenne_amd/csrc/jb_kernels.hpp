@@ -123,8 +123,9 @@ __global__ void __launch_bounds__(kBlock) k_lam_ghost_codes(DevMesh M, const int
         dest = ent & 0x0fffffff;
         // (nbr_dq: in lam_sc's layout, 16 ntot bytes per block)
         dcell = (unsigned)q + (unsigned)((nbr_dq[6 * b + f] - 16 * (int)M.ntot * (dest - b)) / 8);
-      } else if (adjacent && M.exact) {
-        // a neighbour of another level?  centre of the ghost cell, through a periodic boundary if need be
+      } else if (adjacent) {
+        // a neighbour of another level?  (cell centres are half a cell from every face: the floors
+        // below hold on any geometry)  centre of the ghost cell, through a periodic boundary if need be
         double xg[3];
         bool inside = true;
         for (int d = 0; d < 3; ++d) {

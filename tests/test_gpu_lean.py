@@ -43,7 +43,13 @@ CASES = [
     ("stepdiff_smr", dict(SMR3D, **{"jaybenne/num_particles": 20000}), 1),             # pure IMC (k_imc_cell<3>)
     ("stepdiff_smr_hybrid", dict(SMR3D, **{"jaybenne/num_particles": 30000,
                                            "jaybenne/tau_ddmc": 20.0}), 1),            # coarse DDMC / fine IMC
-    # cell widths that are not powers of two: the lean step on general geometry
+    # cell widths that are not powers of two: the cell-local step does not care (only its conversions
+    # to and from the swarm's coordinates round) -- uniform 3-D, and level changes in 2-D and 3-D SMR
+    ("stepdiff_smr", {"parthenon/mesh/nx1": 60, "parthenon/mesh/nx2": 30, "parthenon/meshblock/nx1": 15,
+                      "parthenon/meshblock/nx2": 15, "jaybenne/num_particles": 8000}, 1),
+    ("stepdiff_smr", {"parthenon/mesh/nx1": 24, "parthenon/mesh/nx2": 12, "parthenon/mesh/nx3": 12,
+                      "parthenon/meshblock/nx1": 6, "parthenon/meshblock/nx2": 6, "parthenon/meshblock/nx3": 6,
+                      "jaybenne/num_particles": 20000}, 1),
     ("stepdiff", {"parthenon/mesh/nx1": 24, "parthenon/mesh/nx2": 12, "parthenon/mesh/nx3": 12,
                   "parthenon/meshblock/nx1": 12, "parthenon/meshblock/nx2": 6,
                   "parthenon/meshblock/nx3": 6, "jaybenne/num_particles": 4000}, 1),
