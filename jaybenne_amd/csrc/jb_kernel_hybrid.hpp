@@ -47,6 +47,9 @@ namespace jb {
 #ifndef JB_HYBRID_CELL3D_WAVES_PER_SIMD   // ... in 3-D
 #define JB_HYBRID_CELL3D_WAVES_PER_SIMD 3
 #endif
+#ifndef JB_HYBRID_XLEAN_WAVES_PER_SIMD    // the x-space lean IMC phase (MODE 1 / 2) in 1-D / 2-D
+#define JB_HYBRID_XLEAN_WAVES_PER_SIMD 4
+#endif
 #ifndef JB_HYBRID_REMAINDER_WAVES_PER_SIMD
 #define JB_HYBRID_REMAINDER_WAVES_PER_SIMD 3
 #endif
@@ -98,12 +101,14 @@ template <int NDIM, bool TALLY, bool NOABS, int MODE, int PHASE>
 // configurations; the stepdiff decks run none of them).
 // Round 4: the cell-local IMC phase in 1-D / 2-D runs FOUR waves per SIMD: 128 registers cost it
 // 4 - 18 dwords of scratch, all of them stored and reloaded around the event loops (none inside:
-// tests/test_cabi.py), and the loop is bound by instruction issue -- BASELINE configs[4] 60.1 -> 57.0 ms.
+// tests/test_cabi.py), and the loop is bound by instruction issue -- BASELINE configs[4] 60.1 -> 57.0 ms;
+// the x-space lean IMC phase (general geometry, MODE 1; JB_NO_IMC_CELL=1, MODE 2) likewise: 79.5 -> 73.1 ms.
 __global__ void __launch_bounds__(kBlock, PHASE == 0 ? JB_HYBRID_REMAINDER_WAVES_PER_SIMD
                                           : ((PHASE == 1 && MODE == 0 && (NDIM == 3 || !NOABS)) ||
                                              (PHASE == 1 && NDIM == 3 && !NOABS)) ? 2
                                           : (PHASE == 1 && MODE == 3 && NDIM < 3) ? JB_HYBRID_CELL_WAVES_PER_SIMD
                                           : (PHASE == 1 && MODE == 3) ? JB_HYBRID_CELL3D_WAVES_PER_SIMD
+                                          : (PHASE == 1 && NDIM < 3 && MODE != 0) ? JB_HYBRID_XLEAN_WAVES_PER_SIMD
                                                                       : JB_HYBRID_WAVES_PER_SIMD)
     k_hybrid(const DevMesh *__restrict__, DevParams, DevSwarm, double, double, long long, long long,
              unsigned long long *, const unsigned *, unsigned *, unsigned long long *,
