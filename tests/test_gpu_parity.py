@@ -151,6 +151,34 @@ def test_step_functions_bit_exact(ctx):
     assert len(seen) >= 9         # the cases really do spread over the branches
 
 
+def test_hand_written_step_vectors_on_the_device(ctx):
+    """tests/golden/hand_step_vectors.json (worked out on paper from the reference's text) and SURVEY.md
+    Appendix D's vector (computed by the reference's own header) through the device's step functions --
+    pins that do not come from the oracle (tests/test_oracle_steps.py holds the oracle to the same file)."""
+    from jaybenne_amd import _lib
+    from test_oracle_steps import check_hand_case, hand_vectors
+    which = {"transport": 0, "ddmc": 1, "albedo": 2}
+    cases, app_d = hand_vectors()
+
+    def run(kind, d, tape):
+        sd = _lib.DebugStep()
+        for k, v in d.items():
+            setattr(sd, k, v)
+        tp = np.ascontiguousarray(tape, dtype=np.float64)
+        nd = C.c_int(0)
+        _lib.check(ctx.lib.jb_debug_step_call(ctx.ctx, which[kind], C.byref(sd), tp.ctypes.data, tp.size,
+                                              C.byref(nd)))
+        return sd, nd.value
+
+    for name, kind, d, tape, ndraws, exact, close in cases:
+        sd, n = run(kind, d, tape)
+        check_hand_case(name, sd, n, ndraws, exact, close)
+    sd, n = run(app_d["kind"], app_d["in"], app_d["tape"])
+    assert n == app_d["ndraws"]
+    for k, v in app_d["expect"].items():
+        assert getattr(sd, k) == v, (k, getattr(sd, k), v)
+
+
 def test_sampling_functions_bit_exact(ctx):
     from jaybenne_amd import _lib
     from oracle import orc

@@ -154,3 +154,67 @@ def test_block_face_resampling_helpers():
     assert (i, n) == (8, 2) and x == 0.25 + 0.01 * 0.5
     ij, x12, n = orc.call_face_3d(3, 9, 0.01, 0.02, [0.1, 0.2, 0.3, 0.4], [0.25, 0.5, 0.5], [0, 0], [0.5, -0.25])
     assert n == 3 and ij == [4, 9] and x12[0] == 0.5 + 0.005 and x12[1] == -0.25 - 0.01
+
+
+# ------------------------------------------------------------------------------------------------
+# Vectors the oracle did NOT write: tests/golden/hand_step_vectors.json is worked
+# out on paper from the reference's text (dyadic inputs, closed-form results), and carries the one
+# vector that came out of the reference's own headers.
+def hand_vectors():
+    import math
+    doc = json.load(open(os.path.join(HERE, "golden", "hand_step_vectors.json")))
+    names = {"eps_imc": 1e7 * 2.0 ** -52, "eps_ddmc": 1e9 * 2.0 ** -52,
+             "ln2": float.fromhex("0x1.62e42fefa39efp-1"), "sqrt": math.sqrt}
+    assert names["eps_imc"] == 1.0e6 * (10.0 * np.finfo(float).eps)       # transport_utils.hpp:24
+    assert names["eps_ddmc"] == 1.0e8 * (10.0 * np.finfo(float).eps)      # :25
+
+    def val(v):
+        return eval(v, {"__builtins__": {}}, names) if isinstance(v, str) else v
+
+    out = []
+    for c in doc["cases"]:
+        d = dict(doc["ddmc_common"])
+        d.update({k: val(v) for k, v in c["in"].items()})
+        exact = {k: val(v) for k, v in c.get("exact", {}).items()}
+        close = {k: (val(v[0]), float(v[1])) for k, v in c.get("close", {}).items()}
+        out.append((c["name"], c["kind"], d, c["tape"], c["ndraws"], exact, close))
+    return out, doc["survey_appendix_d"]
+
+
+def check_hand_case(name, got, ndraws, want_draws, exact, close):
+    assert ndraws == want_draws, (name, ndraws)
+    for k, v in exact.items():
+        assert getattr(got, k) == v, (name, k, getattr(got, k), v)
+    for k, (v, tol) in close.items():
+        assert abs(getattr(got, k) - v) <= tol, (name, k, getattr(got, k), v)
+
+
+@pytest.mark.parametrize("mode", [orc.MATH_LIBM, orc.MATH_PORTABLE])
+def test_hand_written_step_vectors(mode):
+    orc.set_math_mode(mode)
+    cases, _ = hand_vectors()
+    kinds = set()
+    for name, kind, d, tape, ndraws, exact, close in cases:
+        st = orc.Step()
+        for k, v in d.items():
+            setattr(st, k, v)
+        n = orc.call_step(kind, st, tape)
+        check_hand_case(name, st, n, ndraws, exact, close)
+        kinds.add((kind, ndraws))
+    assert len(cases) >= 20 and len(kinds) >= 7
+
+
+@pytest.mark.parametrize("mode", [orc.MATH_LIBM, orc.MATH_PORTABLE])
+def test_survey_appendix_d_vector_from_the_reference_headers(mode):
+    """ptcl_transport_step of the reference (transport_utils.hpp:111-160, compiled by
+    the survey from the reference's own header) on tape {0.3, 0.7, ...} gave a scatter at
+    t = 1.1897395495477489e-14, x = -0.49728599503363674 after two draws."""
+    orc.set_math_mode(mode)
+    _, app_d = hand_vectors()
+    assert app_d["in"]["vx"] == 0.6 * C and app_d["in"]["vy"] == 0.8 * C
+    st = orc.Step()
+    for k, v in app_d["in"].items():
+        setattr(st, k, v)
+    assert orc.call_step(app_d["kind"], st, app_d["tape"]) == app_d["ndraws"]
+    for k, v in app_d["expect"].items():
+        assert getattr(st, k) == v, (k, getattr(st, k), v)

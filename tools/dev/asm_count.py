@@ -5,7 +5,8 @@ import re, sys, collections
 src = open(sys.argv[1]).read().split("\n")
 pat = sys.argv[2]
 start = next(i for i, l in enumerate(src) if l.startswith("_ZN") and pat in l and re.match(r"^_ZN\S+:", l))
-end = next(i for i in range(start, len(src)) if src[i].strip().startswith("s_endpgm"))
+# (a kernel may hold several s_endpgm -- early returns: count up to the end-of-function label)
+end = next(i for i in range(start, len(src)) if src[i].startswith(".Lfunc_end"))
 blocks = collections.OrderedDict()
 cur = "entry"
 blocks[cur] = collections.Counter()
