@@ -87,3 +87,41 @@ def test_three_level_deck_is_the_bench_workload():
     assert mesh.nblocks == len(case["blocks"]) == 32
     assert np.array_equal(mesh.blk_level, np.array([b[0] for b in case["blocks"]]))
     assert np.array_equal(mesh.blk_lloc[:, :2], np.array([b[1:] for b in case["blocks"]]))
+
+
+def test_uniform_3d_periodic_mesh_matches_the_listed_neighbour_table():
+    """BASELINE configs[1]'s mesh (4 x 4 x 4 blocks of 64^3, periodic in x2 / x3): block order, logical
+    locations, the leaf map and the destination block behind every face against
+    tests/golden/c2_block_neighbours.json, a table built from the deck's geometry alone
+    (tests/golden/make_c2_neighbours.py imports nothing of this package)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    tab = json.load(open(os.path.join(os.path.dirname(FIXTURE), "c2_block_neighbours.json")))
+    mesh = Mesh.from_deck(bench.make_deck(1, 1000, workload="c2"))
+    assert mesh.nblocks == 64 and mesh.ndim == 3 and list(mesh.nx) == [64, 64, 64]
+    ext = np.array(tab["block_extent"])
+    gmin = np.array(tab["domain_min"])
+    for b, ent in enumerate(tab["blocks"]):
+        lloc = np.array(ent["lloc"])
+        assert np.array_equal(mesh.blk_lloc[b], lloc) and mesh.blk_level[b] == 0
+        assert np.array_equal(mesh.blk_xmin[b], gmin + lloc * ext)
+        assert np.array_equal(mesh.blk_xmax[b], gmin + (lloc + 1) * ext)
+        assert mesh.leaf_map[lloc[2], lloc[1], lloc[0]] == b
+        # where a photon that has just crossed a face is handed to: a point a quarter of a cell beyond it
+        # (wrapped where the boundary is periodic), through the package's own destination look-up
+        ctr = gmin + (lloc + 0.5) * ext
+        for f, want in enumerate(ent["faces"]):
+            d, up = f >> 1, f & 1
+            p = ctr.copy()
+            p[d] = (gmin[d] + (lloc[d] + up) * ext[d]) + (0.25 / 256) * (1 if up else -1)
+            if p[d] < gmin[d] or p[d] > gmin[d] + 4 * ext[d]:
+                if want < 0:
+                    assert d == 0
+                    continue
+                p[d] += 4 * ext[d] * (1 if p[d] < gmin[d] else -1)
+            assert want >= 0 and mesh.find_block(p[None, :])[0] == want, (b, f)
+    # every neighbour relation is mutual, and Mesh.neighbours (the halo copies of a rank) agrees with the
+    # table's faces plus edges and corners: 26 distinct blocks around an interior block
+    assert set(int(g) for g in mesh.neighbours([21])) >= {g for g in tab["blocks"][21]["faces"] if g >= 0}
+    assert len(mesh.neighbours([21])) == 26
