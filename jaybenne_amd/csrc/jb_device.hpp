@@ -56,6 +56,9 @@ struct DevMesh {
   // IMC steps (dx_push (sigma_a + sigma_s) <= tau_ddmc, transport_ddmc.cpp:135); 0 = every step
   // of every particle is a DDMC step (k_ddmc_all)
   int *not_all_ddmc;
+  // 1.0 / ntot, 1.0 / (ni nj), 1.0 / ni (host): k_ddmc_all turns a record number back into block and
+  // cell indices with them (floor(x / d) as a product and one correction)
+  double inv_ntot, inv_nij, inv_ni;
 };
 
 struct DevParams {
@@ -276,12 +279,12 @@ __device__ __forceinline__ unsigned sgpr_copy(unsigned v) {
 }
 // a wave-uniform double in a scalar register pair of its own
 __device__ __forceinline__ double uniform_f64(double v) {
+  // (two 32-bit copies: the 64-bit "s" operand of a single s_mov_b64 is sometimes handed over in a
+  // vector register pair, which the assembler rejects)
   const unsigned long long q = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(q >> 32));
-  unsigned long long r;
-  asm volatile("s_mov_b64 %0, %1" : "=s"(r) : "s"(((unsigned long long)hi << 32) | lo));
-  return __longlong_as_double((long long)r);
+  const unsigned lo = sgpr_copy((unsigned)q);
+  const unsigned hi = sgpr_copy((unsigned)(q >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 __device__ __forceinline__ const double *sgpr_copy_ptr(const double *p) {
   const unsigned long long q = (unsigned long long)p;

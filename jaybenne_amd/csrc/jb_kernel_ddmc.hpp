@@ -45,7 +45,39 @@ namespace jb {
 #define JB_DDMC_ALL_WINDOW 1
 #endif
 
-enum { DS_IDLE = 0, DS_VIRT = 1, DS_PARK = 2, DS_DONE = 3, DS_RELOC = 4 };
+// (DS_ABS / DS_CENSUS: how a lane left the event loop -- absorbed / at census without an event in its last
+// step: turned into DS_DONE, with the bookkeeping that goes with it, right behind the loop)
+enum { DS_IDLE = 0, DS_VIRT = 1, DS_PARK = 2, DS_DONE = 3, DS_RELOC = 4, DS_ABS = 5, DS_CENSUS = 6 };
+// Ghost cells of the STEP records (DevMesh::ddmc_step; written once per mesh by k_lam_ghost_codes, the
+// per-cycle k_ddmc_pack only writes interior cells): the last double -- in a real cell the positive
+// reciprocal of c (f sigma_a + leak_tot + DBL_MIN) -- is negative there, its high word
+// 0x80000000 | flags, and with kStepGhostTable its low word is the RECORD NUMBER of the cell a particle
+// that leaks into this ghost cell really is in: the first / last interior cell along the axis of the
+// same-size resident neighbour or of the block across a periodic boundary, or the cell it came from at
+// a reflecting wall (more than one dimension: in 1-D the direction travels and has to be mirrored).
+// Without the flag (level changes, destinations that are not resident, outflow): the general relocation.
+constexpr int kStepGhostTable = 1;
+constexpr int kPdZero = 0x40000000;  // pd: the zero-velocity flag of a multi-D leak across a block face
+
+// The swarm is a stream: every particle attribute is read once and written once per launch.  Where the
+// event loop gathers its records through L2 (GATHER 0 / 1 / 3) these accesses carry the non-temporal
+// hint, so that they do not push the cell records -- which ARE re-read, by every step -- out of the XCD's
+// L2: BASELINE configs[2] in 3-D 28.1 -> 26.9 ms (A/B on one box; 5 % of the record requests miss L2 and
+// nearly every 64-lane pass waits for one of them).  With the records in LDS (GATHER 2) there is
+// nothing to protect and the hint costs 11 %.  JB_DDMC_NT=0 switches it off.
+#ifndef JB_DDMC_NT
+#define JB_DDMC_NT 1
+#endif
+template <bool NT, class T>
+__device__ __forceinline__ T swarm_ld(const T *p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT, class T, class V>
+__device__ __forceinline__ void swarm_st(T *p, V v) {
+  if constexpr (NT) __builtin_nontemporal_store((T)v, p);
+  else *p = (T)v;
+}
 
 // the kernel's argument list as the kernel-argument segment holds it (natural alignment, in order)
 struct DdmcAllArgs {
@@ -99,6 +131,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   const long long first = A.first, last = A.last;
   unsigned long long *const counters = g1(A.counters);
   constexpr bool COOP = GATHER == 1 || GATHER == 3;   // (3: COOP with 64-bit addresses, records >= 4 GiB)
+  constexpr bool NT = GATHER != 2 && JB_DDMC_NT != 0;  // non-temporal swarm accesses (see swarm_ld)
   // PF (records in LDS: the event loop issues no vector-memory load, so one requested before it is
   // not waited for until it is needed -- the counter of outstanding loads completes in order):
   // the wave keeps a WINDOW of the next 64 slots of the swarm it will hand to its lanes, requested
@@ -151,16 +184,24 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0;
   unsigned long long c_ev = 0;
   unsigned int c_pass = 0, c_service = 0;
+  unsigned long long c_ghost = 0;   // lane-passes spent on a ghost record (counted in c_ev, taken off at the end)
 
-  // ---- lane state that lives across the event loop ("virtual" particle)
+  // ---- lane state that lives across the event loop ("virtual" particle): slot, stream state, time,
+  //      the RECORD NUMBER of its cell (block * cells per block + cell: what the step gathers with, and
+  //      what a leak moves by +-1, +-ni, +-ni nj), the pending leak and the stream state in front of it
   int ls = DS_IDLE;
   long long n = 0;
   LcgRng rng(0);
-  int b = 0, ip = 0, jp = 0, kp = 0;
+  unsigned rec = 0u;
   double t = 0.0;
-  // channel of the last leak (0..5) while its direction is deferred; -1: the direction is the one
-  // in vx, vy, vz (real_pos) or, for a lane in the loop, the one in S.vx, vy, vz [n]; -2: zero,
-  // the flag a multi-D DDMC leak across a block face leaves behind (transport_ddmc.cpp:203-211)
+  // pd: the record-number step of the last leak while its direction is deferred (+-1 / +-ni / +-ni nj:
+  // channel x-, x+, y-, y+, z-, z+); 0: none -- the direction is the one in S.vx, vy, vz [n];
+  // kPdZero: zero, the flag a multi-D DDMC leak across a block face leaves behind
+  // (transport_ddmc.cpp:203-211)
+  int pd = 0;
+  // ---- ... and what exists between two event loops only (decoded from rec / pd behind the loop):
+  // block, cell indices, and the leak as channel 0..5 / -1 none / -2 zero-velocity flag
+  int b = 0, ip = 0, jp = 0, kp = 0;
   int pend = -1;
   // ... kept as the stream state right before them: the loop only steps the stream past the two
   // draws (one multiply-add by the two-step constants instead of two draws with their conversions)
@@ -200,6 +241,17 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   const int l_js = (int)sgpr_copy((unsigned)M.js), l_je = (int)sgpr_copy((unsigned)M.je);
   const int l_ks = (int)sgpr_copy((unsigned)M.ks), l_ke = (int)sgpr_copy((unsigned)M.ke);
   auto cidx_l = [&](int k, int j, int i) { return __mul24(__mul24(k, l_nj) + j, l_ni) + i; };
+  // record-number strides of the three axes (and their reciprocals, for the decode behind the loop)
+  const int l_nij = (int)sgpr_copy((unsigned)(M.ni * M.nj));
+  const double inv_ntot = M.inv_ntot, inv_nij = M.inv_nij, inv_ni = M.inv_ni;   // (jb_mesh_create)
+  // floor(x / d) for x < 2^32 with inv = 1.0 / d: the product is within 2^-20 of the quotient, so the
+  // truncation is the floor or one below it (an exact multiple of d seen from below)
+  auto udiv = [](unsigned x, unsigned d, double inv, unsigned &rem) {
+    unsigned q = (unsigned)((double)x * inv);
+    rem = x - q * d;
+    if (rem >= d) { ++q; rem -= d; }
+    return q;
+  };
   // (the index along an inactive axis is the block's first there and never moves: Xtoijk, the step)
   auto on_block_l = [&](int i, int j, int k) {
     bool on = i >= l_is && i <= l_ie;
@@ -231,12 +283,13 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     Step s;
     faces_of(s, Bq, ip, jp, kp);
     s.x = x; s.y = y; s.z = z;
-    if (at_cell_face<NDIM>(s)) {
-      ls = DS_PARK;
-    } else {
-      real_pos = false;
-      ls = DS_VIRT;
-    }
+    // (selects: stores to different variables in the two arms of a branch are merged into one store through
+    // a selected address, and those variables then live in scratch memory)
+    const bool face = at_cell_face<NDIM>(s);
+    ls = face ? DS_PARK : DS_VIRT;
+    real_pos = face && real_pos;
+    rec = face ? rec : (unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip);
+    pd = face ? pd : 0;   // (pend is -1 wherever a particle enters: just loaded, or relocated)
   };
 
 #ifdef JB_TIMING
@@ -314,7 +367,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           if (t < t_end) {
             enter(Bn);
             if (ls == DS_VIRT) {  // (the loop does not carry the direction: park it)
-              g1(S.vx)[n] = vx; g1(S.vy)[n] = vy; g1(S.vz)[n] = vz;
+              swarm_st<NT>(&g1(S.vx)[n], vx); swarm_st<NT>(&g1(S.vy)[n], vy); swarm_st<NT>(&g1(S.vz)[n], vz);
             }
           } else {
             ls = DS_DONE;
@@ -369,11 +422,11 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         const bool mine = ((need >> lane) & 1ull) != 0ull && rank < give;
         if (mine) {
           cand = chunk_pos + rank;
-          st_in = g1(S.status)[cand];
-          rng_in = g1(S.rng)[cand];
-          b_in = g1(S.blk)[cand];
-          t_in = g1(S.t)[cand]; x_in = g1(S.x)[cand]; y_in = g1(S.y)[cand]; z_in = g1(S.z)[cand];
-          vx_in = g1(S.vx)[cand]; vy_in = g1(S.vy)[cand]; vz_in = g1(S.vz)[cand];
+          st_in = swarm_ld<NT>(&g1(S.status)[cand]);
+          rng_in = swarm_ld<NT>(&g1(S.rng)[cand]);
+          b_in = swarm_ld<NT>(&g1(S.blk)[cand]);
+          t_in = swarm_ld<NT>(&g1(S.t)[cand]); x_in = swarm_ld<NT>(&g1(S.x)[cand]); y_in = swarm_ld<NT>(&g1(S.y)[cand]); z_in = swarm_ld<NT>(&g1(S.z)[cand]);
+          vx_in = swarm_ld<NT>(&g1(S.vx)[cand]); vy_in = swarm_ld<NT>(&g1(S.vy)[cand]); vz_in = swarm_ld<NT>(&g1(S.vz)[cand]);
         }
         chunk_pos += give;
         need &= ~__ballot(mine);
@@ -421,21 +474,21 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           if constexpr (TALLY) {  // jaybenne.cpp:547-561
             const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
             // (the weight is read here, once per history, rather than carried through the event loop)
-            const double wgt = PF ? wgt_l : g1(S.w)[n];
+            const double wgt = PF ? wgt_l : swarm_ld<NT>(&g1(S.w)[n]);
             if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
             else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], wgt / dv);
           }
         }
       }
-      g1(S.blk)[n] = b;
-      g1(S.t)[n] = t;
-      g1(S.x)[n] = x; g1(S.y)[n] = y; g1(S.z)[n] = z;
+      swarm_st<NT>(&g1(S.blk)[n], b);
+      swarm_st<NT>(&g1(S.t)[n], t);
+      swarm_st<NT>(&g1(S.x)[n], x); swarm_st<NT>(&g1(S.y)[n], y); swarm_st<NT>(&g1(S.z)[n], z);
       if (write_v) {
-        g1(S.vx)[n] = vx; g1(S.vy)[n] = vy; g1(S.vz)[n] = vz;
+        swarm_st<NT>(&g1(S.vx)[n], vx); swarm_st<NT>(&g1(S.vy)[n], vy); swarm_st<NT>(&g1(S.vz)[n], vz);
       }
-      g1(S.ip)[n] = ip; g1(S.jp)[n] = jp; g1(S.kp)[n] = kp;
-      g1(S.status)[n] = status;
-      g1(S.rng)[n] = rng.s;
+      swarm_st<NT>(&g1(S.ip)[n], ip); swarm_st<NT>(&g1(S.jp)[n], jp); swarm_st<NT>(&g1(S.kp)[n], kp);
+      swarm_st<NT>(&g1(S.status)[n], status);
+      swarm_st<NT>(&g1(S.rng)[n], rng.s);
       resample = false;
       ls = DS_IDLE;
     }
@@ -460,7 +513,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       if (pf_mine) {
         cand = c;
         // (the weight is not part of the window: asked for now, read when the history ends)
-        wgt_l = g1(S.w)[c];
+        wgt_l = swarm_ld<NT>(&g1(S.w)[c]);
       }
       win_head = (win_head + pf_give) & 63;
       win_count -= pf_give;
@@ -503,12 +556,12 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         if (pos < got) {
           const long long q = pos < seg_n[0] ? seg_first[0] + pos : seg_first[1] + (pos - seg_n[0]);
           pf_slot = q;
-          pf_st = g1(S.status)[q];
-          pf_rng = g1(S.rng)[q];
-          pf_b = g1(S.blk)[q];
-          pf_t = g1(S.t)[q];
-          pf_x = g1(S.x)[q]; pf_y = g1(S.y)[q]; pf_z = g1(S.z)[q];
-          pf_vx = g1(S.vx)[q]; pf_vy = g1(S.vy)[q]; pf_vz = g1(S.vz)[q];
+          pf_st = swarm_ld<NT>(&g1(S.status)[q]);
+          pf_rng = swarm_ld<NT>(&g1(S.rng)[q]);
+          pf_b = swarm_ld<NT>(&g1(S.blk)[q]);
+          pf_t = swarm_ld<NT>(&g1(S.t)[q]);
+          pf_x = swarm_ld<NT>(&g1(S.x)[q]); pf_y = swarm_ld<NT>(&g1(S.y)[q]); pf_z = swarm_ld<NT>(&g1(S.z)[q]);
+          pf_vx = swarm_ld<NT>(&g1(S.vx)[q]); pf_vy = swarm_ld<NT>(&g1(S.vy)[q]); pf_vz = swarm_ld<NT>(&g1(S.vz)[q]);
         }
         win_count += got;
       }
@@ -535,11 +588,11 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     //       over to k_hybrid as it stands
     if (ls == DS_PARK) {
       if (!fresh) {
-        g1(S.blk)[n] = b;
-        g1(S.t)[n] = t;
-        g1(S.x)[n] = x; g1(S.y)[n] = y; g1(S.z)[n] = z;
-        g1(S.vx)[n] = vx; g1(S.vy)[n] = vy; g1(S.vz)[n] = vz;
-        g1(S.rng)[n] = rng.s;
+        swarm_st<NT>(&g1(S.blk)[n], b);
+        swarm_st<NT>(&g1(S.t)[n], t);
+        swarm_st<NT>(&g1(S.x)[n], x); swarm_st<NT>(&g1(S.y)[n], y); swarm_st<NT>(&g1(S.z)[n], z);
+        swarm_st<NT>(&g1(S.vx)[n], vx); swarm_st<NT>(&g1(S.vy)[n], vy); swarm_st<NT>(&g1(S.vz)[n], vz);
+        swarm_st<NT>(&g1(S.rng)[n], rng.s);
       }
       const unsigned long long pm = __ballot(true);
       const int leader = __ffsll((long long)pm) - 1;
@@ -567,98 +620,151 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
 #endif
     int thresh = 1;
     int nrun = running;
+    // One DDMC step per running lane and pass (transport_utils.hpp:163-263 on the virtual state), as
+    // straight-line code: the three stream states a step can end in (no event: one draw; an event that
+    // is no leak: two; a leak: four -- its two direction uniforms stay deferred) are formed side by
+    // side from the state the step starts in, the channel walk of :218-254 selects the record-number
+    // step of the leak, and the outcome is committed through selects.  "Has the particle left its
+    // block?" is read off the record the next pass gathers anyway (kStepGhostTable above).
+    constexpr unsigned long long kMul2 = kLcgMul * kLcgMul, kInc2 = (kLcgMul + 1ull) * kLcgInc;
+    constexpr unsigned long long kMul4 = kMul2 * kMul2, kInc4 = (kMul2 + 1ull) * kInc2;
     while (nrun >= thresh) {
       ++c_pass;
       c_ev += (unsigned int)nrun;
+      const bool run = ls == DS_VIRT;
+      // (every lane takes part in the gather; one without a particle in the loop asks for record 0)
+      const unsigned rq = run ? rec : 0u;
       if constexpr (COOP) {
-        // (every lane takes part; one without a particle in the loop asks for record 0)
-        const unsigned rec = ls == DS_VIRT ? (unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip) : 0u;
         typedef const __attribute__((address_space(1))) void *gvoid;
         if constexpr (!coop_wide) {  // the records span < 4 GiB: 32-bit byte offsets from a scalar base
-          const unsigned off = rec << 6;
+          const unsigned off = rq << 6;
           __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<0>(off, sub16)), wave_buf, 16, 0, 0);
           __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<1>(off, sub16)), wave_buf + 1024, 16, 0, 0);
           __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<2>(off, sub16)), wave_buf + 2048, 16, 0, 0);
           __builtin_amdgcn_global_load_lds((gvoid)((const char *)step_base + quad_bcast_add<3>(off, sub16)), wave_buf + 3072, 16, 0, 0);
         } else {           // ... or more (> 67e6 resident cells): the record number travels, 64-bit addresses
           const char *const mine = (const char *)step_base + sub16;
-          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<0>(rec, 0u) << 6)), wave_buf, 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<1>(rec, 0u) << 6)), wave_buf + 1024, 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<2>(rec, 0u) << 6)), wave_buf + 2048, 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<3>(rec, 0u) << 6)), wave_buf + 3072, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<0>(rq, 0u) << 6)), wave_buf, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<1>(rq, 0u) << 6)), wave_buf + 1024, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<2>(rq, 0u) << 6)), wave_buf + 2048, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gvoid)(mine + ((unsigned long long)quad_bcast_add<3>(rq, 0u) << 6)), wave_buf + 3072, 16, 0, 0);
         }
       }
-      if (ls == DS_VIRT) {
-        DdmcStepRec r;
-        double nlog;
-        if constexpr (COOP) {
-          nlog = -m_log(rng.drand());          // (the step's first draw, while the record is on its way)
-          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the four pieces have landed
-          const v4d r0 = my_rec[0];
-          const v4d r1 = my_rec[1];
-          r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
-          r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
-        } else if constexpr (GATHER == 2) {
-          const v4d *rec = (const v4d *)(lds_rec_tab + 8u * ((unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip)));
-          const v4d r0 = rec[0];
-          const v4d r1 = rec[1];
-          nlog = -m_log(rng.drand());
-          r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
-          r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
-        } else {
-          typedef const v4d __attribute__((address_space(1))) *grec;
-          const grec rec = (grec)((gcptr)step_base +
-                                  8 * ((unsigned long long)(unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip)));
-          const v4d r0 = rec[0];
-          const v4d r1 = rec[1];
-          nlog = -m_log(rng.drand());
-          r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
-          r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
-        }
-        bool is_absorbed = false;
-        const bool census = ddmc_step_rec<NDIM>(r, vv, t_end - t, nlog, rng, t, ip, jp, kp, pend, pzs,
-                                                is_absorbed);
-        // (ip, jp, kp = Xtoijk of the position the step gives: see the header)
-        resample = census;
-        if (!on_block_l(ip, jp, kp)) {
-          // A leak through a block face (0.4 per history on BASELINE configs[2]).  Into a resident
-          // block of the same size -- directly or through a periodic boundary -- nothing happens
-          // to the particle beyond the new block and cell: SampleDDMCBlockFace only acts on an
-          // arrival from a COARSER block (it looks for x_min + 2 eps_ddmc dx, a same-size leak
-          // lands at x_min + eps_ddmc dx: sample_ddmc_bface.cpp:158-165), Xtoijk gives the first
-          // or last cell along the axis, and in more than one dimension the direction is zeroed
-          // (transport_ddmc.cpp:203-211).  Everything else goes through the service phase.
-          const int axis = pend >> 1;
-          const bool up = (pend & 1) != 0;
-          const int ent = lds_blocks.nbr_ent[b][pend];
-          // (a reflecting boundary puts the particle back into the cell it left, eps_ddmc dx
-          // inside the wall; in 1-D its direction would have to be mirrored: service phase)
-          if (ent >= 0 && (multi_d || (ent >> 28) != 2)) {
-            const bool at_first = ((ent >> 28) == 2) != up;
-            b = ent & 0x0fffffff;
-            if (axis == 0) ip = at_first ? l_is : l_ie;
-            else if (axis == 1) jp = at_first ? l_js : l_je;
-            else kp = at_first ? l_ks : l_ke;
-            if constexpr (multi_d) pend = -2;
-            if (!(t < t_end)) ls = DS_DONE;
-          } else {
-            ls = DS_RELOC;
-          }
-        } else if (is_absorbed) {  // transport.cpp:157-163
-          if (lds_blocks.owned[b] != 0) {
-            atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], PF ? wgt_l : g1(S.w)[n]);
-            status = ST_ABSORBED;
-          } else {
-            status = ST_OUTGOING_ABSORBED;
-          }
-          ls = DS_DONE;
-        } else if (!(t < t_end)) {  // census
-          ls = DS_DONE;
-        }
+      const unsigned long long s0 = rng.s;
+      const unsigned long long s1 = s0 * kLcgMul + kLcgInc;
+      DdmcStepRec r;
+      double nlog;
+      if constexpr (COOP) {
+        nlog = -m_log(u52_to_double(s1 >> 12));  // (the step's first draw, while the record is on its way)
+        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the four pieces have landed
+        const v4d r0 = my_rec[0];
+        const v4d r1 = my_rec[1];
+        r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
+        r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
+      } else if constexpr (GATHER == 2) {
+        const v4d *rp = (const v4d *)(lds_rec_tab + 8u * rq);
+        const v4d r0 = rp[0];
+        const v4d r1 = rp[1];
+        nlog = -m_log(u52_to_double(s1 >> 12));
+        r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
+        r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
+      } else {
+        typedef const v4d __attribute__((address_space(1))) *grec;
+        const grec rp = (grec)((gcptr)step_base + 8ull * (unsigned long long)rq);
+        const v4d r0 = rp[0];
+        const v4d r1 = rp[1];
+        nlog = -m_log(u52_to_double(s1 >> 12));
+        r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
+        r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
+      }
+      const int rcp_hi = __double2hiint(r.rcp);
+      const bool ghost = rcp_hi < 0;
+      // transport_utils.hpp:184-191
+      const double a2 = r.ffaa + r.leak_tot;
+      const double cdf_ddmc = a2 + DBL_MIN;
+      const double dt_ddmc = m_div_r(nlog, vv * cdf_ddmc, r.rcp);
+      const double dt_end = t_end - t;
+      const bool ev = dt_ddmc < dt_end;
+      const double t_new = t + dmin(dt_ddmc, dt_end);
+      // :196-254 (what an event does; committed below only if there was one)
+      const unsigned long long s2 = s0 * kMul2 + kInc2;
+      const double xi = cdf_ddmc * u52_to_double(s2 >> 12);
+      const bool absorbed = xi < r.ffaa;
+      const double xim = xi - r.ffaa;
+      // the first threshold above xim, as the chain of :218-254 finds it (the leak opacities of an
+      // inactive axis are exactly zero -- k_ddmc_pack -- so its two thresholds repeat the one before
+      // them and their comparisons can never be the first to hold); 0: none (xim beyond leak_tot)
+      int delta = (xim <= r.leak_tot) ? l_nij : 0;
+      if constexpr (NDIM == 3) delta = (xim < r.c5) ? -l_nij : delta;   // (2-D: c5 = c4; 1-D: c5 = c4 = c3 = c2)
+      if constexpr (multi_d) {
+        delta = (xim < r.c4) ? l_ni : delta;
+        delta = (xim < r.c3) ? -l_ni : delta;
+      }
+      delta = (xim < r.c2) ? 1 : delta;
+      delta = (xim < r.c1) ? -1 : delta;
+      const bool leak = ev && !absorbed && xi < a2 && delta != 0;
+      const unsigned long long s4 = s0 * kMul4 + kInc4;
+      if (run && !ghost) {
+        t = t_new;
+        rng.s = leak ? s4 : (ev ? s2 : s1);
+        // the leak's two direction uniforms (:217,235,253) are the two draws behind s2: remember where
+        // they start; the particle is in the neighbouring cell (ip, jp, kp = Xtoijk of the position the
+        // step gives it: see the header)
+        pzs = leak ? s2 : pzs;
+        pd = leak ? delta : pd;
+        rec = leak ? rec + (unsigned)delta : rec;
+        const bool done = !(t_new < t_end);
+        ls = (ev && absorbed) ? DS_ABS : (done ? (ev ? DS_DONE : DS_CENSUS) : DS_VIRT);
+      }
+      const unsigned long long gm = __ballot(run && ghost);
+      c_ghost += (unsigned int)__popcll(gm);   // (no step taken: not an event)
+      if (gm != 0ull) {
+        // A leak through a block face (0.4 per history on BASELINE configs[2]): the particle sat this
+        // pass out.  Into a resident block of the same size -- directly or through a periodic boundary
+        // -- nothing happens to it beyond the new cell: SampleDDMCBlockFace only acts on an arrival
+        // from a COARSER block (it looks for x_min + 2 eps_ddmc dx, a same-size leak lands at x_min +
+        // eps_ddmc dx: sample_ddmc_bface.cpp:158-165), Xtoijk gives the first or last cell along the
+        // axis, and in more than one dimension the direction is zeroed (transport_ddmc.cpp:203-211).
+        // Everything else goes through the service phase.
+        // (selects, not branches with stores to one of two variables: the compiler merges such stores into
+        // one store through a selected ADDRESS, which pins both variables in scratch memory)
+        const bool gl = run && ghost;
+        const bool tab = gl && (rcp_hi & kStepGhostTable) != 0;
+        rec = tab ? (unsigned)__double2loint(r.rcp) : rec;
+        if constexpr (multi_d) pd = tab ? kPdZero : pd;
+        ls = (gl && !tab) ? DS_RELOC : ls;
       }
       nrun = __popcll(__ballot(ls == DS_VIRT));
       waste += running - nrun;
       if (waste >= kBudget) thresh = 65;
+    }
+    // ---- behind the loop: block, cell indices and leak channel of every lane from its record number
+    //      and record-number step (block and indices are dead across the loop: five registers fewer)
+    {
+      unsigned q, rr, ii;
+      const unsigned bb = udiv(rec, ntot_u, inv_ntot, q);
+      const unsigned kk = udiv(q, (unsigned)l_nij, inv_nij, rr);
+      const unsigned jj = udiv(rr, (unsigned)l_ni, inv_ni, ii);
+      b = (int)bb; kp = (int)kk; jp = (int)jj; ip = (int)ii;
+      const int ad = pd < 0 ? -pd : pd;
+      const int axis = ad == 1 ? 0 : (ad == l_ni ? 1 : 2);
+      pend = pd == 0 ? -1 : (pd == kPdZero ? -2 : 2 * axis + (pd > 0 ? 1 : 0));
+      status = ST_ACTIVE;
+      real_pos = false;
+      fresh = false;
+      resample = ls == DS_CENSUS;
+      if (ls == DS_ABS) {  // transport.cpp:157-163
+        if (lds_blocks.owned[b] != 0) {
+          atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], PF ? wgt_l : swarm_ld<NT>(&g1(S.w)[n]));
+          status = ST_ABSORBED;
+        } else {
+          status = ST_OUTGOING_ABSORBED;
+        }
+      }
+      if (ls == DS_ABS || ls == DS_CENSUS) ls = DS_DONE;
+      // (a leak whose event time rounds onto the census time -- one step in ~1e16 -- may end the
+      // history in a ghost cell: the general relocation puts it where it belongs)
+      if (ls == DS_DONE && !on_block_l(ip, jp, kp)) ls = DS_RELOC;
     }
   }
 
@@ -671,7 +777,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       }
     }
   }
-  const unsigned long long r_census = c_census, r_abs = c_abs, r_esc = c_esc, r_out = c_out, r_ev = c_ev;
+  const unsigned long long r_census = c_census, r_abs = c_abs, r_esc = c_esc, r_out = c_out, r_ev = c_ev - c_ghost;
   if (lane == 0) {
     if (r_census) atomicAdd(&counters[CNT_CENSUS], r_census);
     if (r_abs) atomicAdd(&counters[CNT_ABSORBED], r_abs);

@@ -8,7 +8,7 @@ i=0
 for CN in "$@"; do
   i=$((i+1))
   rm -rf gpurun_out/pmcany_${w}_$i
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $CN --output-format csv -d gpurun_out/pmcany_${w}_$i -o runc -- \
+  timeout -k 10 100 rocprofv3 --kernel-trace --pmc $CN --output-format csv -d gpurun_out/pmcany_${w}_$i -o runc -- \
       python3 bench.py --workload $w --particles-per-gpu $n --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant \
       > gpurun_out/pmcany_${w}_$i.json 2> gpurun_out/pmcany_err.txt
   python3 - gpurun_out/pmcany_${w}_$i <<'P'
