@@ -4,7 +4,16 @@
 // CheckCompletion with its global_sync) as a host would write it around
 // jb_transport_photons / jb_pack_outgoing / jb_unpack_incoming.
 //
-//   mpiexec -n R ./handoff_mpi [cells_per_block] [blocks] [particles] [cycles] [halo_rings] [dump_prefix]
+//   mpiexec -n R ./handoff_mpi [cells_per_block] [blocks] [particles] [cycles] [halo_rings] [dump_prefix] [exchange]
+//
+// exchange = "tasks" (default): the three tasks as a host strings them together itself (jb_pack_outgoing,
+//   its own MPI calls, jb_unpack_incoming);
+// "mpi" / "rccl": ONE call per transport iteration, jb_exchange (count on the device -> all-gather of
+//   the rank x rank count matrix, read back once -> pack -> all-to-all-v -> unpack, all on the
+//   context's stream), over a jb_exchange_transport: "rccl" = jb_transport_rccl on a communicator this
+//   program bootstraps over MPI (ncclGetUniqueId / ncclCommInitRank: one rank per GPU -- the production
+//   path; the records never leave the device), "mpi" = the same two collectives written with MPI and
+//   host staging below (runs with all ranks on one GPU, which RCCL refuses).
 //
 // Problem: inputs/stepdiff.in in 1-D (x in [-0.5, 0.5], sigma_s = 1e3, no absorption, T = 1e5 K
 // for x < 0 and 1 K for x >= 0, reflecting walls), `blocks` meshblocks dealt to the R ranks in
@@ -27,6 +36,7 @@
 // integrates to the radiation energy.  All ranks may share one GPU (rank % device_count).
 #include <hip/hip_runtime.h>
 #include <mpi.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -53,6 +63,34 @@
     }                                                                                        \
   } while (0)
 
+// ---- a jb_exchange_transport over MPI with host staging (what "mpi" runs; "rccl" uses the library's)
+struct MpiTransport { int nranks; };
+static int mpi_all_gather_u64(void *h, const uint64_t *in_dev, uint64_t *out_dev, int count, void *stream) {
+  const int nranks = ((MpiTransport *)h)->nranks;
+  std::vector<uint64_t> in((size_t)count), out((size_t)count * nranks);
+  if (hipMemcpyAsync(in.data(), in_dev, sizeof(uint64_t) * count, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return 1;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
+  MPI_Allgather(in.data(), count, MPI_UINT64_T, out.data(), count, MPI_UINT64_T, MPI_COMM_WORLD);
+  return hipMemcpy(out_dev, out.data(), sizeof(uint64_t) * out.size(), hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+}
+static int mpi_all_to_all_v(void *h, const int64_t *send_dev, const int64_t *sc, const int64_t *so, int64_t *recv_dev,
+                            const int64_t *rc, const int64_t *ro, int words, void *stream) {
+  const int nranks = ((MpiTransport *)h)->nranks;
+  std::vector<int> c1(nranks), d1(nranks), c2(nranks), d2(nranks);
+  long long ns = 0, nr = 0;
+  for (int r = 0; r < nranks; ++r) {
+    c1[r] = (int)(sc[r] * words); d1[r] = (int)(so[r] * words); ns += sc[r];
+    c2[r] = (int)(rc[r] * words); d2[r] = (int)(ro[r] * words); nr += rc[r];
+  }
+  std::vector<int64_t> sbuf((size_t)ns * words + 1), rbuf((size_t)nr * words + 1);
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;   // the pack kernel has written send_dev
+  if (ns && hipMemcpy(sbuf.data(), send_dev, (size_t)ns * words * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  MPI_Alltoallv(sbuf.data(), c1.data(), d1.data(), MPI_INT64_T, rbuf.data(), c2.data(), d2.data(), MPI_INT64_T,
+                MPI_COMM_WORLD);
+  if (nr && hipMemcpy(recv_dev, rbuf.data(), (size_t)nr * words * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) return 1;
+  return 0;
+}
+
 template <class T>
 static T *dev_alloc(size_t n) {
   T *p = nullptr;
@@ -71,7 +109,13 @@ int main(int argc, char **argv) {
   const long long nparticles = argc > 3 ? std::atoll(argv[3]) : 200000;
   const int cycles = argc > 4 ? std::atoi(argv[4]) : 3;
   const int halo_rings = argc > 5 ? std::atoi(argv[5]) : 1;
-  const char *dump_prefix = argc > 6 ? argv[6] : nullptr;
+  const char *dump_prefix = argc > 6 && std::strcmp(argv[6], "-") != 0 ? argv[6] : nullptr;
+  const char *exchange = argc > 7 ? argv[7] : "tasks";
+  if (std::strcmp(exchange, "tasks") != 0 && std::strcmp(exchange, "mpi") != 0 && std::strcmp(exchange, "rccl") != 0) {
+    if (rank == 0) std::fprintf(stderr, "exchange must be tasks, mpi or rccl\n");
+    MPI_Finalize();
+    return 2;
+  }
   if (nblocks_total < nranks) {
     if (rank == 0) std::fprintf(stderr, "need at least one block per rank\n");
     MPI_Finalize();
@@ -249,6 +293,38 @@ int main(int argc, char **argv) {
   // ---- cycles
   int64_t *rec_dev = dev_alloc<int64_t>((size_t)sw.capacity / 4 * JB_RECORD_WORDS + JB_RECORD_WORDS);
   const int64_t rec_cap = sw.capacity / 4;
+  // (jb_exchange: a receive buffer of its own -- both directions are in flight at once)
+  const bool one_call = std::strcmp(exchange, "tasks") != 0;
+  int64_t *recv_dev = one_call ? dev_alloc<int64_t>((size_t)rec_cap * JB_RECORD_WORDS + JB_RECORD_WORDS) : nullptr;
+  jb_exchange_transport tr{};
+  MpiTransport mpi_tr{nranks};
+  ncclComm_t nccl = nullptr;
+  if (std::strcmp(exchange, "mpi") == 0) {
+    tr.handle = &mpi_tr; tr.all_gather_u64 = mpi_all_gather_u64; tr.all_to_all_v = mpi_all_to_all_v;
+  } else if (std::strcmp(exchange, "rccl") == 0) {
+    ncclUniqueId uid;
+    if (rank == 0 && ncclGetUniqueId(&uid) != ncclSuccess) { std::fprintf(stderr, "ncclGetUniqueId failed\n"); MPI_Abort(MPI_COMM_WORLD, 6); }
+    MPI_Bcast(&uid, (int)sizeof uid, MPI_BYTE, 0, MPI_COMM_WORLD);
+    const ncclResult_t nr_ = ncclCommInitRank(&nccl, nranks, uid, rank);
+    if (nr_ != ncclSuccess) { std::fprintf(stderr, "ncclCommInitRank failed: %s\n", ncclGetErrorString(nr_)); MPI_Abort(MPI_COMM_WORLD, 6); }
+    JB_OK(jb_transport_rccl(nccl, rank, nranks, &tr));
+    // self-test of the transport's payload path (a rank may send to itself in a grouped send / recv):
+    // 5 records from one buffer into the other through ncclSend / ncclRecv, bit for bit
+    {
+      std::vector<int64_t> pat(5 * JB_RECORD_WORDS), back(5 * JB_RECORD_WORDS, 0);
+      for (size_t q = 0; q < pat.size(); ++q) pat[q] = (int64_t)(0x0123456789abcdefll * (long long)(q + 1) + rank);
+      HIP_OK(hipMemcpy(rec_dev, pat.data(), pat.size() * 8, hipMemcpyHostToDevice));
+      std::vector<int64_t> c(nranks, 0), o(nranks, 0);
+      c[rank] = 5;
+      if (tr.all_to_all_v(tr.handle, rec_dev, c.data(), o.data(), recv_dev, c.data(), o.data(), JB_RECORD_WORDS, nullptr) != 0) {
+        std::fprintf(stderr, "RCCL self send / recv failed\n"); MPI_Abort(MPI_COMM_WORLD, 6);
+      }
+      HIP_OK(hipDeviceSynchronize());
+      HIP_OK(hipMemcpy(back.data(), recv_dev, back.size() * 8, hipMemcpyDeviceToHost));
+      if (back != pat) { std::fprintf(stderr, "RCCL self send / recv changed the records\n"); MPI_Abort(MPI_COMM_WORLD, 6); }
+      if (rank == 0) std::printf("RCCL transport: grouped self send / recv of 5 records ok\n");
+    }
+  }
   std::vector<int64_t> send_counts(nranks), recv_counts(nranks);
   std::vector<int> sc(nranks), sd(nranks), rc(nranks), rd(nranks);
   long long handed_total = 0, iterations_total = 0;
@@ -261,6 +337,27 @@ int main(int argc, char **argv) {
     for (int it = 0; it < p.max_transport_iterations; ++it) {
       const int64_t last = sw.n;
       JB_OK(jb_transport_photons(ctx, mesh, &sw, time, p.dt, first, last, /*fuse_census_tally=*/1));
+      if (one_call) {
+        // MeshResetCommunication -> MeshSend -> MeshReceive in one call (include/jaybenne_amd.h: jb_exchange)
+        int64_t nsent = 0, nrecv1 = 0, moved1 = 0;
+        const int64_t n_before = sw.n;
+        jb_status xs = jb_exchange(ctx, mesh, &sw, first, last, rank, nranks, &tr, rec_dev, rec_cap, recv_dev, rec_cap,
+                                   &nsent, &nrecv1, &moved1);
+        if (xs == JB_ERR_CAPACITY && sw.n + nrecv1 > sw.capacity) {
+          // no room for the arrivals: close the holes earlier departures left (nothing was packed yet; what is
+          // still to go is found by its status, wherever the compaction has moved it)
+          JB_OK(jb_remove_marked_particles(ctx, &sw));
+          xs = jb_exchange(ctx, mesh, &sw, 0, sw.n, rank, nranks, &tr, rec_dev, rec_cap, recv_dev, rec_cap, &nsent,
+                           &nrecv1, &moved1);
+        }
+        JB_OK(xs);
+        ++iterations_total;
+        if (moved1 == 0) break;
+        handed_total += nsent;
+        first = sw.n - nrecv1;      // the arrivals, appended at the end: the next transport pass covers only them
+        (void)n_before;
+        continue;
+      }
       // MeshSend: records grouped by destination rank, counts on the host
       JB_OK(jb_pack_outgoing(ctx, mesh, &sw, first, last, nranks, rec_dev, rec_cap, send_counts.data()));
       MPI_Alltoall(send_counts.data(), 1, MPI_INT64_T, recv_counts.data(), 1, MPI_INT64_T, MPI_COMM_WORLD);
@@ -352,6 +449,7 @@ int main(int argc, char **argv) {
     std::fclose(fh);
   }
   const int rcode = ok && (nranks == 1 || handed_g > 0) ? 0 : 1;
+  if (nccl) { jb_transport_release(&tr); ncclCommDestroy(nccl); }
   jb_mesh_destroy(mesh);
   jb_finalize(ctx);
   MPI_Finalize();

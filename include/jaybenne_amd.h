@@ -193,6 +193,20 @@ jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh, const jb_swarm_
                                  int source_type, double t_start, double dt,
                                  const int32_t *nper_block_host, const int32_t *prefix_dev,
                                  const int64_t *slot_base_host, const uint64_t *id_base_host);
+/* ... and the same for a SHARE of every block's new particles: of the photons _count found for block b
+ * (numbered 0.. in cell order, the order the stream ids follow) this call creates nper_block[b] of
+ * them starting at number first_in_block[b]; id_base[b] stays the id of the block's photon 0.  This is
+ * what a rank of a replicated-mesh run calls (every rank holds every block and sources its share of
+ * each: SURVEY 8e "replicated mesh, split particles"; the reference has no such mode -- its blocks
+ * are partitioned, jaybenne.cpp:92-95): histories are then dealt to ranks by stream id, whatever the
+ * blocks cost.  set_energy_delta = 0 makes the emission source leave energy_delta at zero instead of
+ * minus the emitted energy (sourcing.cpp:165-166,196): all ranks but one, so that the sum of the
+ * ranks' energy_delta carries the emission once.  first_in_block_host = NULL: all of them, from 0. */
+jb_status jb_source_photons_fill_range(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
+                                       int source_type, double t_start, double dt,
+                                       const int32_t *nper_block_host, const int32_t *prefix_dev,
+                                       const int64_t *slot_base_host, const uint64_t *id_base_host,
+                                       const int32_t *first_in_block_host, int set_energy_delta);
 
 /* TransportPhotons / TransportPhotons_DDMC(md, t_start, dt) -- jaybenne.hpp:59-60,
  * transport.cpp:28-181, transport_ddmc.cpp:28-237.  Particles [first,last) with status ACTIVE
@@ -236,6 +250,10 @@ jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh, const jb_swa
  *     the nudge of transport_utils.hpp:151-159, as in the reference.  (More than 4 GiB of per-cell
  *     arrays, or JB_NO_IMC_CELL=1: the x-space form of round 3, which tests only the face ahead.)
  *     ~40 % fewer instructions per event than the exact variant.
+ *     In one line: 1e-9 PER CYCLE; measured growth about one decade per cycle, 1e-4 of the domain and
+ *     <= 1e-3 of the histories re-sequenced after ten cycles (the same as the CPU path's libm vs portable
+ *     arithmetic); the tally within 6 sigma per cell at any length.  bench.py measures these in every
+ *     default run (accuracy.lean_vs_exact_after_10_cycles).
  *     Stated tolerance (tests/test_gpu_lean.py, tests/test_gpu_accuracy.py):
  *       - after ONE full cycle every floating-point attribute of every photon is within 1e-9 of the
  *         exact variant's and of the oracle's (positions relative to the domain size, velocities to
@@ -353,6 +371,40 @@ jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *
                            int64_t record_capacity, int64_t *counts_host);
 jb_status jb_unpack_incoming(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm,
                              const int64_t *records_dev, int64_t nrecords);
+
+/* MeshResetCommunication -> MeshSend -> MeshReceive (jaybenne.cpp:26-61) in ONE call, the records never
+ * leaving the device: the OUTGOING particles among [first,last) are counted per destination rank on the
+ * device; the transport gathers every rank's counts into the rank x rank matrix straight from that buffer;
+ * the matrix is read back once (the only host read-back of the call: nranks^2 words -- it carries this
+ * rank's receive sizes and *moved_anywhere, the answer to the completion question of jaybenne.cpp:130-131);
+ * if anything moved anywhere the records are packed into send_dev, exchanged into recv_dev and appended to
+ * the swarm, everything on the context's stream (the call returns when the unpack kernel is launched).
+ * *nsent / *nreceived: records this rank handed over / took in.
+ * JB_ERR_CAPACITY (nothing has been packed or changed yet; *nsent / *nreceived hold what is needed): a
+ * buffer or the swarm is too small -- grow it, or close the swarm's holes with jb_remove_marked_particles,
+ * and call again with [first,last) = [0, swarm->n) (what still has to go is found by its status).
+ *
+ * A jb_exchange_transport is the two collectives of the exchange on DEVICE buffers, enqueued on the given
+ * HIP stream (0 = success): all_gather_u64 -- count words of every rank, in rank order; all_to_all_v --
+ * send_counts[r] records of `words` 8-byte words at send_offsets[r] (in records) to rank r, recv_counts[r]
+ * from rank r to recv_offsets[r].  jb_transport_rccl makes the production one from an RCCL communicator
+ * (ncclComm_t, one rank per GPU): ncclAllGather and one grouped ncclSend / ncclRecv per peer -- xGMI is a
+ * full point-to-point mesh, every rank pair moves its records over its own link.  RCCL is loaded with
+ * dlopen when the first transport is made; the library does not link against it.  A host with another
+ * fabric fills the struct with its own functions (examples/handoff_mpi.cpp: MPI with host staging). */
+typedef struct jb_exchange_transport {
+  void *handle;
+  int (*all_gather_u64)(void *handle, const uint64_t *in_dev, uint64_t *out_dev, int count, void *hip_stream);
+  int (*all_to_all_v)(void *handle, const int64_t *send_dev, const int64_t *send_counts,
+                      const int64_t *send_offsets, int64_t *recv_dev, const int64_t *recv_counts,
+                      const int64_t *recv_offsets, int words, void *hip_stream);
+} jb_exchange_transport;
+jb_status jb_transport_rccl(void *nccl_comm, int rank, int nranks, jb_exchange_transport *out);
+jb_status jb_transport_release(jb_exchange_transport *transport);
+jb_status jb_exchange(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm, int64_t first, int64_t last,
+                      int rank, int nranks, const jb_exchange_transport *transport,
+                      int64_t *send_dev, int64_t send_capacity, int64_t *recv_dev, int64_t recv_capacity,
+                      int64_t *nsent, int64_t *nreceived, int64_t *moved_anywhere);
 
 /* Ghost-zone / halo refresh of one host field -- the role of Parthenon's boundary exchange on
  * the host's FillGhost fields (mcblock.cpp:66-70: density, internal_energy; driven from

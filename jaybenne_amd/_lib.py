@@ -109,6 +109,8 @@ PROTOTYPES = {
     "jb_source_photons_count": (_int, [_vp, _vp, _int, _f64, _int, C.c_uint32, _vp, _vp]),
     "jb_source_photons_fill": (_int, [_vp, _vp, C.POINTER(SwarmView), _int, _f64, _f64, _vp, _vp,
                                       _vp, _vp]),
+    "jb_source_photons_fill_range": (_int, [_vp, _vp, C.POINTER(SwarmView), _int, _f64, _f64, _vp, _vp,
+                                            _vp, _vp, _vp, _int]),
     "jb_transport_photons": (_int, [_vp, _vp, C.POINTER(SwarmView), _f64, _f64, _i64, _i64, _int]),
     "jb_transport_photons_ddmc": (_int, [_vp, _vp, C.POINTER(SwarmView), _f64, _f64, _i64, _i64,
                                          _int]),
@@ -127,6 +129,10 @@ PROTOTYPES = {
     "jb_defrag_policy": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, C.c_int32, C.POINTER(C.c_int32)]),
     "jb_pack_outgoing": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, _i64, _int, _vp, _i64, _vp]),
     "jb_unpack_incoming": (_int, [_vp, _vp, C.POINTER(SwarmView), _vp, _i64]),
+    "jb_transport_rccl": (_int, [_vp, _int, _int, _vp]),
+    "jb_transport_release": (_int, [_vp]),
+    "jb_exchange": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, _i64, _int, _int, _vp, _vp, _i64, _vp, _i64,
+                           C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "jb_gather_cells": (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp]),
     "jb_fill_cells": (_int, [_vp, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "jb_estimate_timestep": (_f64, [_vp]),

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <rocrand/rocrand_kernel.h>
 
+#include <dlfcn.h>
+
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -52,6 +54,8 @@ struct jb_context {
   unsigned long long *counters_d = nullptr;   // CNT_N + 2 cursors + per-rank counters
   unsigned long long *counters_h = nullptr;   // pinned
   long long *scratch_d = nullptr;             // holes / movers / small tables
+  std::vector<unsigned long long> xch_matrix;  // jb_exchange: the rank x rank record counts (host copy)
+  std::vector<long long> xch_tab;             // ... this rank's send / receive counts and offsets
   size_t scratch_words = 0;
   // arithmetic of the gray IMC tracking step: lean (default) or exact (JB_EXACT_ARITH=1 in the
   // environment at jb_initialize, or jb_set_arithmetic)
@@ -94,6 +98,9 @@ struct jb_mesh {
   // the mean-free-path arrays of all resident blocks lie within 4 GiB (32-bit byte offsets): what
   // the cell-local IMC kernel needs of a mesh, whatever its cell widths
   bool offsets32 = false;
+  // the cell-local kernels (k_imc_cell, k_hybrid MODE 3) step the photon's byte offset with 24-bit
+  // multiply-adds of the BYTE strides 8 ni and 8 ni nj: both have to stay below 2^23
+  bool cell_ok = false;
   const char *last_variant = "";  // the k_transport instantiation launched last
   const char *last_pair = "";     // ... and the k_ddmc_all launched beside it (gray DDMC), or ""
   const DevMesh *dm_dev = nullptr;  // copy of dm in device memory (k_hybrid reads the view through it)
@@ -333,6 +340,9 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
   D.ie = D.is + v->nx[0] - 1; D.je = D.js + v->nx[1] - 1; D.ke = D.ks + v->nx[2] - 1;
   D.ncell = v->nx[0] * v->nx[1] * v->nx[2];
   D.ntot = (long long)D.ni * D.nj * D.nk;
+  D.inv_ntot = 1.0 / (double)D.ntot;
+  D.inv_nij = 1.0 / ((double)D.ni * (double)D.nj);
+  D.inv_ni = 1.0 / (double)D.ni;
   if (D.ntot * 8 >= (1ll << 31)) { delete m; return fail(JB_ERR_INVALID, "block too large: cell indices are 32-bit"); }
   if (D.ni >= (1 << 23) || (long long)D.nj * D.nk >= (1ll << 23)) {
     delete m;
@@ -362,6 +372,7 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
     // with 32-bit byte offsets: 16 bytes per cell)
     m->offsets32 = 16ull * (unsigned long long)D.ntot * (unsigned long long)v->nblocks < (1ull << 32);
     m->exact_geom = exact && m->offsets32;
+    m->cell_ok = m->offsets32 && 8ll * D.ni < (1ll << 23) && (v->ndim < 3 || 8ll * D.ni * D.nj < (1ll << 23));
     m->uniform_geom = true;
     for (int b = 1; b < v->nblocks; ++b)
       for (int d = 0; d < 3; ++d) m->uniform_geom = m->uniform_geom && v->blk_dx[3 * b + d] == v->blk_dx[d];
@@ -650,6 +661,19 @@ extern "C" jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh,
                                             const int32_t *prefix_dev,
                                             const int64_t *slot_base_host,
                                             const uint64_t *id_base_host) {
+  return jb_source_photons_fill_range(ctx, mesh, swarm, source_type, t_start, dt, nper_block_host, prefix_dev,
+                                      slot_base_host, id_base_host, nullptr, 1);
+}
+
+extern "C" jb_status jb_source_photons_fill_range(jb_context *ctx, jb_mesh *mesh,
+                                                  const jb_swarm_view *swarm, int source_type,
+                                                  double t_start, double dt,
+                                                  const int32_t *nper_block_host,
+                                                  const int32_t *prefix_dev,
+                                                  const int64_t *slot_base_host,
+                                                  const uint64_t *id_base_host,
+                                                  const int32_t *first_in_block_host,
+                                                  int set_energy_delta) {
   if (!ctx || !mesh || !nper_block_host || !prefix_dev || !slot_base_host || !id_base_host)
     return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
@@ -657,15 +681,18 @@ extern "C" jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh,
   if (st != JB_COMPLETE) return st;
   const DevMesh &M = mesh->dm;
   if (source_type == JB_SOURCE_EMISSION && !ctx->params.do_emission) return JB_COMPLETE;
-  st = ensure_scratch(ctx, (size_t)M.nblocks * 4 + 8);
+  st = ensure_scratch(ctx, (size_t)M.nblocks * 5 + 8);
   if (st != JB_COMPLETE) return st;
   const int32_t *nper = nper_block_host;
-  std::vector<long long> tab(3 * (size_t)M.nblocks);
+  std::vector<long long> tab(4 * (size_t)M.nblocks);
   long long total = 0;
   for (int b = 0; b < M.nblocks; ++b) {
     tab[b] = total;                                   // blk_first
     tab[M.nblocks + b] = slot_base_host[b];           // slot_base
     tab[2 * M.nblocks + b] = (long long)id_base_host[b];
+    tab[3 * M.nblocks + b] = first_in_block_host ? (long long)first_in_block_host[b] : 0ll;
+    if (first_in_block_host && first_in_block_host[b] < 0)
+      return fail(JB_ERR_INVALID, "negative first photon number for block %d", b);
     if (nper[b] < 0) return fail(JB_ERR_INVALID, "negative particle count for block %d", b);
     if (nper[b] > 0 && (slot_base_host[b] < 0 || slot_base_host[b] + nper[b] > swarm->capacity))
       return fail(JB_ERR_CAPACITY, "swarm capacity %lld too small for block %d (slots %lld..%lld)",
@@ -676,13 +703,17 @@ extern "C" jb_status jb_source_photons_fill(jb_context *ctx, jb_mesh *mesh,
   long long *tab_d = ctx->scratch_d + M.nblocks;  // after the int counts (nblocks ints fit in nblocks words)
   JB_HIP(hipMemcpyAsync(tab_d, tab.data(), sizeof(long long) * tab.size(), hipMemcpyHostToDevice,
                         ctx->stream));
+  // (set_energy_delta = 0: energy_delta := 0 instead of minus the emitted energy -- every rank of a
+  // replicated-mesh run but one, so that the sum over ranks carries the emission once)
   hipLaunchKernelGGL(k_source_edelta, dim3(grid_for(ctx, (long long)M.nblocks * M.ncell)),
-                     dim3(kBlock), 0, ctx->stream, M, source_type);
+                     dim3(kBlock), 0, ctx->stream, M, set_energy_delta ? source_type : 0);
   if (total > 0)
     hipLaunchKernelGGL(k_source_fill, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream, M,
                        ctx->dp, dev_swarm(swarm), source_type, t_start, dt, (const int *)prefix_dev,
                        (const long long *)tab_d, (const long long *)(tab_d + M.nblocks),
-                       (const unsigned long long *)(tab_d + 2 * M.nblocks), total);
+                       (const unsigned long long *)(tab_d + 2 * M.nblocks),
+                       first_in_block_host ? (const long long *)(tab_d + 3 * M.nblocks) : (const long long *)nullptr,
+                       total);
   JB_HIP(hipGetLastError());
   JB_HIP(hipStreamSynchronize(ctx->stream));  // tab lives on this stack frame
   return JB_COMPLETE;
@@ -746,13 +777,13 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
   do {                                                                                             \
     if constexpr (!DDMC && G != 0) {                                                               \
       if (mesh->exact_geom) {                                                                      \
-        if (ctx->lean_arith && !ctx->no_imc_cell) JB_LAUNCH_CELL(T, (G == 2));                     \
+        if (ctx->lean_arith && !ctx->no_imc_cell && mesh->cell_ok) JB_LAUNCH_CELL(T, (G == 2));    \
         else if (ctx->lean_arith) JB_LAUNCH_X(T, G, true, true);                                   \
         else JB_LAUNCH_X(T, G, true, false);                                                       \
       } else {                                                                                     \
         /* (the cell-local step does not care what the cell widths are: only its conversions to and \
            from the swarm's coordinates round, by an ulp of the position) */                       \
-        if (ctx->lean_arith && !ctx->no_imc_cell && mesh->offsets32) JB_LAUNCH_CELL(T, (G == 2));  \
+        if (ctx->lean_arith && !ctx->no_imc_cell && mesh->cell_ok) JB_LAUNCH_CELL(T, (G == 2));    \
         else if (ctx->lean_arith) JB_LAUNCH_X(T, G, false, true);                                  \
         else JB_LAUNCH_X(T, G, false, false);                                                      \
       }                                                                                            \
@@ -887,12 +918,12 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
 #define JB_PHASE1(T, NA, F, L, LIN)                                                                \
   do {                                                                                             \
     if (!ctx->lean_arith) JB_LAUNCH_H(T, NA, 0, 1, F, L, LIN, list_d, cnt);                        \
-    else if (mesh->exact_geom && !ctx->no_imc_cell) JB_LAUNCH_H(T, NA, 3, 1, F, L, LIN, list_d, cnt);      \
+    else if (mesh->exact_geom && mesh->cell_ok && !ctx->no_imc_cell) JB_LAUNCH_H(T, NA, 3, 1, F, L, LIN, list_d, cnt); \
     else if (mesh->exact_geom) JB_LAUNCH_H(T, NA, 2, 1, F, L, LIN, list_d, cnt);                            \
     else JB_LAUNCH_H(T, NA, 1, 1, F, L, LIN, list_d, cnt);                                         \
   } while (0)
       {
-        const bool cell = mesh->exact_geom && !ctx->no_imc_cell;
+        const bool cell = mesh->exact_geom && mesh->cell_ok && !ctx->no_imc_cell;
         static const char *const hyb_names[3][4] = {
             {"k_hybrid<1, exact>", "k_hybrid<1, lean>", "k_hybrid<1, lean, exact geometry>", "k_hybrid<1, lean, cell-local>"},
             {"k_hybrid<2, exact>", "k_hybrid<2, lean>", "k_hybrid<2, lean, exact geometry>", "k_hybrid<2, lean, cell-local>"},
@@ -902,7 +933,7 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
 #define JB_PHASE0(T, NA, L, LIN)                                                                   \
   do {                                                                                             \
     if (!ctx->lean_arith) JB_LAUNCH_H(T, NA, 0, 0, 0, L, LIN, nullptr, nullptr);                   \
-    else if (mesh->exact_geom && !ctx->no_imc_cell) JB_LAUNCH_H(T, NA, 3, 0, 0, L, LIN, nullptr, nullptr); \
+    else if (mesh->exact_geom && mesh->cell_ok && !ctx->no_imc_cell) JB_LAUNCH_H(T, NA, 3, 0, 0, L, LIN, nullptr, nullptr); \
     else if (mesh->exact_geom) JB_LAUNCH_H(T, NA, 2, 0, 0, L, LIN, nullptr, nullptr);                       \
     else JB_LAUNCH_H(T, NA, 1, 0, 0, L, LIN, nullptr, nullptr);                                    \
   } while (0)
@@ -1398,6 +1429,160 @@ extern "C" jb_status jb_unpack_incoming(jb_context *ctx, jb_mesh *mesh, jb_swarm
                      (long long)nrecords);
   JB_HIP(hipGetLastError());
   swarm->n += nrecords;
+  return JB_COMPLETE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// jb_exchange: MeshResetCommunication -> MeshSend -> MeshReceive (jaybenne.cpp:26-61) as ONE call on the
+// context's stream, the records never leaving the device.  What moves the bytes is a jb_exchange_transport
+// (two collectives on device buffers): jb_transport_rccl below is the production one.
+extern "C" jb_status jb_exchange(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm, int64_t first,
+                                 int64_t last, int rank, int nranks, const jb_exchange_transport *tr,
+                                 int64_t *send_dev, int64_t send_capacity, int64_t *recv_dev,
+                                 int64_t recv_capacity, int64_t *nsent, int64_t *nreceived,
+                                 int64_t *moved_anywhere) {
+  if (!ctx || !mesh || !tr || !tr->all_gather_u64 || !tr->all_to_all_v || !nsent || !nreceived || !moved_anywhere)
+    return fail(JB_ERR_INVALID, "null argument");
+  JB_HIP(hipSetDevice(ctx->device));
+  jb_status st = check_swarm(swarm, "jb_exchange");
+  if (st != JB_COMPLETE) return st;
+  if (first < 0 || last > swarm->n || first > last) return fail(JB_ERR_INVALID, "bad particle range");
+  if (rank < 0 || rank >= nranks) return fail(JB_ERR_INVALID, "rank outside [0, nranks)");
+  if (nranks < mesh->nranks_seen || nranks > kCounterWords - kRankBase)
+    return fail(JB_ERR_INVALID, "nranks = %d does not cover the owners in the mesh view", nranks);
+  *nsent = 0; *nreceived = 0; *moved_anywhere = 0;
+  // 1. records per destination rank, counted on the device ...
+  unsigned long long *per_rank = ctx->counters_d + kRankBase;
+  JB_HIP(hipMemsetAsync(per_rank, 0, sizeof(unsigned long long) * nranks, ctx->stream));
+  const DevSwarm S = dev_swarm(swarm);
+  if (last > first)
+    hipLaunchKernelGGL(k_count_outgoing, dim3(grid_for(ctx, last - first)), dim3(kBlock), 0, ctx->stream,
+                       mesh->dm, S, (long long)first, (long long)last, per_rank);
+  JB_HIP(hipGetLastError());
+  // 2. ... gathered from every rank straight from that buffer (no read-back in front of the collective):
+  // the rank x rank matrix carries this rank's receive sizes AND the answer to "did anything move
+  // anywhere" (the completion test of jaybenne.cpp:130-131 needs no collective of its own) ...
+  st = ensure_scratch(ctx, (size_t)nranks * (size_t)nranks + 4 * (size_t)nranks + 8);
+  if (st != JB_COMPLETE) return st;
+  unsigned long long *matrix_d = (unsigned long long *)ctx->scratch_d;
+  if (tr->all_gather_u64(tr->handle, (const uint64_t *)per_rank, (uint64_t *)matrix_d, nranks, (void *)ctx->stream) != 0)
+    return fail(JB_ERR_HIP, "jb_exchange: the transport's all-gather of the record counts failed");
+  // 3. ... and read back ONCE per call: nranks^2 words
+  ctx->xch_matrix.resize((size_t)nranks * (size_t)nranks);
+  JB_HIP(hipMemcpyAsync(ctx->xch_matrix.data(), matrix_d, sizeof(unsigned long long) * ctx->xch_matrix.size(),
+                        hipMemcpyDeviceToHost, ctx->stream));
+  JB_HIP(hipStreamSynchronize(ctx->stream));
+  long long total = 0, mine_out = 0, mine_in = 0;
+  ctx->xch_tab.assign(4 * (size_t)nranks, 0);   // send counts | send offsets | recv counts | recv offsets (records)
+  long long *sc = ctx->xch_tab.data(), *so = sc + nranks, *rc = so + nranks, *ro = rc + nranks;
+  for (int s_ = 0; s_ < nranks; ++s_)
+    for (int r = 0; r < nranks; ++r) total += (long long)ctx->xch_matrix[(size_t)s_ * nranks + r];
+  for (int r = 0; r < nranks; ++r) {
+    sc[r] = (long long)ctx->xch_matrix[(size_t)rank * nranks + r];
+    rc[r] = (long long)ctx->xch_matrix[(size_t)r * nranks + rank];
+    so[r] = mine_out; ro[r] = mine_in;
+    mine_out += sc[r]; mine_in += rc[r];
+  }
+  *moved_anywhere = total;
+  *nsent = mine_out; *nreceived = mine_in;
+  if (sc[rank] != 0) return fail(JB_ERR_INVALID, "jb_exchange: a rank does not hand particles to itself");
+  if (total == 0) return JB_COMPLETE;
+  if (mine_out > 0 && (!send_dev || mine_out > send_capacity))
+    return fail(JB_ERR_CAPACITY, "jb_exchange: send buffer holds %lld records, %lld needed", (long long)send_capacity, mine_out);
+  if (mine_in > 0 && (!recv_dev || mine_in > recv_capacity))
+    return fail(JB_ERR_CAPACITY, "jb_exchange: receive buffer holds %lld records, %lld needed", (long long)recv_capacity, mine_in);
+  if (swarm->n + mine_in > swarm->capacity)
+    return fail(JB_ERR_CAPACITY, "jb_exchange: swarm capacity %lld too small for %lld arrivals", (long long)swarm->capacity, mine_in);
+  // 4. pack (the packed slots become holes), 5. the payload, 6. unpack behind it on the same stream
+  if (mine_out > 0) {
+    long long *firsts_d = (long long *)(matrix_d + (size_t)nranks * nranks);
+    JB_HIP(hipMemcpyAsync(firsts_d, so, sizeof(long long) * nranks, hipMemcpyHostToDevice, ctx->stream));
+    JB_HIP(hipMemsetAsync(per_rank, 0, sizeof(unsigned long long) * nranks, ctx->stream));
+    hipLaunchKernelGGL(k_pack_outgoing, dim3(grid_for(ctx, last - first)), dim3(kBlock), 0, ctx->stream,
+                       mesh->dm, S, (long long)first, (long long)last, (const long long *)firsts_d,
+                       per_rank, (long long *)send_dev);
+    JB_HIP(hipGetLastError());
+  }
+  if (tr->all_to_all_v(tr->handle, send_dev, (const int64_t *)sc, (const int64_t *)so, recv_dev,
+                       (const int64_t *)rc, (const int64_t *)ro, kRecWords, (void *)ctx->stream) != 0)
+    return fail(JB_ERR_HIP, "jb_exchange: the transport's record exchange failed");
+  if (mine_in > 0) {
+    hipLaunchKernelGGL(k_unpack_incoming, dim3(grid_for(ctx, mine_in)), dim3(kBlock), 0, ctx->stream,
+                       mesh->dm, dev_swarm(swarm), (long long)swarm->n, (const long long *)recv_dev,
+                       (long long)mine_in);
+    JB_HIP(hipGetLastError());
+    swarm->n += mine_in;
+  }
+  return JB_COMPLETE;
+}
+
+// ---- the RCCL transport: all-gather + grouped send / recv on the caller's communicator.  RCCL is
+// loaded when the first transport is made (dlopen: the library itself does not link against it, so a
+// host without RCCL -- or with its own copy already in the process, as PyTorch has -- loads fine).
+namespace {
+struct RcclApi {
+  void *lib = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+constexpr int kNcclInt64 = 4, kNcclUint64 = 5;   // ncclDataType_t (rccl.h)
+struct RcclHandle { void *comm; int rank, nranks; };
+
+bool load_rccl() {
+  if (g_rccl.lib) return true;
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib) return false;
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.lib, "ncclAllGather");
+  g_rccl.Send = (decltype(g_rccl.Send))dlsym(g_rccl.lib, "ncclSend");
+  g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(g_rccl.lib, "ncclRecv");
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(g_rccl.lib, "ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(g_rccl.lib, "ncclGroupEnd");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
+  return g_rccl.AllGather && g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd;
+}
+
+int rccl_all_gather(void *h, const uint64_t *in_dev, uint64_t *out_dev, int count, void *stream) {
+  const RcclHandle *H = (const RcclHandle *)h;
+  return g_rccl.AllGather(in_dev, out_dev, (size_t)count, kNcclUint64, H->comm, (hipStream_t)stream);
+}
+// every rank pair uses its own xGMI link: one grouped send / recv per peer, no ring through the node
+int rccl_all_to_all_v(void *h, const int64_t *send_dev, const int64_t *sc, const int64_t *so, int64_t *recv_dev,
+                      const int64_t *rc, const int64_t *ro, int words, void *stream) {
+  const RcclHandle *H = (const RcclHandle *)h;
+  int err = g_rccl.GroupStart();
+  for (int r = 0; r < H->nranks && err == 0; ++r) {
+    if (sc[r] > 0) err = g_rccl.Send(send_dev + so[r] * words, (size_t)(sc[r] * words), kNcclInt64, r, H->comm, (hipStream_t)stream);
+    if (err == 0 && rc[r] > 0)
+      err = g_rccl.Recv(recv_dev + ro[r] * words, (size_t)(rc[r] * words), kNcclInt64, r, H->comm, (hipStream_t)stream);
+  }
+  const int end = g_rccl.GroupEnd();
+  return err != 0 ? err : end;
+}
+}  // namespace
+
+extern "C" jb_status jb_transport_rccl(void *nccl_comm, int rank, int nranks, jb_exchange_transport *out) {
+  if (!nccl_comm || !out) return fail(JB_ERR_INVALID, "null argument");
+  if (rank < 0 || rank >= nranks) return fail(JB_ERR_INVALID, "rank outside [0, nranks)");
+  if (!load_rccl()) return fail(JB_ERR_INVALID, "jb_transport_rccl: librccl.so could not be loaded (%s)", dlerror());
+  RcclHandle *H = new (std::nothrow) RcclHandle{nccl_comm, rank, nranks};
+  if (!H) return fail(JB_ERR_INVALID, "out of memory");
+  out->handle = H;
+  out->all_gather_u64 = rccl_all_gather;
+  out->all_to_all_v = rccl_all_to_all_v;
+  return JB_COMPLETE;
+}
+
+extern "C" jb_status jb_transport_release(jb_exchange_transport *tr) {
+  if (tr && tr->all_gather_u64 == rccl_all_gather) delete (RcclHandle *)tr->handle;
+  if (tr) { tr->handle = nullptr; tr->all_gather_u64 = nullptr; tr->all_to_all_v = nullptr; }
   return JB_COMPLETE;
 }
 

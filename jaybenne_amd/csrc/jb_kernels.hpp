@@ -171,6 +171,31 @@ __global__ void __launch_bounds__(kBlock) k_lam_ghost_codes(DevMesh M, const int
       }
     }
     const unsigned ntot = (unsigned)M.ntot;
+    if (M.ddmc_step != nullptr) {
+      // ... and of the DDMC step records (jb_kernel_ddmc.hpp: kStepGhostTable): the record number of the
+      // cell a particle that leaked into this ghost cell is in -- same-size resident neighbour, periodic
+      // image, or (more than one dimension) the cell it came from at a reflecting wall
+      int sflag = 0;
+      unsigned srec = 0u;
+      if (nout == 1) {
+        int f = 0;
+        for (int d = 0; d < 3; ++d) {
+          if (lo[d]) f = 2 * d;
+          if (hi[d]) f = 2 * d + 1;
+        }
+        const int n = f >> 1;
+        const bool adjacent = (f & 1) ? idx[n] == last[n] + 1 : idx[n] == first[n] - 1;
+        const int ent = M.nbr_ent[6 * b + f];
+        const bool wall = (ent >> 28) == 2;
+        if (adjacent && ent >= 0 && (M.ndim >= 2 || !wall)) {
+          const int stride = n == 0 ? 1 : (n == 1 ? M.ni : M.ni * M.nj);
+          const int back = wall ? stride : stride * M.nx[n];
+          sflag = 1;  // kStepGhostTable
+          srec = (unsigned)(ent & 0x0fffffff) * ntot + (unsigned)(q + ((f & 1) ? -back : back));
+        }
+      }
+      M.ddmc_step[8 * ((long long)b * M.ntot + q) + 7] = __hiloint2double((int)(0x80000000u | (unsigned)sflag), (int)srec);
+    }
     M.lam_sc[b][q] = __hiloint2double(kGhostHi | bits, (int)(16u * ntot * (unsigned)dest + 8u * dcell));
     M.lam_abs[b][q] = 1.0;
     if (M.lam_hyb != nullptr)  // (the destination block in the low 8 bits: <= kLdsBlocks resident blocks there)
@@ -350,7 +375,7 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     k_source_fill(DevMesh M, DevParams P, DevSwarm S, int source_type, double t_start, double dt,
                   const int *prefix, const long long *blk_first, const long long *slot_base,
-                  const unsigned long long *id_base, long long total) {
+                  const unsigned long long *id_base, const long long *ord_first, long long total) {
   load_math_tables();
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
        g += (long long)gridDim.x * blockDim.x) {
@@ -360,7 +385,10 @@ __global__ void __launch_bounds__(kBlock)
       if (blk_first[mid] <= g) lo = mid; else hi = mid - 1;
     }
     const int b = lo;
-    const int np = (int)(g - blk_first[b]);
+    // (ord_first: this call sources the block's photons number ord_first[b] ... only -- a rank of a
+    // replicated-mesh run takes its share of every block, jb_source_photons_fill_range)
+    const int nq = (int)(g - blk_first[b]);
+    const int np = nq + (ord_first ? (int)ord_first[b] : 0);
     const int *pf = prefix + (long long)b * M.ncell;
     lo = 0; hi = M.ncell - 1;  // last cell with pf[cell] <= np (empty cells share a prefix value:
                                // the LAST of them that still satisfies <= is the non-empty one)
@@ -377,7 +405,7 @@ __global__ void __launch_bounds__(kBlock)
     const long long q = cidx(M, k, j, i);
     Blk B;
     load_block(M, b, B);
-    const long long n = slot_base[b] + np;
+    const long long n = slot_base[b] + nq;
     const uint64_t id = id_base[b] + (uint64_t)np;
     LcgRng rng(rng_stream_start(P.key0, id));
     S.ip[n] = i; S.jp[n] = j; S.kp[n] = k;

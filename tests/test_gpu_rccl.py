@@ -78,3 +78,72 @@ def test_rccl_one_rank_group(gpu_device):
     p.join(300)
     assert p.exitcode == 0
     assert out.get(timeout=5) == "ok"
+
+
+def _mpi_env():
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec) or not os.path.exists("/opt/conda/lib/libmpi.so"):
+        pytest.skip("no MPI installation in this image")
+    import subprocess
+    build = subprocess.run(["make", "-C", os.path.join(root, "examples"), "mpi"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stdout + build.stderr
+    return root, mpiexec
+
+
+def test_c_level_exchange_over_rccl_one_rank(gpu_device, tmp_path):
+    """jb_exchange over jb_transport_rccl (include/jaybenne_amd.h), from C++ with no Python in the process
+    (examples/handoff_mpi.cpp, exchange = rccl): the program makes a one-rank RCCL communicator
+    (ncclGetUniqueId / ncclCommInitRank -- one card here, so one rank), sends five records to itself through
+    the transport's grouped ncclSend / ncclRecv, and runs three cycles whose every transport iteration goes
+    through jb_exchange (device-side count -> ncclAllGather -> one read-back: nothing moved) -- the photons
+    equal the oracle's bit for bit."""
+    import subprocess
+    from helpers import load_deck, make_oracle, run_oracle_cycles
+    from oracle import orc
+    from test_gpu_multirank import _read_photon_dumps
+    root, mpiexec = _mpi_env()
+    ov = {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 16, "jaybenne/num_particles": 50000}
+    O, mesh, _ = make_oracle(load_deck("stepdiff", ov), orc.MATH_PORTABLE)
+    run_oracle_cycles(O, load_deck("stepdiff", ov), 3)
+    order = np.argsort(O.sw["id"][:O.n])
+    prefix = str(tmp_path / "photons")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([mpiexec, "-n", "1", os.path.join(root, "examples", "handoff_mpi"), "16", "8", "50000", "3",
+                          "1", prefix, "rccl"], capture_output=True, text=True, timeout=240, env=env)
+    assert run.returncode == 0 and "HANDOFF OK" in run.stdout, run.stdout + run.stderr
+    assert "RCCL transport: grouped self send / recv of 5 records ok" in run.stdout
+    g = _read_photon_dumps(prefix, 1)
+    assert len(g) == O.n and np.array_equal(g["id"], O.sw["id"][:O.n][order])
+    for k in ("x", "vx", "t", "w", "rng", "ip"):
+        assert np.array_equal(g[k], O.sw[k][:O.n][order]), k
+
+
+@pytest.mark.parametrize("rings", [1, 0])
+def test_c_level_exchange_three_ranks_over_the_mpi_transport(gpu_device, tmp_path, rings):
+    """The same jb_exchange -- counts on the device, rank x rank matrix, pack, all-to-all-v, unpack, the
+    capacity protocol -- on three ranks that share the card, over a jb_exchange_transport written with MPI
+    (RCCL wants one GPU per rank): with halo copies two transport iterations per cycle, without them
+    dozens; either way the union of the ranks' photons equals the single-process oracle bit for bit."""
+    import re
+    import subprocess
+    from helpers import load_deck, make_oracle, run_oracle_cycles
+    from oracle import orc
+    from test_gpu_multirank import _read_photon_dumps
+    root, mpiexec = _mpi_env()
+    ov = {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 16, "jaybenne/num_particles": 200000}
+    O, mesh, _ = make_oracle(load_deck("stepdiff", ov), orc.MATH_PORTABLE)
+    run_oracle_cycles(O, load_deck("stepdiff", ov), 3)
+    order = np.argsort(O.sw["id"][:O.n])
+    prefix = str(tmp_path / f"photons{rings}")
+    run = subprocess.run([mpiexec, "-n", "3", os.path.join(root, "examples", "handoff_mpi"), "16", "8", "200000", "3",
+                          str(rings), prefix, "mpi"], capture_output=True, text=True, timeout=240)
+    assert run.returncode == 0 and "HANDOFF OK" in run.stdout, run.stdout + run.stderr
+    per_cycle = float(re.search(r"\(([0-9.]+) per cycle\)", run.stdout).group(1))
+    assert per_cycle == 2.0 if rings == 1 else per_cycle > 20.0
+    g = _read_photon_dumps(prefix, 3)
+    assert len(g) == O.n and np.array_equal(g["id"], O.sw["id"][:O.n][order])
+    for k in ("x", "vx", "t", "w", "rng", "ip"):
+        assert np.array_equal(g[k], O.sw[k][:O.n][order]), (rings, k)
+    assert np.array_equal(g["gblk"], O.sw["blk"][:O.n][order])
