@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cmath>
 #include <functional>
+#include <limits>
 #include <memory>
 #include <numeric>
 #include <stdexcept>
@@ -166,6 +167,137 @@ inline SourcePlan PlanSource(const std::vector<int32_t> &nper_local, const std::
 inline uint32_t SourceEpoch(uint64_t cycle, SourceType st) {
   if (st == SourceType::emission) return (uint32_t)cycle;
   return cycle == 0 ? 0u : (uint32_t)((1u << 19) | cycle);
+}
+
+// ---- block -> rank partition (several ranks; jaybenne_amd/mesh.py Mesh.partition is the same algorithm,
+// operation for operation, so that a C++ host and the Python host deal the same blocks to the same rank) --
+// Contiguous runs of the Z-ordered block list.  cost[b] = the tracking work of block b for one cycle
+// (photons sourced there x events per history: BlockCost below); the runs are the split with the
+// SMALLEST LARGEST load, found exactly by dynamic programming over the prefix sums (a cycle lasts as
+// long as its slowest rank); then a boundary that separates the children of one parent (group[b] equal
+// for consecutive blocks) moves to the nearer end of that family if the largest load stays within
+// 1 + sibling_slack of the optimum.  The reference inherits Parthenon's balancer with unit cost per
+// block (jaybenne.cpp:92-95): pass cost = all ones for that.
+// Returns bounds[0 .. nranks]: rank r owns blocks bounds[r] .. bounds[r + 1] - 1.
+inline std::vector<int32_t> PartitionBlocks(const std::vector<double> &cost, int nranks,
+                                            const std::vector<int64_t> &group, double sibling_slack = 0.10) {
+  const int nb = (int)cost.size();
+  if (nranks < 1 || nranks > nb) throw Error(JB_ERR_INVALID, "cannot spread the blocks over that many ranks");
+  std::vector<double> S((size_t)nb + 1, 0.0);
+  for (int b = 0; b < nb; ++b) {
+    if (!(cost[b] > 0.0) || !std::isfinite(cost[b])) throw Error(JB_ERR_INVALID, "block costs must be positive and finite");
+    S[(size_t)b + 1] = S[(size_t)b] + cost[b];
+  }
+  const double inf = std::numeric_limits<double>::infinity();
+  std::vector<std::vector<double>> best((size_t)nranks, std::vector<double>((size_t)nb + 1, inf));
+  std::vector<std::vector<int32_t>> cut((size_t)nranks, std::vector<int32_t>((size_t)nb + 1, 0));
+  for (int i = 1; i <= nb; ++i) best[0][(size_t)i] = S[(size_t)i];
+  for (int r = 1; r < nranks; ++r)
+    for (int i = r + 1; i <= nb; ++i) {
+      double bv = inf;
+      int32_t bj = r;
+      for (int j = r; j < i; ++j) {
+        const double a = best[(size_t)r - 1][(size_t)j], c = S[(size_t)i] - S[(size_t)j];
+        const double v = a > c ? a : c;
+        if (v < bv) { bv = v; bj = j; }                    // (the first of equal minima)
+      }
+      best[(size_t)r][(size_t)i] = bv;
+      cut[(size_t)r][(size_t)i] = bj;
+    }
+  std::vector<int32_t> bounds((size_t)nranks + 1, 0);
+  bounds[(size_t)nranks] = nb;
+  for (int r = nranks - 1; r >= 1; --r) bounds[(size_t)r] = cut[(size_t)r][(size_t)bounds[(size_t)r + 1]];
+  const double optimum = best[(size_t)nranks - 1][(size_t)nb];
+  auto largest = [&](const std::vector<int32_t> &bd) {
+    double m = 0.0;
+    for (int r = 0; r < nranks; ++r) {
+      const double l = S[(size_t)bd[(size_t)r + 1]] - S[(size_t)bd[(size_t)r]];
+      m = l > m ? l : m;
+    }
+    return m;
+  };
+  for (int r = 1; r < nranks; ++r) {
+    const int q = bounds[(size_t)r];
+    if (group[(size_t)q - 1] != group[(size_t)q]) continue;   // not inside a family
+    int lo = q, hi = q;
+    while (lo > 0 && group[(size_t)lo - 1] == group[(size_t)q]) --lo;
+    while (hi < nb && group[(size_t)hi] == group[(size_t)q]) ++hi;
+    bool have = false;
+    double bl = 0.0;
+    int bd_dist = 0, bc = q;
+    for (int cand : {lo, hi}) {
+      if (!(bounds[(size_t)r - 1] < cand && cand < bounds[(size_t)r + 1])) continue;
+      std::vector<int32_t> bd = bounds;
+      bd[(size_t)r] = cand;
+      const double l = largest(bd);
+      const int dist = cand > q ? cand - q : q - cand;
+      // (order of the Python host's tuples: load, distance, position)
+      if (!have || l < bl || (l == bl && (dist < bd_dist || (dist == bd_dist && cand < bc)))) {
+        have = true; bl = l; bd_dist = dist; bc = cand;
+      }
+    }
+    if (have && bl <= (1.0 + sibling_slack) * optimum) bounds[(size_t)r] = bc;
+  }
+  return bounds;
+}
+
+// group[] of PartitionBlocks from the Z-ordered leaf list: level[b] and the logical location lloc[3 b + d]
+// at that level (Mesh.sibling_groups of the Python host)
+inline std::vector<int64_t> SiblingGroups(int ndim, const std::vector<int32_t> &level, const std::vector<int32_t> &lloc) {
+  std::vector<int64_t> group(level.size());
+  int64_t g = -1;
+  bool have_prev = false;
+  int32_t pl = 0, pp[3] = {0, 0, 0};
+  for (size_t b = 0; b < level.size(); ++b) {
+    bool same = false;
+    int32_t par[3] = {0, 0, 0};
+    if (level[b] > 0) {
+      for (int d = 0; d < 3; ++d) par[d] = d < ndim ? lloc[3 * b + d] >> 1 : 0;
+      same = have_prev && pl == level[b] && pp[0] == par[0] && pp[1] == par[1] && pp[2] == par[2];
+    }
+    if (!same) ++g;
+    group[b] = g;
+    have_prev = level[b] > 0;
+    pl = level[b];
+    for (int d = 0; d < 3; ++d) pp[d] = par[d];
+  }
+  return group;
+}
+
+// The tracking work of a block for one cycle, in events per photon it starts with (mcblock.block_costs of
+// the Python host, the same expressions): c dt (sigma_s + sigma_a + sum_d 1 / (2 dx_d)) in a block that
+// takes IMC steps; c dt (sigma_a + sum_d 2 P / dx_d), P = 1 / (3 (sigma_a + sigma_s) dx_d), in one that takes
+// DDMC steps (dx_min (sigma_a + sigma_s) > tau_ddmc, transport_ddmc.cpp:135).  With the `uniform` source
+// strategy every block starts with the same number of photons (sourcing.cpp:68-69), so this IS the cost.
+inline double BlockCost(int ndim, const double dx[3], double c_dt, double sig_a, double sig_s, bool use_ddmc,
+                        double tau_ddmc) {
+  double dmin = dx[0];
+  for (int d = 1; d < ndim; ++d) dmin = dx[d] < dmin ? dx[d] : dmin;
+  double per_history;
+  if (use_ddmc && dmin * (sig_a + sig_s) > tau_ddmc) {
+    double leak = 0.0;
+    for (int d = 0; d < ndim; ++d) leak += 2.0 * (2.0 / (3.0 * 2.0 * (sig_a + sig_s) * dx[d])) / dx[d];
+    per_history = c_dt * (sig_a + leak);
+  } else {
+    double cross = 0.0;
+    for (int d = 0; d < ndim; ++d) cross += 0.5 / dx[d];
+    per_history = c_dt * (sig_s + sig_a + cross);
+  }
+  return per_history > 1.0 ? per_history : 1.0;
+}
+
+// Replicated mesh, split particles (jb_source_photons_fill_range; jaybenne_amd/jaybenne.py rank_share): of
+// the nper[b] new photons of block b, rank `rank` of `nranks` sources count[b] starting at first[b].
+inline void RankShare(const std::vector<int32_t> &nper, int rank, int nranks, std::vector<int32_t> *first,
+                      std::vector<int32_t> *count) {
+  first->resize(nper.size());
+  count->resize(nper.size());
+  for (size_t b = 0; b < nper.size(); ++b) {
+    const int64_t n = nper[b];
+    const int64_t f = (n * rank) / nranks;
+    (*first)[b] = (int32_t)f;
+    (*count)[b] = (int32_t)((n * (rank + 1)) / nranks - f);
+  }
 }
 
 // ---- halo copies (several ranks; shared by examples/handoff_mpi.cpp, the Parthenon adapter and,

@@ -57,6 +57,16 @@ class Comm:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
+    def allreduce_sum_tensor(self, t: torch.Tensor) -> None:
+        """Sum of a float64 device tensor over the ranks, in place, the same bits on every rank (RCCL on
+        the tensor itself; gloo through a host copy).  The replicated-mesh mode's only exchange."""
+        if t.device == self.device:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            h = t.to(self.device)
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+
     def barrier(self) -> None:
         dist.barrier(group=self.group)
 

@@ -35,8 +35,11 @@ class FieldExchange:
     def __init__(self, md):
         self.md = md
         mesh = md.mesh
-        rank, nranks = md.rank, md.nranks
-        owner = np.asarray(mesh.owner, dtype=np.int64)
+        rank = md.rank
+        # (a replicated-mesh run holds every block on every rank: the refresh is local)
+        nranks = 1 if getattr(md, "replicated", False) else md.nranks
+        owner = np.asarray(getattr(md, "field_owner", mesh.owner), dtype=np.int64)
+        self.nranks = nranks
         ns = 2 ** mesh.ndim
         ni, nj = mesh.ntot_dim[0], mesh.ntot_dim[1]
         K, J, I = np.meshgrid(np.arange(mesh.is_[2], mesh.is_[2] + mesh.nx[2]),
@@ -111,7 +114,7 @@ class FieldExchange:
         fid = _lib.FIELD_IDS[name]
         md._sync_stream()
         nsend = int(self.send_counts.sum())
-        if md.nranks > 1:
+        if self.nranks > 1:
             _lib.check(md.lib.jb_gather_cells(md.pkg.ctx, md.handle, fid, nsend,
                                               self.serve_blk.data_ptr(), self.serve_cell.data_ptr(),
                                               self.send_buf.data_ptr()))

@@ -148,7 +148,7 @@ class MeshData:
     """
 
     def __init__(self, pkg: StateDescriptor, mesh: Mesh, capacity: int, rank: int = 0,
-                 nranks: int = 1, comm=None, halo_rings: int = 1):
+                 nranks: int = 1, comm=None, halo_rings: int = 1, replicated: bool = False):
         self.pkg = pkg
         self.mesh = mesh
         self.rank, self.nranks = rank, nranks
@@ -156,7 +156,20 @@ class MeshData:
         self.lib = pkg.lib
         dev = pkg.device
         self.device = dev
-        owner = np.ascontiguousarray(mesh.owner, dtype=np.int32)
+        # Replicated mesh, split particles (the reference has no such mode, its blocks are
+        # partitioned: jaybenne.cpp:92-95): every rank holds EVERY block and follows its share of each
+        # block's photons -- dealt by stream id at the source (jb_source_photons_fill_range) -- from
+        # source to census; nothing is ever handed over, and the ranks' energy_tally / energy_delta
+        # are summed once per cycle (one all-reduce each).  For meshes whose fields fit every GPU
+        # many times over (the SMR decks: 20 / 32 blocks of 32^2 cells) this balances whatever the
+        # blocks cost -- a DDMC block of BASELINE configs[4] costs 1 % of an IMC block --, which a
+        # partition of 32 blocks over 8 ranks cannot.
+        self.replicated = bool(replicated) and nranks > 1
+        if self.replicated:
+            owner = np.full(mesh.nblocks, rank, dtype=np.int32)
+        else:
+            owner = np.ascontiguousarray(mesh.owner, dtype=np.int32)
+        self.field_owner = owner           # who holds the authoritative copy of a block's fields (halo.py)
         if owner.max() >= nranks:
             raise ValueError("mesh.owner names a rank >= nranks")
         self.gids = np.nonzero(owner == rank)[0].astype(np.int32)       # the blocks this rank owns
@@ -168,7 +181,7 @@ class MeshData:
         # to its owner once, when its history ends, instead of at every crossing (in the
         # reference every crossing costs a transport iteration with a global sync,
         # jaybenne.cpp:113-131).  HBM is plentiful: one ring costs a few GB at most.
-        halo = (mesh.neighbours(self.gids, halo_rings) if (nranks > 1 and halo_rings > 0)
+        halo = (mesh.neighbours(self.gids, halo_rings) if (nranks > 1 and halo_rings > 0 and not self.replicated)
                 else np.zeros(0, dtype=np.int32))
         self.resident_gids = np.concatenate([self.gids, halo]).astype(np.int32)
         self.owned_flags = np.concatenate([np.ones(self.nowned, dtype=np.int32),
@@ -343,9 +356,26 @@ def UpdateDerivedTransportFields(md: MeshData, dt: float) -> TaskStatus:
 def _global_block_counts(md: MeshData, nper_local: np.ndarray) -> np.ndarray:
     counts = np.zeros(md.mesh.nblocks, dtype=np.int64)
     counts[md.resident_gids] = nper_local        # halo copies source nothing (zeros)
-    if md.comm is not None and md.nranks > 1:
+    if md.comm is not None and md.nranks > 1 and not md.replicated:
         counts = md.comm.allreduce_sum_int64(counts)
-    return counts
+    return counts     # (replicated mesh: every rank has counted every block itself)
+
+
+def rank_share(nper: np.ndarray, rank: int, nranks: int):
+    """Which of a block's ``nper[b]`` new photons (numbered in cell order, as their stream ids are)
+    rank ``rank`` of a replicated-mesh run sources: a contiguous range per block, ``first[b]`` ..
+    ``first[b] + count[b]`` -- contiguous cells, so a rank's photons start out as compact in space as
+    the whole swarm's do."""
+    n = nper.astype(np.int64)
+    first = (n * rank) // nranks
+    return first.astype(np.int32), ((n * (rank + 1)) // nranks - first).astype(np.int32)
+
+
+def _sum_over_ranks(md: MeshData, names) -> None:
+    """Replicated mesh: the ranks' partial cell fields -> their sum, on every rank."""
+    if md.replicated:
+        for n in names:
+            md.comm.allreduce_sum_tensor(md.fields[n])
 
 
 def source_epoch(cycle: int, source_type) -> int:
@@ -375,13 +405,21 @@ def SourcePhotons(md: MeshData, source_type: SourceType, t_start: float, dt: flo
     counts = _global_block_counts(md, nper)
     excl = np.concatenate(([0], np.cumsum(counts)[:-1]))
     id_base = np.ascontiguousarray(md.next_id + excl[md.resident_gids], dtype=np.uint64)
+    if md.replicated:    # this rank's share of every block (stream ids stay those of the whole block)
+        first, nper = rank_share(nper, md.rank, md.nranks)
     local_excl = np.concatenate(([0], np.cumsum(nper.astype(np.int64))[:-1]))
     slot_base = np.ascontiguousarray(md.n + local_excl, dtype=np.int64)
     tot = int(nper.sum())
     md.reserve(md.n + tot)
-    _lib.check(md.lib.jb_source_photons_fill(pkg.ctx, md.handle, C.byref(md.sv), int(source_type),
-                                             t_start, dt, nper.ctypes.data, md.prefix.data_ptr(),
-                                             slot_base.ctypes.data, id_base.ctypes.data))
+    if md.replicated:
+        _lib.check(md.lib.jb_source_photons_fill_range(pkg.ctx, md.handle, C.byref(md.sv), int(source_type),
+                                                       t_start, dt, nper.ctypes.data, md.prefix.data_ptr(),
+                                                       slot_base.ctypes.data, id_base.ctypes.data,
+                                                       first.ctypes.data, int(md.rank == 0)))
+    else:
+        _lib.check(md.lib.jb_source_photons_fill(pkg.ctx, md.handle, C.byref(md.sv), int(source_type),
+                                                 t_start, dt, nper.ctypes.data, md.prefix.data_ptr(),
+                                                 slot_base.ctypes.data, id_base.ctypes.data))
     md.sv.n += tot
     md.next_id += int(counts.sum())
     return TaskStatus.complete
@@ -440,6 +478,7 @@ def EvaluateRadiationEnergy(md: MeshData) -> TaskStatus:
     """reference jaybenne.cpp:514-564"""
     md._sync_stream()
     _lib.check(md.lib.jb_evaluate_radiation_energy(md.pkg.ctx, md.handle, C.byref(md.sv)))
+    _sum_over_ranks(md, ("tally",))
     return TaskStatus.complete
 
 
@@ -587,7 +626,7 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
             transport(md, t_start, dt, first, last, fuse_census_tally=True)
         md.transport_iterations += 1
         md.transport_iterations_total += 1
-        if md.nranks == 1 and not (md.force_exchange and md.comm is not None):
+        if (md.nranks == 1 or md.replicated) and not (md.force_exchange and md.comm is not None):
             break
         with _Phase(md, "exchange"):
             # the hand-off clock starts when the transport launch has finished (its first device
@@ -611,8 +650,11 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
     with _Phase(md, "compaction+fluid"):
         after = md.stats()
         md._stats_cache = after
-        if md.nranks == 1 and after["n_outgoing"] != before["n_outgoing"]:
-            raise RuntimeError("particles left for another rank in a single-rank step")
+        if (md.nranks == 1 or md.replicated) and after["n_outgoing"] != before["n_outgoing"]:
+            raise RuntimeError("particles left for another rank in a step that holds the whole mesh")
+        # replicated mesh: the one exchange of the cycle -- census tally and absorbed / emitted energy
+        # of all ranks' photons, summed on every rank (UpdateFluid then does the same on all of them)
+        _sum_over_ranks(md, ("tally", "edelta"))
         if any(after[k] != before[k] for k in ("n_absorbed", "n_escaped", "n_outgoing")):
             RemoveMarkedParticles(md)
         md.events += after["n_events"] - before["n_events"]

@@ -180,6 +180,60 @@ def UpdateDerived(rho: np.ndarray, u: np.ndarray) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------
+def block_costs(mesh: Mesh, pin: ParameterInput, pkg: McblockPackage) -> np.ndarray:
+    """Tracking work per meshblock for one cycle, in events: what ``Mesh.partition`` balances.
+
+    photons in the block x events per history there.  With the ``uniform`` source strategy every cell
+    sources the same number of photons whatever its temperature (reference sourcing.cpp:68-69,99-101:
+    ``npc = N / cells per block / nbtotal``; a cold cell's photons carry tiny weights but cost a
+    history each), so every block starts with N / nbtotal of them -- the stepdiff decks' hot half
+    holds the ENERGY, not the photons.  What differs between blocks is the length of a history:
+
+    * an IMC block (transport.cpp:98-171): collisions + face crossings along a path of c dt,
+      ``c dt (sigma_s + sigma_a + sum_d <|Omega_d|> / dx_d)``, ``<|Omega_d|> = 1/2``
+      (BASELINE configs[1]: 1000 + 3 * 128 = 1384; measured 1388.5);
+    * a DDMC block (``dx_push (sigma_a + sigma_s) > tau_ddmc``, transport_ddmc.cpp:135): one event per
+      leak or absorption, ``c dt (f sigma_a + sum_faces P / dx)`` with ``P = 2 / (3 (tau_l + tau_u))``
+      (jaybenne.cpp:381) -- a few dozen.
+    Material state as the problem generator sets it (rho0; the opacities of the decks are constants)."""
+    c = pkg.opacity.c
+    dt = pin.GetReal("jaybenne", "dt")
+    rho = pkg.initial_density
+    sig_a = rho * pkg.opacity.kappa
+    sig_s = (rho / pkg.scattering.apm) * pkg.scattering.kappa_s
+    use_ddmc = pin.GetOrAddBoolean("jaybenne", "use_ddmc", False)
+    tau_ddmc = pin.GetOrAddReal("jaybenne", "tau_ddmc", 5.0)
+    cost = np.empty(mesh.nblocks)
+    for b in range(mesh.nblocks):
+        dx = mesh.blk_dx[b, :mesh.ndim]
+        if use_ddmc and dx.min() * (sig_a + sig_s) > tau_ddmc:
+            leak = sum(2.0 * (2.0 / (3.0 * 2.0 * (sig_a + sig_s) * d)) / d for d in dx)
+            per_history = c * dt * (sig_a + leak)
+        else:
+            per_history = c * dt * (sig_s + sig_a + sum(0.5 / d for d in dx))
+        cost[b] = max(per_history, 1.0)
+    return cost
+
+
+def choose_decomposition(mesh: Mesh, cost: np.ndarray, nranks: int, device=None) -> str:
+    if nranks <= 1:
+        return "blocks"
+    field_bytes = 12 * 8 * mesh.nblocks * mesh.ntot          # every cell field of every block
+    try:
+        import torch
+        total = torch.cuda.get_device_properties(device).total_memory
+    except Exception:
+        total = 288 << 30
+    small = field_bytes * 64 <= total
+    owner = mesh.partition(nranks, cost=cost) if mesh.nblocks >= nranks else None
+    if owner is None:
+        return "replicated" if small else "blocks"
+    load = np.bincount(owner, weights=cost, minlength=nranks)
+    unbalanced = load.max() > 1.15 * load.mean()
+    return "replicated" if (small and unbalanced) else "blocks"
+
+
+# ------------------------------------------------------------------------------------------------
 # device-side driver (needs the HIP library; imported lazily so that the host-only helpers above
 # stay usable without a GPU)
 class McblockDriver:
@@ -189,20 +243,37 @@ class McblockDriver:
 
     def __init__(self, pin: ParameterInput, rank: int = 0, nranks: int = 1, comm=None,
                  device=None, capacity_factor: float = 1.3, mesh: Mesh = None,
-                 halo_rings: int = 1):
+                 halo_rings: int = 1, decomposition: str = "blocks"):
+        """``decomposition`` (several ranks): "blocks" -- the reference's: meshblocks dealt to ranks
+        (``Mesh.partition`` by the cost ``block_costs`` estimates), photons handed over where they
+        leave a rank's blocks; "replicated" -- every rank holds the whole mesh and follows its share
+        of every block's photons (``jaybenne.MeshData``: for meshes that fit every GPU many times
+        over); "auto" -- replicated when the mesh's fields take less than 1/64 of the device's memory
+        and its blocks are too few or too unequal to balance (< 8 per rank, or cost spread > 1.5)."""
         from . import jaybenne as jb
         self.jb = jb
         self.pin = pin
         self.mesh = mesh if mesh is not None else Mesh.from_deck(pin)
-        if nranks > 1:
-            self.mesh.partition(nranks)
         self.mcb = Initialize(pin)
         self.pkg = jb.Initialize(pin, self.mcb.opacity, self.mcb.scattering, self.mcb.eos,
                                  device=device, my_rank=rank)
-        n_local_blocks = int((self.mesh.owner == rank).sum())
-        share = self.pkg.Param("num_particles") * n_local_blocks / self.mesh.nblocks
+        cost = block_costs(self.mesh, pin, self.mcb)
+        if decomposition == "auto":
+            decomposition = choose_decomposition(self.mesh, cost, nranks, device)
+        if decomposition not in ("blocks", "replicated"):
+            raise ValueError("decomposition must be 'blocks', 'replicated' or 'auto'")
+        self.decomposition = decomposition if nranks > 1 else "blocks"
+        replicated = self.decomposition == "replicated"
+        if nranks > 1 and not replicated:
+            self.mesh.partition(nranks, cost=cost)
+        if replicated:
+            share = self.pkg.Param("num_particles") / nranks
+        else:
+            n_local_blocks = int((self.mesh.owner == rank).sum()) if nranks > 1 else self.mesh.nblocks
+            share = self.pkg.Param("num_particles") * n_local_blocks / self.mesh.nblocks
         capacity = int(share * capacity_factor) + 4096
-        self.md = jb.MeshData(self.pkg, self.mesh, capacity, rank, nranks, comm, halo_rings)
+        self.md = jb.MeshData(self.pkg, self.mesh, capacity, rank, nranks, comm, halo_rings,
+                              replicated=replicated)
         # (not a parameter of the reference: DefragParticles -- here a sort of the swarm by cell, for
         # the locality of the cell gathers -- after every k-th cycle; 0 = never, as the reference)
         self.md.defrag_interval = pin.GetOrAddInteger("jaybenne", "defrag_interval", -1)

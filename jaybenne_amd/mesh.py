@@ -371,15 +371,93 @@ class Mesh:
         return np.array(sorted(have - set(int(g) for g in gids)), dtype=np.int32)
 
     # ------------------------------------------------------------------ partition
-    def partition(self, nranks: int) -> np.ndarray:
-        """Contiguous runs of the Z-ordered block list per rank (Parthenon's default load
-        balance with unit cost per block).  Returns ``owner[b]``."""
+    def sibling_groups(self) -> np.ndarray:
+        """``group[b]``: the same number for the blocks that are children of one parent and follow each
+        other in the Z-ordered list (a refined block's 2^ndim children), a number of its own for every
+        other block."""
+        group = np.empty(self.nblocks, dtype=np.int64)
+        g = -1
+        prev = None
+        for b, (lev, lx) in enumerate(self.leaves):
+            key = (lev, tuple(lx[d] >> 1 if d < self.ndim else 0 for d in range(3))) if lev > 0 else None
+            if key is None or key != prev:
+                g += 1
+            group[b] = g
+            prev = key
+        return group
+
+    def partition(self, nranks: int, cost: Optional[Sequence[float]] = None,
+                  sibling_slack: float = 0.10) -> np.ndarray:
+        """Contiguous runs of the Z-ordered block list per rank.  Returns ``owner[b]``.
+
+        ``cost=None``: unit cost per block, runs of equal length (Parthenon's default load balance:
+        the reference inherits it, jaybenne.cpp:92-95).  With a cost per block -- the tracking work
+        ``mcblock.block_costs`` estimates: photons sourced there x events per history -- the runs are
+        the contiguous split with the SMALLEST LARGEST load (a cycle lasts as long as its slowest
+        rank), found exactly by dynamic programming over the prefix sums; then every boundary that
+        separates the children of one parent moves to the nearer end of that family if the largest load
+        stays within ``1 + sibling_slack`` of the optimum (children of one parent exchange the most
+        photons).  ``include/jaybenne_amd.hpp: PartitionBlocks`` is the same algorithm for the C++
+        hosts, operation for operation."""
         nb = self.nblocks
         if nranks > nb:
             raise ValueError(f"cannot spread {nb} blocks over {nranks} ranks")
-        bounds = [(r * nb) // nranks for r in range(nranks + 1)]
+        if cost is None:
+            bounds = [(r * nb) // nranks for r in range(nranks + 1)]
+        else:
+            bounds = partition_bounds(np.asarray(cost, dtype=np.float64), nranks, self.sibling_groups(),
+                                      sibling_slack)
         owner = np.empty(nb, dtype=np.int32)
         for r in range(nranks):
             owner[bounds[r]:bounds[r + 1]] = r
         self.owner = owner
         return owner
+
+
+def partition_bounds(cost: np.ndarray, nranks: int, group: np.ndarray, sibling_slack: float = 0.10):
+    """``bounds[r] .. bounds[r + 1]`` = the blocks of rank r: see ``Mesh.partition``."""
+    nb = len(cost)
+    if np.any(cost <= 0.0) or not np.all(np.isfinite(cost)):
+        raise ValueError("block costs must be positive and finite")
+    S = np.concatenate(([0.0], np.cumsum(cost)))          # sequential sums (the C++ host forms the same)
+    # best[r][i]: smallest largest load of blocks [0, i) in r + 1 runs; cut[r][i]: where the last run starts
+    best = np.full((nranks, nb + 1), np.inf)
+    cut = np.zeros((nranks, nb + 1), dtype=np.int64)
+    best[0, 1:] = S[1:]
+    for r in range(1, nranks):
+        for i in range(r + 1, nb + 1):
+            j = np.arange(r, i)
+            v = np.maximum(best[r - 1, r:i], S[i] - S[r:i])
+            k = int(np.argmin(v))                          # (the first of equal minima)
+            best[r, i] = v[k]
+            cut[r, i] = j[k]
+    bounds = [0] * (nranks + 1)
+    bounds[nranks] = nb
+    for r in range(nranks - 1, 0, -1):
+        bounds[r] = int(cut[r, bounds[r + 1]])
+    optimum = float(best[nranks - 1, nb])
+
+    def largest(bd):
+        return max(S[bd[r + 1]] - S[bd[r]] for r in range(nranks))
+
+    for r in range(1, nranks):
+        q = bounds[r]
+        if group[q - 1] != group[q]:
+            continue                                       # not inside a family
+        lo = q
+        while lo > 0 and group[lo - 1] == group[q]:
+            lo -= 1
+        hi = q
+        while hi < nb and group[hi] == group[q]:
+            hi += 1
+        tries = []
+        for cand in (lo, hi):
+            if bounds[r - 1] < cand < bounds[r + 1]:
+                bd = list(bounds)
+                bd[r] = cand
+                tries.append((largest(bd), abs(cand - q), cand))
+        if tries:
+            load, _, cand = min(tries)
+            if load <= (1.0 + sibling_slack) * optimum:
+                bounds[r] = cand
+    return bounds

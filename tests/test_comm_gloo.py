@@ -68,6 +68,18 @@ def _worker(rank, world, port, out):
         allc = comm.allreduce_sum_int64(counts)
         assert np.array_equal(allc, 100 + np.arange(mesh.nblocks))
         assert comm.allreduce_max_float(float(rank)) == 1.0
+        # 5. replicated mesh, split particles: the ranks' shares of every block's new photons tile the
+        # block exactly, and the one exchange of a cycle -- the sum of the ranks' cell fields -- leaves
+        # the same bits on every rank
+        from jaybenne_amd.jaybenne import rank_share
+        nper = np.array([1000003, 0, 7, 64], dtype=np.int32)
+        first, cnt = rank_share(nper, rank, world)
+        ends = comm.allreduce_sum_int64(cnt.astype(np.int64))
+        assert np.array_equal(ends, nper)
+        assert np.array_equal(first, (nper.astype(np.int64) * rank) // world)
+        field = torch.full((3, 5), 0.1 * (rank + 1), dtype=torch.float64)
+        comm.allreduce_sum_tensor(field)
+        assert torch.equal(field, torch.full((3, 5), 0.1, dtype=torch.float64) + torch.full((3, 5), 0.2, dtype=torch.float64))
         # a rank never sends to itself
         with pytest.raises(ValueError):
             bad = np.zeros(world, dtype=np.int64)

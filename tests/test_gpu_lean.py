@@ -226,3 +226,23 @@ def test_lean_against_exact_over_ten_cycles(gpu_device):
     moved = (~same) & ((g["ip"] != h["ip"]) | (g["jp"] != h["jp"]) | (g["kp"] != h["kp"]) | (g["blk"] != h["blk"]))
     allow = 1e-9 * np.abs(te[sl]).max() + 2.0 * w / dv * max(int(moved.sum()), 0)
     assert np.abs(tl[sl] - te[sl]).max() <= allow
+
+
+def test_wide_flat_block_does_not_run_the_cell_local_kernel(gpu_device):
+    """A 3-D block with ni * nj >= 2^20 (1020 x 1020 x 4 cells): the byte stride 8 ni nj of the cell-local
+    step no longer fits the 24-bit multiply-add that forms the photon's cell offset, so
+    jb_mesh_create keeps such a mesh on the x-space lean kernel -- same tolerance against the oracle."""
+    from oracle import orc
+    ov = {"parthenon/mesh/nx1": 1020, "parthenon/mesh/nx2": 1020, "parthenon/mesh/nx3": 4,
+          "parthenon/meshblock/nx1": 1020, "parthenon/meshblock/nx2": 1020, "parthenon/meshblock/nx3": 4,
+          "jaybenne/num_particles": 20000}
+    pin = load_deck("stepdiff", ov)
+    drv = _gpu_problem(pin, gpu_device)
+    assert drv.pkg.arithmetic() == "lean"
+    O, mesh, _ = make_oracle(load_deck("stepdiff", ov), orc.MATH_PORTABLE)
+    drv.Step()
+    run_oracle_cycles(O, pin, 1)
+    variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
+    assert "k_imc_cell" not in variant and variant.endswith("true>"), variant
+    assert drv.md.n == O.n and drv.md.events == O.events
+    _compare_within_tolerance(drv.md.get_swarm(), O.sw, O.n, mesh, pin.GetReal("jaybenne", "dt"))

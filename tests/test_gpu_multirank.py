@@ -38,7 +38,22 @@ CASES = [
     # DefragParticles (every rank sorts its part of the swarm by block and cell) after every cycle:
     # arrivals are appended behind a sorted swarm, local block indices include the halo copies
     ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 20000, "jaybenne/defrag_interval": 1}, 3),
+    # BASELINE configs[4]'s mesh: the hybrid deck with the nested level-2 region (32 blocks, 3 levels;
+    # coarse cells DDMC, both finer levels IMC), as bench.py --workload c5 builds it
+    ("stepdiff_smr_hybrid", {"jaybenne/num_particles": 30000, "_level2": True}, 2),
 ]
+LEVEL2 = ("<parthenon/static_refinement2>\nlevel = 2\nx1min = -0.125\nx1max = 0.125\n"
+          "x2min = -0.125\nx2max = 0.125\nx3min = -0.25\nx3max = 0.25\n")
+
+
+def _deck(case):
+    deck, ov, cycles = CASES[case]
+    ov = dict(ov)
+    level2 = ov.pop("_level2", False)
+    pin = load_deck(deck, ov)
+    if level2:
+        pin.load_string(LEVEL2)
+    return pin, cycles
 
 
 
@@ -69,7 +84,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, outdir):
+def _worker(rank, world, port, case, outdir, decomposition="blocks"):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -77,16 +92,20 @@ def _worker(rank, world, port, case, outdir):
     try:
         from jaybenne_amd import mcblock
         from jaybenne_amd.comm import Comm
-        deck, ov, cycles = CASES[case]
-        drv = mcblock.McblockDriver(load_deck(deck, ov), rank=rank, nranks=world, comm=Comm(),
-                                    device=torch.device("cuda", 0), capacity_factor=2.0)
+        pin, cycles = _deck(case)
+        drv = mcblock.McblockDriver(pin, rank=rank, nranks=world, comm=Comm(),
+                                    device=torch.device("cuda", 0), capacity_factor=2.0,
+                                    decomposition=decomposition)
+        assert drv.decomposition == decomposition
+        n0 = drv.md.n
         for _ in range(cycles):
             drv.Step()
         g = drv.md.get_swarm()
         g["gblk"] = drv.md.gids[g["blk"]]
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), tally=drv.md.get_field("tally"),
-                 gids=drv.md.gids, events=np.array([drv.md.events]),
-                 outgoing=np.array([drv.md.stats()["n_outgoing"]]), **g)
+                 gids=drv.md.gids, events=np.array([drv.md.events]), sourced=np.array([n0]),
+                 outgoing=np.array([drv.md.stats()["n_outgoing"]]),
+                 iterations=np.array([drv.md.transport_iterations_total]), **g)
     finally:
         dist.destroy_process_group()
 
@@ -115,19 +134,46 @@ def test_five_ranks_equal_the_oracle(gpu_device, case, tmp_path):
     _ranks_equal_the_oracle(case, 5, tmp_path)
 
 
-def _ranks_equal_the_oracle(case, world, tmp_path):
+@pytest.mark.parametrize("case,world", [(9, 4), (9, 2)])
+def test_three_level_hybrid_mesh_across_ranks(gpu_device, case, world, tmp_path):
+    """BASELINE configs[4]'s 3-level mesh (32 blocks) split over 4 and 2 ranks by Mesh.partition with the
+    cost of mcblock.block_costs (a DDMC block costs 1 % of an IMC block): level changes, DDMC / IMC
+    interfaces and rank boundaries coincide; the union of the ranks' photons equals the oracle."""
+    _ranks_equal_the_oracle(case, world, tmp_path)
+
+
+@pytest.mark.parametrize("case,world", [(3, 2), (9, 4), (6, 4), (8, 3), (1, 2)])
+def test_replicated_mesh_split_particles_equals_the_oracle(gpu_device, case, world, tmp_path):
+    """SURVEY 8e's other decomposition (jaybenne.MeshData(replicated=True)): every rank holds the whole
+    mesh and sources its share of every block's photons (jb_source_photons_fill_range), one transport
+    iteration per cycle, nothing handed over, the ranks' tallies summed by one all-reduce.  The
+    histories are the single-process ones bit for bit (a photon's stream and every field it reads do
+    not depend on which rank follows it); every rank ends with the whole tally; every rank sources
+    1 / world of the photons to within one photon per block."""
+    _ranks_equal_the_oracle(case, world, tmp_path, decomposition="replicated")
+
+
+def _ranks_equal_the_oracle(case, world, tmp_path, decomposition="blocks"):
     from oracle import orc
     sys.path.insert(0, os.path.dirname(__file__))
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, str(tmp_path), decomposition))
+             for r in range(world)]
     _run_workers(procs)
-    deck, ov, cycles = CASES[case]
-    pin = load_deck(deck, ov)
+    pin, cycles = _deck(case)
     O, mesh, _ = make_oracle(pin, orc.MATH_PORTABLE)
+    n_sourced = O.n
     run_oracle_cycles(O, pin, cycles)
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
-    assert sum(int(p["outgoing"][0]) for p in parts) > 0, "the case must exercise the hand-off"
+    if decomposition == "replicated":
+        assert all(int(p["outgoing"][0]) == 0 for p in parts)
+        assert all(int(p["iterations"][0]) == cycles for p in parts)       # one transport launch per cycle
+        assert all(len(p["gids"]) == mesh.nblocks for p in parts)
+        share = np.array([int(p["sourced"][0]) for p in parts])
+        assert share.sum() == n_sourced and np.all(np.abs(share - n_sourced / world) <= mesh.nblocks)
+    else:
+        assert sum(int(p["outgoing"][0]) for p in parts) > 0, "the case must exercise the hand-off"
     ids = np.concatenate([p["id"] for p in parts])
     order = np.argsort(ids)
     oo = np.argsort(O.sw["id"][:O.n])
@@ -156,12 +202,12 @@ def test_lean_arithmetic_does_not_depend_on_the_partition(gpu_device, case, tmp_
     from jaybenne_amd import mcblock
     from test_gpu_lean import _compare_within_tolerance
     sys.path.insert(0, os.path.dirname(__file__))
-    deck, ov, cycles = CASES[case]
+    pin, cycles = _deck(case)
     ctx = mp.get_context("spawn")
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, case, str(tmp_path))) for r in range(2)]
     _run_workers(procs)
-    drv = mcblock.McblockDriver(load_deck(deck, ov), device=gpu_device)
+    drv = mcblock.McblockDriver(pin, device=gpu_device)
     assert drv.pkg.arithmetic() == "lean"
     for _ in range(cycles):
         drv.Step()
@@ -173,7 +219,7 @@ def test_lean_arithmetic_does_not_depend_on_the_partition(gpu_device, case, tmp_
     assert np.array_equal(ids[order], one["id"][o1])
     for k in ("x", "y", "z", "vx", "vy", "vz", "t", "w", "e", "ip", "jp", "kp", "rng"):
         assert np.array_equal(np.concatenate([p[k] for p in parts])[order], one[k][o1]), k
-    pin = load_deck(deck, ov)
+    pin, _ = _deck(case)
     O, mesh, _ = make_oracle(pin, orc.MATH_PORTABLE)
     run_oracle_cycles(O, pin, cycles)
     _compare_within_tolerance(one, O.sw, O.n, mesh, pin.GetReal("jaybenne", "dt"), by_id=True)
@@ -184,7 +230,7 @@ FEEDBACK = dict(SMR, **{"jaybenne/num_particles": 30000, "jaybenne/do_emission":
                         "mcblock/opacity_constant_value": 20.0})
 
 
-def _feedback_worker(rank, world, port, outdir):
+def _feedback_worker(rank, world, port, outdir, decomposition="blocks"):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -194,8 +240,9 @@ def _feedback_worker(rank, world, port, outdir):
         from jaybenne_amd.comm import Comm
         drv = mcblock.McblockDriver(load_deck("stepdiff_smr_hybrid", FEEDBACK), rank=rank,
                                     nranks=world, comm=Comm(), device=torch.device("cuda", 0),
-                                    capacity_factor=8.0)
-        assert len(drv.md.resident_gids) > drv.md.nowned        # halo copies are in use
+                                    capacity_factor=8.0, decomposition=decomposition)
+        if decomposition == "blocks":
+            assert len(drv.md.resident_gids) > drv.md.nowned        # halo copies are in use
         for _ in range(3):
             drv.Step()
         g = drv.md.get_swarm()
@@ -241,6 +288,39 @@ def test_two_ranks_with_material_feedback(gpu_device, tmp_path):
         sl = mesh.interior()
         np.testing.assert_allclose(p["fleck"][sl], O.fields["fleck"][p["gids"]][sl], rtol=1e-12)
         np.testing.assert_allclose(p["tally"][sl], O.fields["tally"][p["gids"]][sl], rtol=1e-11)
+
+
+def test_replicated_mesh_with_material_feedback(gpu_device, tmp_path):
+    """The same absorbing / emitting problem with the mesh replicated on three ranks: every rank sources
+    its share of every cell's emission photons, rank 0 alone books the emitted energy, absorption adds
+    to each rank's own energy_delta, ONE all-reduce sums them, and UpdateFluid then forms the same
+    internal energy on every rank (the ranks' u arrays are equal bit for bit -- the all-reduce gives
+    every rank the same sum; against the oracle 1e-12: the order of the sum)."""
+    from oracle import orc
+    sys.path.insert(0, os.path.dirname(__file__))
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_feedback_worker, args=(r, 3, port, str(tmp_path), "replicated")) for r in range(3)]
+    _run_workers(procs)
+    pin = load_deck("stepdiff_smr_hybrid", FEEDBACK)
+    O, mesh, _ = make_oracle(pin, orc.MATH_PORTABLE, capacity_factor=8.0)
+    O.emission_blocks_in_call = mesh.nblocks          # (sourcing.cpp:68-69: the whole mesh in one MeshData)
+    run_oracle_cycles(O, pin, 3)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(3)]
+    ids = np.concatenate([p["id"] for p in parts])
+    order = np.argsort(ids)
+    oo = np.argsort(O.sw["id"][:O.n])
+    assert len(ids) == O.n and np.array_equal(ids[order], O.sw["id"][:O.n][oo])
+    for k in ("ip", "jp", "kp", "rng"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts])[order], O.sw[k][:O.n][oo]), k
+    for k in ("x", "y", "z", "vx", "vy", "vz", "t", "w", "e"):
+        got = np.concatenate([p[k] for p in parts])[order]
+        np.testing.assert_allclose(got, O.sw[k][:O.n][oo], rtol=1e-11, atol=0, err_msg=k)
+    sl = mesh.interior()
+    for p in parts:
+        assert np.array_equal(p["u"], parts[0]["u"])
+        np.testing.assert_allclose(p["u"], O.fields["u"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(p["tally"][sl], O.fields["tally"][sl], rtol=1e-11)
 
 
 def _read_photon_dumps(prefix, nranks):

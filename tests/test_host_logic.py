@@ -262,3 +262,50 @@ def test_mcblock_unit_scales_and_epbremss_deck():
     assert pkg.opacity.model == mcblock.OPAC_EPBREMSS and pkg.opacity.mass_scale == 3.0
     with pytest.raises(ValueError, match="scattering models"):
         mcblock.Initialize(load_deck("stepdiff", {"mcblock/scattering_model": "thomson"}))
+
+
+@pytest.mark.parametrize("workload,nranks", [("c4", 4), ("c5", 8)])
+def test_photon_and_work_share_per_rank_on_the_smr_configs(workload, nranks):
+    """BASELINE configs[3] on 4 and configs[4] on 8 ranks.  With the `uniform` source
+    strategy every CELL sources the same number of photons whatever its temperature (reference
+    sourcing.cpp:68-69, 99-101): the hot half x < 0 of the stepdiff decks (mcblock.cpp:187-199) holds the
+    energy, not the photons -- counted here on the oracle's initial source.  So every contiguous split of
+    the 20 / 32 equal-size blocks gives every rank its 1 / N of the photons; what a block COSTS differs
+    (events per history: a DDMC block of configs[4] 22, an IMC block 1256 or 1512), and that is what
+    Mesh.partition balances and what the replicated-mesh mode removes from the question."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from jaybenne_amd import mcblock
+    from jaybenne_amd.jaybenne import rank_share
+    from jaybenne_amd.mesh import Mesh
+    from oracle import orc
+    from oracle.harness import make_oracle
+    pin = bench.make_deck(nranks, 25000, workload=workload)
+    O, mesh, pkg = make_oracle(pin, orc.MATH_PORTABLE)
+    per_block = np.bincount(O.sw["blk"][:O.n], minlength=mesh.nblocks)
+    x = O.sw["x"][:O.n]
+    assert 0.45 < (x < 0).mean() < 0.55                       # half of the photons are COLD ones
+    assert per_block.min() > 0.9 * O.n / mesh.nblocks         # every block sources its share
+    cost = mcblock.block_costs(mesh, pin, pkg)
+    owner = mesh.partition(nranks, cost=cost)
+    assert np.all(np.diff(owner) >= 0) and len(np.unique(owner)) == nranks          # contiguous runs, none empty
+    photons = np.bincount(owner, weights=per_block, minlength=nranks) / O.n
+    assert np.all(np.abs(photons - 1.0 / nranks) <= 0.15 / nranks + 1.0 / mesh.nblocks), photons
+    work = np.bincount(owner, weights=cost, minlength=nranks)      # (equal photon counts per block)
+    unit = np.bincount(mesh.partition(nranks), weights=cost, minlength=nranks)
+    # (the optimum of the contiguous splits, up to the 10 % a boundary may cost to keep siblings together)
+    assert work.max() <= 1.10 * unit.max()
+    # 32 blocks of three costs over 8 ranks cannot be balanced by any contiguous split (4 / 3.5 = 1.14 at
+    # best): the replicated mode deals every block's photons out evenly instead
+    shares = np.array([rank_share(per_block.astype(np.int32), r, nranks)[1] for r in range(nranks)])
+    assert np.array_equal(shares.sum(axis=0), per_block)
+    rep_work = (shares * cost[None, :]).sum(axis=1)
+    assert rep_work.max() <= 1.01 * rep_work.mean()
+    if workload == "c5":
+        assert work.max() > 1.10 * work.mean()
+        assert mcblock.choose_decomposition(mesh, cost, nranks) == "replicated"
+    else:
+        assert work.max() <= 1.02 * work.mean()
+        assert mcblock.choose_decomposition(mesh, cost, nranks) == "blocks"
