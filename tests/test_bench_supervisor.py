@@ -58,7 +58,12 @@ def test_rank_killed_mid_run_ends_in_a_diagnostic_and_nonzero_exit_not_a_hang():
     assert res.returncode != 0
     assert not lines
     assert wall < 120.0
+    # the culprit, not a victim (rank 0's worker breaks on "connection reset by peer" a moment later), is
+    # the attempt's reason: first failure wins; every rank's own reason is listed, and the per-rank logs
+    # carry the worker's last words
+    assert "failed (rank 1: worker exit code 17)" in res.stderr, res.stderr[-3000:]
     assert "rank 1: worker exit code 17" in res.stderr and "dies at step 2" in res.stderr
+    assert "[supervisor] worker exit code 17" in res.stderr
 
 
 def test_hung_rank_is_cut_off_by_the_budget():
