@@ -41,11 +41,13 @@ FLOPS_PER_EVENT = 200.0      # FP64 flop-equivalents per IMC event
 
 
 def block_grid(ngpus: int):
-    """Blocks of the weak-scaled headline mesh.  The stepdiff initial condition puts the photons
-    into the hot half x < 0, so the domain keeps its four block columns in x and grows in the
-    periodic directions y and z: every rank's contiguous Z-order range is then a 4 x 4 x 4 cube of
-    blocks with 32 hot and 32 cold ones -- the one-GPU problem, coupled to its neighbours through
-    the particle hand-off (growing in x instead would leave every other rank without photons)."""
+    """Blocks of the weak-scaled headline mesh.  The domain keeps its four block columns in x (the axis
+    of the stepdiff temperature step and of the reflecting walls) and grows in the periodic directions y
+    and z: every rank's contiguous Z-order range is then a 4 x 4 x 4 cube of blocks with 32 hot and 32
+    cold ones -- the one-GPU problem, coupled to its neighbours through the particle hand-off.  (Every
+    block starts with the same number of photons whatever its temperature -- the `uniform` source
+    strategy, reference sourcing.cpp:68-69 -- so the ranks' photon counts are equal either way; growing
+    in x would give every other rank a problem without the step in it.)"""
     return {1: (4, 4, 4), 2: (4, 8, 4), 4: (4, 8, 8), 8: (4, 16, 8)}.get(ngpus) or (4, 4 * ngpus, 4)
 
 
@@ -607,7 +609,7 @@ def main() -> None:
         # counters of this very command under rocprofv3 (separate --pmc passes), if a committed
         # summary matches workload and size: labelled as read from that file, not measured now
         pmc, pmc_file = None, None
-        for rnd in ("r04", "r04_exact", "r03", "r03_exact", "r02", "r02_exact", "r01_g"):
+        for rnd in ("r05", "r05_exact", "r04", "r04_exact", "r03", "r03_exact", "r02", "r02_exact", "r01_g"):
             f = os.path.join(ROOT, "profiles", f"{rnd.split('_exact')[0]}_pmc_summary_{args.workload}"
                                                f"{'_exact' if rnd.endswith('_exact') else ''}.json")
             try:

@@ -339,10 +339,14 @@ jb_status jb_defrag_particles(jb_context *ctx, jb_mesh *mesh, const jb_swarm_vie
  * at least 2^20 photons in the swarm.  A sort after which the next cycle is not at least 1 % faster
  * was not what the kernels needed: the minimum distance between sorts doubles (2, 4, .. 256 cycles)
  * until one pays
- * again.  The sort's scratch records (128 bytes per photon) are allocated at the first call with
- * at least 2^20 photons, not in the cycle that first sorts; jb_release_scratch returns them.
- * Slot order only affects speed, never results; defrag_interval = 0 in the hosts keeps the
- * order of the reference (never sorted), k > 0 sorts after every k-th cycle.
+ * again.  The sort's scratch records (128 bytes per photon) are allocated when the cycles first slow down
+ * by 0.5 % (at least a cycle before a sort can be decided, so that the allocation -- ~30 ms per GB -- does
+ * not land in the sorting cycle; a run whose swarm keeps its order never allocates them);
+ * jb_release_scratch returns them.
+ * Slot order only affects speed, never results -- but under this schedule WHEN the swarm is sorted
+ * depends on measured times, so the order of the slots (not what any photon carries: compare photons by
+ * their creation id) differs from run to run; defrag_interval = 0 in the hosts keeps the order of the
+ * reference (never sorted, reproducible slot for slot), k > 0 sorts after every k-th cycle.
  * The caller must have synchronised the stream since the cycle's last transport call.
  * mode: JB_DEFRAG_DECIDE_AND_SORT for a host that holds the whole swarm.  Several ranks sort
  * TOGETHER (a cycle is as long as its slowest rank: a sort on one rank per cycle, in turn, would be
@@ -434,8 +438,12 @@ double jb_estimate_timestep(const jb_context *ctx);
 /* RadiationStep(pmesh, t_start, dt) for a mesh held by ONE rank -- jaybenne.hpp:72,
  * jaybenne.cpp:68-151: derived fields, emission source, transport to completion, census tally,
  * fluid update.  next_id: first unused stream id (updated); cycle: the number of radiation cycles
- * taken so far (0 after initialisation; incremented at entry) -- the emission source of cycle k keys
- * its per-cell rounding streams with epoch k, as every host does (jaybenne_amd.hpp: SourceEpoch). */
+ * taken so far (0 after initialisation; incremented at ENTRY) -- the emission source of cycle k keys
+ * its per-cell rounding streams with epoch k, as every host does (jaybenne_amd.hpp: SourceEpoch).
+ * (Changed in round 4: the counter used to be a source-call counter incremented AFTER the source; a
+ * caller that still passes 1 for the first cycle gets epoch 2 and different -- equally valid -- rounding
+ * streams than the other hosts.  JB_ERR_INVALID for *cycle >= 2^19 - 1: beyond that the keys of the
+ * emission and the in-cycle thermal source, (1 << 19) | cycle, would meet.) */
 jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm, double t_start,
                             double dt, uint64_t *next_id, uint32_t *cycle, int32_t *prefix_dev);
 

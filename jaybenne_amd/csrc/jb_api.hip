@@ -54,6 +54,7 @@ struct jb_context {
   unsigned long long *counters_d = nullptr;   // CNT_N + 2 cursors + per-rank counters
   unsigned long long *counters_h = nullptr;   // pinned
   long long *scratch_d = nullptr;             // holes / movers / small tables
+  bool scratch_alloc_failed = false;          // set by ensure_scratch when hipMalloc itself said no
   std::vector<unsigned long long> xch_matrix;  // jb_exchange: the rank x rank record counts (host copy)
   std::vector<long long> xch_tab;             // ... this rank's send / receive counts and offsets
   size_t scratch_words = 0;
@@ -134,7 +135,14 @@ static jb_status ensure_scratch(jb_context *ctx, size_t words, bool slack = true
   ctx->scratch_d = nullptr;
   ctx->scratch_words = 0;
   const size_t want = slack ? words + words / 4 + 1024 : words + 16;
-  JB_HIP(hipMalloc(&ctx->scratch_d, want * sizeof(long long)));
+  const hipError_t e = hipMalloc(&ctx->scratch_d, want * sizeof(long long));
+  if (e != hipSuccess) {   // (told apart from every other failure: DefragParticles may go without its scratch)
+    ctx->scratch_d = nullptr;
+    ctx->scratch_alloc_failed = true;
+    (void)hipGetLastError();
+    return fail(JB_ERR_HIP, "hipMalloc of %zu bytes of scratch memory failed: %s", want * sizeof(long long),
+                hipGetErrorString(e));
+  }
   ctx->scratch_words = want;
   return JB_COMPLETE;
 }
@@ -1065,9 +1073,9 @@ extern "C" jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats 
   stats->n_wave_passes = (int64_t)ctx->counters_h[CNT_PASSES];
   stats->n_wave_services = (int64_t)ctx->counters_h[CNT_SERVICE];
 #ifdef JB_TIMING  // (diagnostic build: wave-cycles / 1024 per sub-phase of k_ddmc_all's service phase)
-  fprintf(stderr, "JB_TIMING phases reloc %llu claim %llu done %llu take %llu real %llu\n",
+  fprintf(stderr, "JB_TIMING phases reloc %llu claim %llu done %llu take %llu real %llu | episodes %llu passes %llu services %llu\n",
           ctx->counters_h[24], ctx->counters_h[25], ctx->counters_h[26], ctx->counters_h[27],
-          ctx->counters_h[28]);
+          ctx->counters_h[28], ctx->counters_h[29], ctx->counters_h[30], ctx->counters_h[31]);
 #endif
 #ifdef JB_HYB_STATS  // (diagnostic build of k_hybrid: see jb_kernel_hybrid.hpp)
   {
@@ -1253,8 +1261,11 @@ static jb_status defrag_now(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view 
     JB_HIP(hipEventCreate(&ctx->sort_ev[1]));
   }
   (void)hipEventRecord(ctx->sort_ev[0], ctx->stream);
+  ctx->scratch_alloc_failed = false;
   jb_status st = jb_defrag_particles(ctx, mesh, swarm);
-  if (st == JB_ERR_HIP) {  // (no room for the sort's scratch records: the run goes on unsorted)
+  // (only "no room for the sort's scratch records" lets the run go on unsorted: any other failure -- a
+  // launch or a kernel of the sort itself -- may have left the swarm partly permuted and is the caller's)
+  if (st == JB_ERR_HIP && ctx->scratch_alloc_failed) {
     fprintf(stderr, "jaybenne_amd: DefragParticles skipped (%s)\n", g_err);
     (void)hipGetLastError();
     ctx->min_interval = 256;
@@ -1318,10 +1329,21 @@ extern "C" jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_s
     ctx->sort_timed = false;
   }
   if (!ok || events_this_cycle <= 0 || swarm->n < (1ll << 20)) return JB_COMPLETE;
-  // The sort's scratch records (128 bytes per photon; a fresh allocation costs ~30 ms per GB) are
-  // asked for at the FIRST call, not in the cycle that first sorts: a run pays for them at its start,
-  // and one that has no room for them learns so there (the schedule is then off, as below).
-  if (!ctx->sort_scratch_tried) {
+  const double rate = ms / (double)events_this_cycle;
+  ++ctx->cycles_since_sort;
+  if (ctx->cycles_since_sort == 1 && ctx->rate_before_sort > 0.0) {
+    // the first cycle behind a sort: did it pay?  If the rate came down by less than 1 % (timing
+    // noise between cycles is ~0.3 %), what made the kernels slower was not the order of the swarm
+    // -- wait twice as long before the next one
+    if (rate > 0.99 * ctx->rate_before_sort) ctx->min_interval = ctx->min_interval < 256 ? 2 * ctx->min_interval : 256;
+    else ctx->min_interval = 2;
+    ctx->rate_before_sort = 0.0;
+  }
+  // The sort's scratch records (128 bytes per photon; a fresh allocation costs ~30 ms per GB, which must not
+  // land in the cycle that first sorts: 400 ms on BASELINE configs[2]) are asked for as soon as the cycles
+  // START to slow down (0.5 %: at least one cycle before the 1.5 % a sort needs) -- a run whose swarm keeps
+  // its order never allocates them (12.8 GB at 1e8 photons); one that has no room learns so here.
+  if (!ctx->sort_scratch_tried && ctx->rate_ref > 0.0 && rate > 1.005 * ctx->rate_ref) {
     ctx->sort_scratch_tried = true;
     const DevMesh &M0 = mesh->dm;
     const unsigned long long nbins0 = (unsigned long long)M0.nblocks * (unsigned long long)M0.ntot + 1ull;
@@ -1334,16 +1356,6 @@ extern "C" jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_s
         ctx->min_interval = 256;
       }
     }
-  }
-  const double rate = ms / (double)events_this_cycle;
-  ++ctx->cycles_since_sort;
-  if (ctx->cycles_since_sort == 1 && ctx->rate_before_sort > 0.0) {
-    // the first cycle behind a sort: did it pay?  If the rate came down by less than 1 % (timing
-    // noise between cycles is ~0.3 %), what made the kernels slower was not the order of the swarm
-    // -- wait twice as long before the next one
-    if (rate > 0.99 * ctx->rate_before_sort) ctx->min_interval = ctx->min_interval < 256 ? 2 * ctx->min_interval : 256;
-    else ctx->min_interval = 2;
-    ctx->rate_before_sort = 0.0;
   }
   if (ctx->rate_ref == 0.0 || rate < ctx->rate_ref) ctx->rate_ref = rate;
   const double excess_now = (rate - ctx->rate_ref) * (double)events_this_cycle;
@@ -1652,6 +1664,8 @@ extern "C" jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_
   const DevMesh &M = mesh->dm;
   if (M.nblocks != M.nblocks_total || mesh->nranks_seen != 1)
     return fail(JB_ERR_INVALID, "jb_radiation_step needs the whole mesh on one rank");
+  if (*cycle >= (1u << 19) - 1u)   // (SourceEpoch: emission keys k and in-cycle thermal keys (1 << 19) | k must not meet)
+    return fail(JB_ERR_INVALID, "jb_radiation_step: cycle counter %u at the limit of the source epochs (2^19 - 1)", *cycle);
   *cycle += 1;   // (keys the per-cell rounding streams of this cycle's emission source: SourceEpoch)
   jb_status st = jb_update_derived_transport_fields(ctx, mesh, dt);
   if (st != JB_COMPLETE) return st;

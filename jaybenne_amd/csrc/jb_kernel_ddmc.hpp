@@ -293,6 +293,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   };
 
 #ifdef JB_TIMING
+  unsigned c_epi = 0;   // event-loop episodes (entries of the loop): services per episode = c_service / c_epi
   unsigned long long cyc_ev = 0, cyc_sv = 0, cyc_mark = __builtin_readcyclecounter();
   unsigned long long cyc_ph[6] = {0, 0, 0, 0, 0, 0}, ph_mark = 0;  // reloc, claim, done, take, real, tail
 #define JB_PH(k) { const unsigned long long now_ = __builtin_readcyclecounter(); cyc_ph[k] += now_ - ph_mark; ph_mark = now_; }
@@ -618,6 +619,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
 #ifdef JB_TIMING
     { const unsigned long long now = __builtin_readcyclecounter(); cyc_sv += now - cyc_mark; cyc_mark = now; }
 #endif
+#ifdef JB_TIMING
+    ++c_epi;
+#endif
     int thresh = 1;
     int nrun = running;
     // One DDMC step per running lane and pass (transport_utils.hpp:163-263 on the virtual state), as
@@ -787,7 +791,10 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
 #ifdef JB_TIMING
     atomicAdd(&counters[CNT_PASSES], cyc_ev >> 10);
     atomicAdd(&counters[CNT_SERVICE], cyc_sv >> 10);
-    for (int k = 0; k < 6; ++k) atomicAdd(&counters[24 + k], cyc_ph[k] >> 10);  // (scratch words)
+    for (int k = 0; k < 5; ++k) atomicAdd(&counters[24 + k], cyc_ph[k] >> 10);  // (scratch words)
+    atomicAdd(&counters[29], (unsigned long long)c_epi);
+    atomicAdd(&counters[30], (unsigned long long)c_pass);
+    atomicAdd(&counters[31], (unsigned long long)c_service);
 #else
     atomicAdd(&counters[CNT_PASSES], (unsigned long long)c_pass);
     atomicAdd(&counters[CNT_SERVICE], (unsigned long long)c_service);

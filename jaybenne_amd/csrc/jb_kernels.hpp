@@ -122,7 +122,9 @@ __global__ void __launch_bounds__(kBlock) k_lam_ghost_codes(DevMesh M, const int
         bits = kGhostTable | ((ent >> 28) == 2 ? 0x10000 << n : 0);
         dest = ent & 0x0fffffff;
         // (nbr_dq: in lam_sc's layout, 16 ntot bytes per block)
-        dcell = (unsigned)q + (unsigned)((nbr_dq[6 * b + f] - 16 * (int)M.ntot * (dest - b)) / 8);
+        // (unsigned 32-bit arithmetic throughout: the offsets wrap modulo 2^32 by construction, jb_mesh_create)
+        // the wrapped 32-bit difference, then back to a signed (small) byte count
+        dcell = (unsigned)(q + (int)((unsigned)nbr_dq[6 * b + f] - 16u * (unsigned)M.ntot * (unsigned)(dest - b)) / 8);
       } else if (adjacent) {
         // a neighbour of another level?  (cell centres are half a cell from every face: the floors
         // below hold on any geometry)  centre of the ghost cell, through a periodic boundary if need be

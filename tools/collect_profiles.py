@@ -56,7 +56,7 @@ def pmc_pass(d):
 
 for wl, particles in (("c2", 10_000_000), ("c2x", 10_000_000), ("c3", 100_000_000), ("c4", 10_000_000), ("c5", 10_000_000)):
     counters, ms_by_pass, kernel = {}, {}, None
-    for p in "ABCDEFG":
+    for p in "ABCDEFGHI":
         d = os.path.join(src, f"pmc_{wl}_{p}")
         if not os.path.isdir(d):
             continue
@@ -110,6 +110,14 @@ for wl, particles in (("c2", 10_000_000), ("c2x", 10_000_000), ("c3", 100_000_00
         "fp64_counter_frac": ((2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64"))
                               * 64.0 * g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_ACTIVE_INST_VALU"))
                               / (ms_by_pass.get("C", ms) * 1e-3) / 78.6e12) if ms else None,
+        # L2 (TCC) request path, where collected (passes H, I): busy share of the 128 channels' cycles, requests
+        # per channel and cycle -- the guide's gather microbenchmark (MI355X_MICROARCH.md, "Indexed rows": 16.8
+        # TB/s of 128-byte lines from the XCDs' L2) is 0.47 -- and the vector L1's requests to L2 with their
+        # average round trip in cycles
+        "l2_busy_fraction": g("TCC_BUSY_sum") / g("TCC_CYCLE_sum"),
+        "l2_requests_per_channel_cycle": g("TCC_REQ_sum") / g("TCC_CYCLE_sum"),
+        "l2_read_requests_from_l1": g("TCP_TCC_READ_REQ_sum"),
+        "l1_to_l2_read_latency_cycles": g("TCP_TCC_READ_REQ_LATENCY_sum") / g("TCP_TCC_READ_REQ_sum"),
         "non_fp64_valu_per_wave_pass": (g("SQ_INSTS_VALU") - g("SQ_INSTS_VALU_FMA_F64") - g("SQ_INSTS_VALU_ADD_F64")
                                         - g("SQ_INSTS_VALU_MUL_F64") - g("SQ_INSTS_VALU_TRANS_F64")) / passes,
         "counters": counters,

@@ -4,7 +4,7 @@
 # and the bench lines of every workload.  `python tools/collect_profiles.py <tag>` turns
 # gpurun_out/<tag>prof/ into profiles/<tag>_*.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out/${TAG}prof
 mkdir -p $O && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 C2="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
@@ -25,11 +25,13 @@ PD="FETCH_SIZE"
 PE="WRITE_SIZE"
 PF="TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum"
 PG="TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum"
+PH="TCC_BUSY_sum TCC_CYCLE_sum TCC_TAG_STALL_sum"
+PI="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"
 for wl in c2 c3 c5 c4 c2x; do
   case $wl in c2) CMD=$C2;; c3) CMD=$C3;; c4) CMD=$C4;; c5) CMD=$C5;; c2x) CMD=$C2X;; esac
-  for p in A B C D E F G; do
+  for p in A B C D E F G H I; do
     eval "CN=\$P$p"
-    timeout -k 5 150 rocprofv3 --kernel-trace --pmc $CN --output-format csv -d $O/pmc_${wl}_$p -o runc -- $CMD > $O/pmc_${wl}_$p.json 2> $O/pmc_${wl}_$p.err || echo "pass $wl $p FAILED"
+    timeout -k 5 100 rocprofv3 --kernel-trace --pmc $CN --output-format csv -d $O/pmc_${wl}_$p -o runc -- $CMD > $O/pmc_${wl}_$p.json 2> $O/pmc_${wl}_$p.err || echo "pass $wl $p FAILED"
     echo "pmc $wl $p done"
   done
 done
