@@ -234,7 +234,6 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   // arrive in 16-dword groups, and a group the compiler parks in VGPR lanes comes back whole
   // (16 v_readlane per pass for one dword of it).
   const unsigned ntot_u = sgpr_copy((unsigned)M.ntot);
-  const double *rec_base = M.ddmc_base;                    // cell records (service phase: albedo step)
   const double *step_base = sgpr_copy_ptr(M.ddmc_step);    // step records (event loop)
   const int l_ni = (int)sgpr_copy((unsigned)M.ni), l_nj = (int)sgpr_copy((unsigned)M.nj);
   const int l_is = (int)sgpr_copy((unsigned)M.is), l_ie = (int)sgpr_copy((unsigned)M.ie);
@@ -265,18 +264,6 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   typedef __attribute__((address_space(3))) char *lchar;
   lchar const wave_buf = (lchar)(unsigned)__builtin_amdgcn_readfirstlane(
       (int)(unsigned)(size_t)(lchar)&lds_rec[COOP ? threadIdx.x >> 6 : 0][0][0]);
-  auto load_record = [&](Step &s, int blk, int q) {
-    typedef const v4d __attribute__((address_space(1))) *grec;
-    // (library-owned, contiguous: no pointer-table load in front of the gather)
-    // (one 32 x 32 -> 64-bit multiply-add: jb_mesh_create keeps ntot below 2^31)
-    const grec rec = (grec)((gcptr)rec_base +
-                            8 * ((unsigned long long)(unsigned)blk * ntot_u + (unsigned)q));
-    const v4d r0 = rec[0];
-    const v4d r1 = rec[1];
-    s.ffaa = r0.x; s.sig = r0.y;
-    s.Px_l = r0.z; s.Px_u = r0.w; s.Py_l = r1.x; s.Py_u = r1.y; s.Pz_l = r1.z; s.Pz_u = r1.w;
-  };
-
   // a particle with a real position (just loaded / just relocated) enters the loop unless the
   // albedo step would find it at a face of its cell
   auto enter = [&](const Blk &Bq) {

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(kBlock, NDIM < 3 ? JB_IMC_WAVES_PER_SIMD_LOWD
   const double t_start = A.t_start, dt = A.dt;
   const long long first = A.first, last = A.last;
   unsigned long long *const counters = g1(A.counters);
-  const int *const nbr_dq = g1(A.nbr_dq);
+  (void)A.nbr_dq;   // (the face table's byte-offset changes live in the ghost codes of lam_sc since round 4)
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   __shared__ double lds_tally[TALLY ? kLdsTally : 1];
   const bool tally_in_lds = TALLY && (long long)M.nblocks * M.ntot <= (long long)kLdsTally;
@@ -124,7 +124,6 @@ __global__ void __launch_bounds__(kBlock, NDIM < 3 ? JB_IMC_WAVES_PER_SIMD_LOWD
 
   // byte strides of the [nk][nj][ni] cell arrays; the two arrays of block b start at 16 b ntot
   // bytes behind lam_abs0 / lam_sc0 (jb_mesh_create: everything below 4 GiB)
-  constexpr int sx = 8;
   const int sy = (int)sgpr_copy(8u * (unsigned)M.ni), sz = (int)sgpr_copy(8u * (unsigned)(M.ni * M.nj));
   const unsigned blk_bytes = 16u * (unsigned)M.ntot;
   const char *const lam_abs0 = (const char *)sgpr_copy_ptr(M.lam_base);
