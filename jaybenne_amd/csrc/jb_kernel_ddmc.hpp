@@ -54,9 +54,15 @@ enum { DS_IDLE = 0, DS_VIRT = 1, DS_PARK = 2, DS_DONE = 3, DS_RELOC = 4, DS_ABS 
 // 0x80000000 | flags, and with kStepGhostTable its low word is the RECORD NUMBER of the cell a particle
 // that leaks into this ghost cell really is in: the first / last interior cell along the axis of the
 // same-size resident neighbour or of the block across a periodic boundary, or the cell it came from at
-// a reflecting wall (more than one dimension: in 1-D the direction travels and has to be mirrored).
+// a reflecting wall (in 1-D with kStepGhostMirror: the direction travels there and is mirrored).
 // Without the flag (level changes, destinations that are not resident, outflow): the general relocation.
 constexpr int kStepGhostTable = 1;
+// ... and kStepGhostMirror (1-D only): the face is a reflecting wall -- the particle is back in the cell it
+// came from and the direction of its pending leak is mirrored (boundaries.hpp:46-82: v_x = -v_x; in 1-D a
+// leak's direction travels with the particle, transport_ddmc.cpp:206) -- so that the 1-D decks' wall leaks
+// (one in a hundred steps on BASELINE configs[2] as shipped: a lane in nearly every service phase) stay
+// in the event loop like every other same-size crossing
+constexpr int kStepGhostMirror = 2;
 constexpr int kPdZero = 0x40000000;  // pd: the zero-velocity flag of a multi-D leak across a block face
 
 // The swarm is a stream: every particle attribute is read once and written once per launch.  Where the
@@ -199,6 +205,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   // kPdZero: zero, the flag a multi-D DDMC leak across a block face leaves behind
   // (transport_ddmc.cpp:203-211)
   int pd = 0;
+  bool mir = false;   // (1-D) the pending leak's direction has been mirrored by a reflecting wall an odd number of times
   // ---- ... and what exists between two event loops only (decoded from rec / pd behind the loop):
   // block, cell indices, and the leak as channel 0..5 / -1 none / -2 zero-velocity flag
   int b = 0, ip = 0, jp = 0, kp = 0;
@@ -277,6 +284,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     real_pos = face && real_pos;
     rec = face ? rec : (unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip);
     pd = face ? pd : 0;   // (pend is -1 wherever a particle enters: just loaded, or relocated)
+    mir = face && mir;
   };
 
 #ifdef JB_TIMING
@@ -330,7 +338,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         } else {
           s.vx = vx; s.vy = vy; s.vz = vz;
           materialise_dir(s);
-          vx = s.vx; vy = s.vy; vz = s.vz;
+          vx = mir ? -s.vx : s.vx; vy = s.vy; vz = s.vz;
+          mir = false;
         }
         pend = -1;
       }
@@ -448,6 +457,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
           s.vx = vx; s.vy = vy; s.vz = vz;
           materialise_dir(s);
           vx = s.vx; vy = s.vy; vz = s.vz;
+          if constexpr (NDIM == 1) { vx = mir ? -vx : vx; mir = false; }
           pend = -1;
           write_v = true;
         } else if (pend == -2) {
@@ -703,6 +713,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         // step gives it: see the header)
         pzs = leak ? s2 : pzs;
         pd = leak ? delta : pd;
+        if constexpr (NDIM == 1) mir = mir && !leak;   // (a new leak: a new direction)
         rec = leak ? rec + (unsigned)delta : rec;
         const bool done = !(t_new < t_end);
         ls = (ev && absorbed) ? DS_ABS : (done ? (ev ? DS_DONE : DS_CENSUS) : DS_VIRT);
@@ -723,6 +734,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         const bool tab = gl && (rcp_hi & kStepGhostTable) != 0;
         rec = tab ? (unsigned)__double2loint(r.rcp) : rec;
         if constexpr (multi_d) pd = tab ? kPdZero : pd;
+        if constexpr (NDIM == 1) mir = (tab && (rcp_hi & kStepGhostMirror) != 0) ? !mir : mir;
         ls = (gl && !tab) ? DS_RELOC : ls;
       }
       nrun = __popcll(__ballot(ls == DS_VIRT));

@@ -189,10 +189,12 @@ __global__ void __launch_bounds__(kBlock) k_lam_ghost_codes(DevMesh M, const int
         const bool adjacent = (f & 1) ? idx[n] == last[n] + 1 : idx[n] == first[n] - 1;
         const int ent = M.nbr_ent[6 * b + f];
         const bool wall = (ent >> 28) == 2;
-        if (adjacent && ent >= 0 && (M.ndim >= 2 || !wall)) {
+        if (adjacent && ent >= 0) {
           const int stride = n == 0 ? 1 : (n == 1 ? M.ni : M.ni * M.nj);
           const int back = wall ? stride : stride * M.nx[n];
-          sflag = 1;  // kStepGhostTable
+          // kStepGhostTable; + kStepGhostMirror at a reflecting wall in 1-D (the direction travels there
+          // and is mirrored; in more dimensions it is zeroed by the crossing anyway)
+          sflag = (wall && M.ndim == 1) ? 3 : 1;
           srec = (unsigned)(ent & 0x0fffffff) * ntot + (unsigned)(q + ((f & 1) ? -back : back));
         }
       }
