@@ -251,6 +251,9 @@ int main(int argc, char **argv) {
   // ---- swarm: one pool per rank, room for every photon of the problem (they may all come here)
   jb_swarm_view sw{};
   sw.capacity = nparticles + nparticles / 4 + 4096;
+  // (test knobs: a swarm with little room makes the runs close their holes on the way -- jb_exchange's
+  // capacity protocol --, a tiny record buffer makes every rank stop together instead of one hanging the rest)
+  if (const char *e = std::getenv("JB_HANDOFF_CAPACITY")) sw.capacity = std::atoll(e);
   sw.x = dev_alloc<double>(sw.capacity); sw.y = dev_alloc<double>(sw.capacity); sw.z = dev_alloc<double>(sw.capacity);
   sw.vx = dev_alloc<double>(sw.capacity); sw.vy = dev_alloc<double>(sw.capacity); sw.vz = dev_alloc<double>(sw.capacity);
   sw.t = dev_alloc<double>(sw.capacity); sw.w = dev_alloc<double>(sw.capacity); sw.e = dev_alloc<double>(sw.capacity);
@@ -291,8 +294,8 @@ int main(int argc, char **argv) {
   const double e0 = total_weight();
 
   // ---- cycles
-  int64_t *rec_dev = dev_alloc<int64_t>((size_t)sw.capacity / 4 * JB_RECORD_WORDS + JB_RECORD_WORDS);
-  const int64_t rec_cap = sw.capacity / 4;
+  int64_t *rec_dev = dev_alloc<int64_t>((size_t)sw.capacity / 4 * JB_RECORD_WORDS + JB_RECORD_WORDS);   // (allocated at full size)
+  const int64_t rec_cap = std::getenv("JB_HANDOFF_REC_CAP") ? std::atoll(std::getenv("JB_HANDOFF_REC_CAP")) : sw.capacity / 4;
   // (jb_exchange: a receive buffer of its own -- both directions are in flight at once)
   const bool one_call = std::strcmp(exchange, "tasks") != 0;
   int64_t *recv_dev = one_call ? dev_alloc<int64_t>((size_t)rec_cap * JB_RECORD_WORDS + JB_RECORD_WORDS) : nullptr;
@@ -327,7 +330,7 @@ int main(int argc, char **argv) {
   }
   std::vector<int64_t> send_counts(nranks), recv_counts(nranks);
   std::vector<int> sc(nranks), sd(nranks), rc(nranks), rd(nranks);
-  long long handed_total = 0, iterations_total = 0;
+  long long handed_total = 0, iterations_total = 0, compactions_total = 0;
   bool ok = true;
   double time = 0.0;
   for (int cyc = 0; cyc < cycles; ++cyc) {
@@ -343,10 +346,13 @@ int main(int argc, char **argv) {
         const int64_t n_before = sw.n;
         jb_status xs = jb_exchange(ctx, mesh, &sw, first, last, rank, nranks, &tr, rec_dev, rec_cap, recv_dev, rec_cap,
                                    &nsent, &nrecv1, &moved1);
-        if (xs == JB_ERR_CAPACITY && sw.n + nrecv1 > sw.capacity) {
-          // no room for the arrivals: close the holes earlier departures left (nothing was packed yet; what is
-          // still to go is found by its status, wherever the compaction has moved it)
+        if (xs == JB_ERR_CAPACITY) {
+          // Some rank has no room (every rank gets this answer in the same call, so all of them are here):
+          // close the holes earlier departures left and go again -- nothing was packed yet, and what is
+          // still to go is found by its status, wherever the compaction has moved it.  (The buffers of this
+          // program are fixed: if one of THEM is too small the second call fails and the program stops.)
           JB_OK(jb_remove_marked_particles(ctx, &sw));
+          ++compactions_total;
           xs = jb_exchange(ctx, mesh, &sw, 0, sw.n, rank, nranks, &tr, rec_dev, rec_cap, recv_dev, rec_cap, &nsent,
                            &nrecv1, &moved1);
         }
@@ -414,6 +420,8 @@ int main(int argc, char **argv) {
   long long ev = st.n_events, ev_g = 0, handed_g = 0;
   MPI_Allreduce(&ev, &ev_g, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
   MPI_Allreduce(&handed_total, &handed_g, 1, MPI_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+  if (rank == 0 && compactions_total)
+    std::printf("jb_exchange reported JB_ERR_CAPACITY %lld time(s): holes closed, exchange repeated\n", compactions_total);
   if (rank == 0)
     std::printf("%d rank(s), %d blocks, %d halo ring(s): %lld events, %lld photons handed between ranks in %lld "
                 "transport iterations (%.2f per cycle)  -> %s\n", nranks, nblocks_total, halo_rings, ev_g, handed_g,

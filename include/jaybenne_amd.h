@@ -315,7 +315,8 @@ jb_status jb_update_fluid(jb_context *ctx, jb_mesh *mesh);
 jb_status jb_photon_reflect_bc(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm, int face);
 
 /* Swarm::RemoveMarkedParticles (transport.cpp:176-178) / DefragParticles (jaybenne.cpp:499-509):
- * keeps ACTIVE particles, closes the holes, updates swarm->n */
+ * keeps the ACTIVE particles and the ones still waiting for their hand-off (OUTGOING, not packed yet --
+ * jb_pack_outgoing / jb_exchange turn those slots into holes), closes the holes, updates swarm->n */
 jb_status jb_remove_marked_particles(jb_context *ctx, jb_swarm_view *swarm);
 /* jaybenne::DefragParticles (reference jaybenne.cpp:499-509: Swarm::Defrag; scheduled by no task
  * list of the reference).  The swarm is compact after jb_remove_marked_particles; this call restores
@@ -379,14 +380,17 @@ jb_status jb_unpack_incoming(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swar
 /* MeshResetCommunication -> MeshSend -> MeshReceive (jaybenne.cpp:26-61) in ONE call, the records never
  * leaving the device: the OUTGOING particles among [first,last) are counted per destination rank on the
  * device; the transport gathers every rank's counts into the rank x rank matrix straight from that buffer;
- * the matrix is read back once (the only host read-back of the call: nranks^2 words -- it carries this
+ * the matrix is read back once (the only host read-back of the call: nranks (nranks + 3) words -- it carries this
  * rank's receive sizes and *moved_anywhere, the answer to the completion question of jaybenne.cpp:130-131);
  * if anything moved anywhere the records are packed into send_dev, exchanged into recv_dev and appended to
  * the swarm, everything on the context's stream (the call returns when the unpack kernel is launched).
  * *nsent / *nreceived: records this rank handed over / took in.
- * JB_ERR_CAPACITY (nothing has been packed or changed yet; *nsent / *nreceived hold what is needed): a
- * buffer or the swarm is too small -- grow it, or close the swarm's holes with jb_remove_marked_particles,
- * and call again with [first,last) = [0, swarm->n) (what still has to go is found by its status).
+ * JB_ERR_CAPACITY (nothing has been packed or changed yet; *nsent / *nreceived hold what THIS rank
+ * needs; jb_last_error names the rank that lacks room): some rank's buffer or swarm is too small.  Every
+ * rank's room travels with its counts in the all-gather, so EVERY rank returns this status in the same
+ * call -- none is left waiting in the payload exchange -- and every rank calls again: after growing what
+ * was too small, or closing its swarm's holes with jb_remove_marked_particles, with [first,last) =
+ * [0, swarm->n) (what still has to go is found by its status).
  *
  * A jb_exchange_transport is the two collectives of the exchange on DEVICE buffers, enqueued on the given
  * HIP stream (0 = success): all_gather_u64 -- count words of every rank, in rank order; all_to_all_v --

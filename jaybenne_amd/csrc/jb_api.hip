@@ -57,6 +57,7 @@ struct jb_context {
   bool scratch_alloc_failed = false;          // set by ensure_scratch when hipMalloc itself said no
   std::vector<unsigned long long> xch_matrix;  // jb_exchange: the rank x rank record counts (host copy)
   std::vector<long long> xch_tab;             // ... this rank's send / receive counts and offsets
+  unsigned long long xch_room[3] = {0, 0, 0}; // ... and its room: send buffer, receive buffer, free swarm slots (records)
   size_t scratch_words = 0;
   // arithmetic of the gray IMC tracking step: lean (default) or exact (JB_EXACT_ARITH=1 in the
   // environment at jb_initialize, or jb_set_arithmetic)
@@ -1460,9 +1461,10 @@ extern "C" jb_status jb_exchange(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *
   if (st != JB_COMPLETE) return st;
   if (first < 0 || last > swarm->n || first > last) return fail(JB_ERR_INVALID, "bad particle range");
   if (rank < 0 || rank >= nranks) return fail(JB_ERR_INVALID, "rank outside [0, nranks)");
-  if (nranks < mesh->nranks_seen || nranks > kCounterWords - kRankBase)
+  if (nranks < mesh->nranks_seen || nranks + 3 > kCounterWords - kRankBase)
     return fail(JB_ERR_INVALID, "nranks = %d does not cover the owners in the mesh view", nranks);
   *nsent = 0; *nreceived = 0; *moved_anywhere = 0;
+  const int row = nranks + 3;   // what a rank contributes to the all-gather: counts | send, receive, swarm room
   // 1. records per destination rank, counted on the device ...
   unsigned long long *per_rank = ctx->counters_d + kRankBase;
   JB_HIP(hipMemsetAsync(per_rank, 0, sizeof(unsigned long long) * nranks, ctx->stream));
@@ -1471,27 +1473,35 @@ extern "C" jb_status jb_exchange(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *
     hipLaunchKernelGGL(k_count_outgoing, dim3(grid_for(ctx, last - first)), dim3(kBlock), 0, ctx->stream,
                        mesh->dm, S, (long long)first, (long long)last, per_rank);
   JB_HIP(hipGetLastError());
+  // ... followed, in the same buffer, by what this rank has room for: the capacity decision below must
+  // come out the same on EVERY rank (a rank that returned early would leave the others hanging in the
+  // payload exchange), so every rank gets to see every rank's room
+  ctx->xch_room[0] = (unsigned long long)(send_dev ? send_capacity : 0);
+  ctx->xch_room[1] = (unsigned long long)(recv_dev ? recv_capacity : 0);
+  ctx->xch_room[2] = (unsigned long long)(swarm->capacity - swarm->n);
+  JB_HIP(hipMemcpyAsync(per_rank + nranks, ctx->xch_room, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
   // 2. ... gathered from every rank straight from that buffer (no read-back in front of the collective):
   // the rank x rank matrix carries this rank's receive sizes AND the answer to "did anything move
   // anywhere" (the completion test of jaybenne.cpp:130-131 needs no collective of its own) ...
-  st = ensure_scratch(ctx, (size_t)nranks * (size_t)nranks + 4 * (size_t)nranks + 8);
+  st = ensure_scratch(ctx, (size_t)nranks * (size_t)row + 4 * (size_t)nranks + 8);
   if (st != JB_COMPLETE) return st;
   unsigned long long *matrix_d = (unsigned long long *)ctx->scratch_d;
-  if (tr->all_gather_u64(tr->handle, (const uint64_t *)per_rank, (uint64_t *)matrix_d, nranks, (void *)ctx->stream) != 0)
+  if (tr->all_gather_u64(tr->handle, (const uint64_t *)per_rank, (uint64_t *)matrix_d, row, (void *)ctx->stream) != 0)
     return fail(JB_ERR_HIP, "jb_exchange: the transport's all-gather of the record counts failed");
-  // 3. ... and read back ONCE per call: nranks^2 words
-  ctx->xch_matrix.resize((size_t)nranks * (size_t)nranks);
+  // 3. ... and read back ONCE per call: nranks (nranks + 3) words
+  ctx->xch_matrix.resize((size_t)nranks * (size_t)row);
   JB_HIP(hipMemcpyAsync(ctx->xch_matrix.data(), matrix_d, sizeof(unsigned long long) * ctx->xch_matrix.size(),
                         hipMemcpyDeviceToHost, ctx->stream));
   JB_HIP(hipStreamSynchronize(ctx->stream));
+  auto cnt = [&](int from, int to) { return (long long)ctx->xch_matrix[(size_t)from * row + to]; };
   long long total = 0, mine_out = 0, mine_in = 0;
   ctx->xch_tab.assign(4 * (size_t)nranks, 0);   // send counts | send offsets | recv counts | recv offsets (records)
   long long *sc = ctx->xch_tab.data(), *so = sc + nranks, *rc = so + nranks, *ro = rc + nranks;
   for (int s_ = 0; s_ < nranks; ++s_)
-    for (int r = 0; r < nranks; ++r) total += (long long)ctx->xch_matrix[(size_t)s_ * nranks + r];
+    for (int r = 0; r < nranks; ++r) total += cnt(s_, r);
   for (int r = 0; r < nranks; ++r) {
-    sc[r] = (long long)ctx->xch_matrix[(size_t)rank * nranks + r];
-    rc[r] = (long long)ctx->xch_matrix[(size_t)r * nranks + rank];
+    sc[r] = cnt(rank, r);
+    rc[r] = cnt(r, rank);
     so[r] = mine_out; ro[r] = mine_in;
     mine_out += sc[r]; mine_in += rc[r];
   }
@@ -1499,15 +1509,23 @@ extern "C" jb_status jb_exchange(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *
   *nsent = mine_out; *nreceived = mine_in;
   if (sc[rank] != 0) return fail(JB_ERR_INVALID, "jb_exchange: a rank does not hand particles to itself");
   if (total == 0) return JB_COMPLETE;
-  if (mine_out > 0 && (!send_dev || mine_out > send_capacity))
-    return fail(JB_ERR_CAPACITY, "jb_exchange: send buffer holds %lld records, %lld needed", (long long)send_capacity, mine_out);
-  if (mine_in > 0 && (!recv_dev || mine_in > recv_capacity))
-    return fail(JB_ERR_CAPACITY, "jb_exchange: receive buffer holds %lld records, %lld needed", (long long)recv_capacity, mine_in);
-  if (swarm->n + mine_in > swarm->capacity)
-    return fail(JB_ERR_CAPACITY, "jb_exchange: swarm capacity %lld too small for %lld arrivals", (long long)swarm->capacity, mine_in);
+  // the same verdict on every rank: does EVERY rank have room for what it sends and takes in?
+  for (int q = 0; q < nranks; ++q) {
+    long long out_q = 0, in_q = 0;
+    for (int r = 0; r < nranks; ++r) { out_q += cnt(q, r); in_q += cnt(r, q); }
+    const long long send_room = (long long)ctx->xch_matrix[(size_t)q * row + nranks];
+    const long long recv_room = (long long)ctx->xch_matrix[(size_t)q * row + nranks + 1];
+    const long long swarm_room = (long long)ctx->xch_matrix[(size_t)q * row + nranks + 2];
+    if (out_q > send_room)
+      return fail(JB_ERR_CAPACITY, "jb_exchange: rank %d's send buffer holds %lld records, %lld needed", q, send_room, out_q);
+    if (in_q > recv_room)
+      return fail(JB_ERR_CAPACITY, "jb_exchange: rank %d's receive buffer holds %lld records, %lld needed", q, recv_room, in_q);
+    if (in_q > swarm_room)
+      return fail(JB_ERR_CAPACITY, "jb_exchange: rank %d's swarm has room for %lld arrivals, %lld needed", q, swarm_room, in_q);
+  }
   // 4. pack (the packed slots become holes), 5. the payload, 6. unpack behind it on the same stream
   if (mine_out > 0) {
-    long long *firsts_d = (long long *)(matrix_d + (size_t)nranks * nranks);
+    long long *firsts_d = (long long *)(matrix_d + (size_t)nranks * row);
     JB_HIP(hipMemcpyAsync(firsts_d, so, sizeof(long long) * nranks, hipMemcpyHostToDevice, ctx->stream));
     JB_HIP(hipMemsetAsync(per_rank, 0, sizeof(unsigned long long) * nranks, ctx->stream));
     hipLaunchKernelGGL(k_pack_outgoing, dim3(grid_for(ctx, last - first)), dim3(kBlock), 0, ctx->stream,

@@ -12,8 +12,11 @@
 //     2.5e6 eps and cannot fire, and then moves the particle to the cell centre (:392-396);
 //   * the direction drawn at the leak is read by nobody until the particle leaves DDMC cells, is
 //     absorbed or crosses a block (deferred: channel + its two uniforms, as in k_transport).
-// So a lane in the event loop carries cell, time, weight, random-stream state and the pending
-// leak ("virtual" state: 19 registers); position and direction exist only in the service phase.
+// So a lane in the event loop carries its cell -- since round 5 as ONE 32-bit record number, block and
+// cell in one, which is what the step's gather is addressed with and what a leak moves by +-1, +-ni,
+// +-ni nj --, time, random-stream state and the pending leak ("virtual" state: 10 registers); block, cell
+// indices, position and direction exist only in the service phase.  Whether a leak left the block is read
+// off the record the next pass gathers anyway (ghost codes: kStepGhostTable below).
 // It loads a particle and evaluates the albedo step's six face tests on its real position: if
 // none holds (a particle lies within 5.5e-9 dx of a face of its cell once in ~1e8) the step
 // starts from the cell centre like every other and the lane goes straight to the loop; otherwise

@@ -1333,12 +1333,19 @@ __device__ __forceinline__ long long wave_slot(bool pred, unsigned long long *cu
   return base + __popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// What RemoveMarkedParticles keeps: the active photons AND the ones waiting for their hand-off (not packed
+// yet -- k_pack_outgoing turns their slots into holes): a compaction between a transport pass and the
+// exchange (jb_exchange's answer to JB_ERR_CAPACITY) must not drop them.
+__device__ __forceinline__ bool swarm_slot_live(int status) {
+  return status == ST_ACTIVE || status == ST_OUTGOING || status == ST_OUTGOING_ABSORBED;
+}
+
 __global__ void __launch_bounds__(kBlock)
     k_count_active(DevSwarm S, long long n_total, unsigned long long *cursor) {
   unsigned long long c = 0;
   for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
        n += (long long)gridDim.x * blockDim.x)
-    if (S.status[n] == ST_ACTIVE) ++c;
+    if (swarm_slot_live(S.status[n])) ++c;
   c = wave_sum(c);
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(cursor, c);
 }
@@ -1350,7 +1357,7 @@ __global__ void __launch_bounds__(kBlock)
   for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < span;
        n += (long long)gridDim.x * blockDim.x) {
     const bool valid = n < n_total;
-    const bool active = valid && S.status[n] == ST_ACTIVE;
+    const bool active = valid && swarm_slot_live(S.status[n]);
     const bool hole = valid && !active && n < survivors;
     const bool mover = active && n >= survivors;
     const long long hs = wave_slot(hole, &cursors[0]);
@@ -1369,7 +1376,7 @@ __global__ void __launch_bounds__(kBlock)
     S.vx[d] = S.vx[s]; S.vy[d] = S.vy[s]; S.vz[d] = S.vz[s];
     S.t[d] = S.t[s]; S.w[d] = S.w[s]; S.e[d] = S.e[s];
     S.ip[d] = S.ip[s]; S.jp[d] = S.jp[s]; S.kp[d] = S.kp[s];
-    S.blk[d] = S.blk[s]; S.status[d] = ST_ACTIVE;
+    S.blk[d] = S.blk[s]; S.status[d] = S.status[s];
     S.id[d] = S.id[s]; S.rng[d] = S.rng[s];
   }
 }

@@ -470,6 +470,34 @@ def test_defrag_particles_restores_cell_order_and_changes_nothing_else(gpu_devic
     assert jb.DefragParticles(drv.md) == jb.TaskStatus.complete
 
 
+def test_remove_marked_particles_keeps_photons_waiting_for_their_hand_off(gpu_device):
+    """Swarm::RemoveMarkedParticles (reference transport.cpp:176-178) removes what was MARKED: absorbed and
+    escaped photons, and the slots whose records have been packed.  A photon that has left its rank's blocks
+    but has not been packed yet (status OUTGOING / OUTGOING_ABSORBED) is still this rank's to deliver, so a
+    compaction between the transport pass and the exchange -- the answer to jb_exchange's JB_ERR_CAPACITY --
+    keeps it, status included, wherever it is moved."""
+    from jaybenne_amd import jaybenne as jb
+    drv = _gpu_problem(load_deck("stepdiff", {"jaybenne/num_particles": 5000}), gpu_device)
+    drv.Step()
+    md = drv.md
+    n = md.n
+    assert n > 1000
+    rs = np.random.RandomState(11)
+    status = rs.choice(np.array([0, 0, 1, 2, 3, 4], dtype=np.int32), size=n).astype(np.int32)
+    status[-200:] = rs.choice(np.array([0, 3, 4], dtype=np.int32), size=200)   # movers of every live kind at the end
+    import torch
+    md.swarm["status"][:n].copy_(torch.from_numpy(status))
+    before = md.get_swarm()
+    assert jb.RemoveMarkedParticles(md) == int(np.sum((status == 0) | (status >= 3)))
+    after = md.get_swarm()
+    keep = (status == 0) | (status >= 3)
+    order_b = np.argsort(before["id"][keep], kind="stable")
+    order_a = np.argsort(after["id"], kind="stable")
+    for k in before:
+        assert np.array_equal(before[k][keep][order_b], after[k][order_a]), k
+    assert set(np.unique(after["status"]).tolist()) == {0, 3, 4}
+
+
 def test_all_ddmc_mesh_runs_the_lean_kernel(gpu_device):
     for deck, want in (("stepdiff_ddmc", "k_ddmc_all<1"), ("stepdiff_smr_hybrid", "k_hybrid<2"),
                        ("stepdiff_smr_ddmc", "k_ddmc_all<2"), ("stepdiff", "k_transport<1")):

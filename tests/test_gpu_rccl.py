@@ -147,3 +147,40 @@ def test_c_level_exchange_three_ranks_over_the_mpi_transport(gpu_device, tmp_pat
     for k in ("x", "vx", "t", "w", "rng", "ip"):
         assert np.array_equal(g[k], O.sw[k][:O.n][order]), (rings, k)
     assert np.array_equal(g["gblk"], O.sw["blk"][:O.n][order])
+
+
+def test_c_level_exchange_capacity_protocol_is_collective(gpu_device, tmp_path):
+    """jb_exchange's JB_ERR_CAPACITY comes out on EVERY rank in the same call (each rank's room travels with
+    its counts in the all-gather), so no rank is left waiting in the payload exchange: (i) swarms with little
+    room -- the three ranks close their holes and go again, several times per run, and the photons still
+    equal the oracle's; (ii) a record buffer of ten records -- all three ranks stop with the message, at once,
+    instead of two of them hanging until the timeout."""
+    import re
+    import subprocess
+    from helpers import load_deck, make_oracle, run_oracle_cycles
+    from oracle import orc
+    from test_gpu_multirank import _read_photon_dumps
+    root, mpiexec = _mpi_env()
+    ov = {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 16, "jaybenne/num_particles": 200000}
+    O, mesh, _ = make_oracle(load_deck("stepdiff", ov), orc.MATH_PORTABLE)
+    run_oracle_cycles(O, load_deck("stepdiff", ov), 2)
+    order = np.argsort(O.sw["id"][:O.n])
+    prefix = str(tmp_path / "photons")
+    exe = os.path.join(root, "examples", "handoff_mpi")
+    # (i) 200000 photons on three ranks, room for 90000 each, no halo copies: ~75 iterations per cycle append
+    # arrivals behind holes until the swarm is full
+    env = dict(os.environ, JB_HANDOFF_CAPACITY="90000")
+    run = subprocess.run([mpiexec, "-n", "3", exe, "16", "8", "200000", "2", "0", prefix, "mpi"],
+                         capture_output=True, text=True, timeout=240, env=env)
+    assert run.returncode == 0 and "HANDOFF OK" in run.stdout, run.stdout + run.stderr
+    assert int(re.search(r"JB_ERR_CAPACITY (\d+) time", run.stdout).group(1)) >= 2, run.stdout
+    g = _read_photon_dumps(prefix, 3)
+    assert len(g) == O.n and np.array_equal(g["id"], O.sw["id"][:O.n][order])
+    for k in ("x", "vx", "t", "w", "rng", "ip"):
+        assert np.array_equal(g[k], O.sw[k][:O.n][order]), k
+    # (ii) ten records of buffer: every rank reports, none hangs
+    env = dict(os.environ, JB_HANDOFF_REC_CAP="10")
+    run = subprocess.run([mpiexec, "-n", "3", exe, "16", "8", "200000", "1", "0", "-", "mpi"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert run.returncode != 0
+    assert "buffer holds 10 records" in run.stdout + run.stderr
