@@ -464,7 +464,8 @@ jb_status jb_debug_draw_stream(jb_context *ctx, uint64_t state, int n, double *o
                                uint64_t *final_state);
 /* which: 0 log, 1 sin, 2 cos, 3 acos, 4 sqrt, 5 reciprocal, 6 lean sqrt, 7 lean x[i] / x[i+1],
  * 8 lean x[i] / c, 9 sin(2 pi x), 10 cos(2 pi x), 11 1 - exp(-x), 12 x[i] / x[i+1] as the lean
- * arithmetic forms it (numerator times once-refined reciprocal), 13 lean log */
+ * arithmetic forms it (numerator times once-refined reciprocal), 13 lean log, 14 lean sqrt, 15 lean log
+ * on its 1024-row table (the cell-local IMC kernel's) */
 jb_status jb_debug_math(jb_context *ctx, int which, const double *x_host, int n, double *out_host);
 /* the opacity / scattering models as the kernels evaluate them: out[0..3] = EPBremss A, B, E
  * (sigma_a = A rho^2 T^-1/2 (1 - e^(-B nu / T)) nu^-3, j = E rho^2 T^1/2, code units) and the

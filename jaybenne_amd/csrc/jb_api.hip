@@ -1757,7 +1757,7 @@ __global__ void k_dbg_stream_start(uint32_t seed, unsigned long long id, unsigne
   *out = rng_stream_start(seed, id);
 }
 __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
-  load_math_tables();
+  load_math_tables<true, true, true, true, true>();
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     double s, c;
     switch (which) {
@@ -1775,6 +1775,7 @@ __global__ void k_dbg_math(int which, const double *x, int n, double *out) {
     case 11: out[i] = m_one_minus_exp_neg(x[i]); break;
     case 12: out[i] = x[i] * m_rcp_once(x[(i + 1) % n]); break;   // lean quotient
     case 13: out[i] = m_log_lean(x[i]); break;
+    case 15: out[i] = m_log_lean<false, true>(x[i]); break;
     default: out[i] = m_sqrt_lean(x[i]); break;
     }
   }

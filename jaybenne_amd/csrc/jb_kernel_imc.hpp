@@ -79,6 +79,11 @@ struct ImcArgs {
 };
 
 enum { IS_IDLE = 0, IS_RUN = 1, IS_DONE = 2, IS_DONE_RAW = 3 };
+// the lean logarithm on its 1024-row table (m_log_lean<SC, true>): 16 KB of LDS per workgroup instead of 2
+#ifndef JB_IMC_WIDE_LOG
+#define JB_IMC_WIDE_LOG 1
+#endif
+constexpr bool kWideLog = JB_IMC_WIDE_LOG != 0;
 
 
 template <int NDIM, bool TALLY, bool NOABS, bool UNIFORM>
@@ -105,7 +110,9 @@ __global__ void __launch_bounds__(kBlock, NDIM < 3 ? JB_IMC_WAVES_PER_SIMD_LOWD
     if (tally_in_lds)
       for (int q = threadIdx.x; q < M.nblocks * (int)M.ntot; q += blockDim.x) lds_tally[q] = 0.0;
   }
-  load_math_tables<false, true, false, true>();  // lean logarithm, sincos of 2 pi u (ends with a barrier)
+  // (a non-absorbing material only: with the absorption logarithm beside it the 3-D form spills registers)
+  constexpr bool kWide = kWideLog && NOABS;
+  load_math_tables<false, !kWide, false, true, kWide>();  // lean logarithm, sincos of 2 pi u (ends with a barrier)
 
   constexpr int kServiceBudget = JB_IMC_SERVICE_BUDGET;
   const double vv = P.c;
@@ -375,7 +382,7 @@ __global__ void __launch_bounds__(kBlock, NDIM < 3 ? JB_IMC_WAVES_PER_SIMD_LOWD
       }
       if (stepping) {
         bool is_absorbed, is_scattered, hit_any;
-        imc_step_cell<NDIM, NOABS, UNIFORM>(cg, sy, sz, lam_a, lam_s, rng, drem, px, py, pz, ox, oy, oz, qoff,
+        imc_step_cell<NDIM, NOABS, UNIFORM, kWide>(cg, sy, sz, lam_a, lam_s, rng, drem, px, py, pz, ox, oy, oz, qoff,
                                             is_absorbed, is_scattered, hit_any);
         fetch_lam();  // (for the next pass, ahead of the scatter)
         const bool census = !(drem > 0.0);

@@ -94,14 +94,18 @@ __device__ __forceinline__ int mad24(int a, int b_uniform, int c) {
 }
 __shared__ double lds_log_tab[JB_LOG_N][4];  // {1/c, log c hi, log c lo, -}: 32-byte rows, one address serves both reads
 __shared__ double lds_log2_tab[JB_LOG_N][2];  // {1/c, log c as one double}: the lean logarithm's row
+__shared__ double lds_logl_tab[JB_LOGL_N][2]; // the same with 1024 rows (16 KB): m_log_lean<SC, true>, k_imc_cell
 __shared__ double lds_sc_tab[JB_SC_N + 1][2];
 __shared__ double lds_sc2_tab[JB_SC2_N + 1][2];
 
 // Copies the tables into this workgroup's LDS (11.2 KB; a kernel that names the ones it reads
 // -- logarithm, lean logarithm, sincos, sincos of 2 pi u -- gets only those allocated); ends with a
 // barrier.
-template <bool LOG = true, bool LOG2 = true, bool SC = true, bool SC2 = true>
+template <bool LOG = true, bool LOG2 = true, bool SC = true, bool SC2 = true, bool LOGL = false>
 __device__ __forceinline__ void load_math_tables() {
+  if constexpr (LOGL)
+    for (int q = threadIdx.x; q < JB_LOGL_N * 2; q += blockDim.x)
+      (&lds_logl_tab[0][0])[q] = (&jb_logl_tab[0][0])[q];
   if constexpr (LOG)
     for (int q = threadIdx.x; q < JB_LOG_N * 3; q += blockDim.x)
       lds_log_tab[q / 3][q % 3] = (&jb_log_tab[0][0])[q];
@@ -196,11 +200,27 @@ __device__ __forceinline__ double m_log(double x) {  // x positive, finite, norm
 // multiply-add on the rounded constants, plus r + r^2 P(r), added in plain double (<= 3 ulp of the
 // result for the arguments in (0, 1) the kernels feed it, measured <= 2; next to x = 1 the table
 // row is {1, 0} and the result is r + r^2 P(r) itself) ...
-template <bool SC = false>
+// WIDE: 1024 table rows instead of 128 -- |r| <= 2^-11 (2^-10 in the row that holds 1.0, where the
+// result is r + r^2 P(r) itself), so that the series ends with r^5 / 5 (the next term is below 5e-18 of
+// the result): two Horner steps fewer for 14 KB more LDS.  The kernel that has the room asks for it.
+template <bool SC = false, bool WIDE = false>
 __device__ __forceinline__ double m_log_lean(double x) {
   constexpr double ln2 = 6.93147180559945286227e-01;
   const uint32_t hx = (uint32_t)__double2hiint(x);
   const uint32_t th = hx - (uint32_t)(JB_LOG_OFF >> 32);
+  if constexpr (WIDE) {
+    const int i = (int)((th >> 10) & (JB_LOGL_N - 1));
+    const int k = (int)th >> 20;
+    const double z = __hiloint2double((int)(hx - (th & 0xfff00000u)), __double2loint(x));
+    const double invc = lds_logl_tab[i][0], lc = lds_logl_tab[i][1];
+    const double r = fma(z, invc, -1.0);
+    const double w = fma((double)k, ln2, lc);
+    const double r2 = r * r;
+    double p = m_fma_k<SC>(r, 0.2, -0.25);
+    p = m_fma_k<SC>(r, p, 1.0 / 3.0);
+    p = m_fma_k<SC>(r, p, -0.5);
+    return w + fma(r2, p, r);
+  }
   const int i = (int)((th >> 13) & (JB_LOG_N - 1));
   const int k = (int)th >> 20;
   const double z = __hiloint2double((int)(hx - (th & 0xfff00000u)), __double2loint(x));

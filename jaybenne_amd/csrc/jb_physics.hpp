@@ -433,7 +433,7 @@ __device__ __forceinline__ double nudged(double p, double m, bool hit) {
 struct CellGeom {
   double hx, hy, hz, mx, my, mz, dxp;
 };
-template <int NDIM, bool NOABS, bool UNIFORM = false, class Rng>
+template <int NDIM, bool NOABS, bool UNIFORM = false, bool WIDELOG = false, class Rng>
 __device__ __forceinline__ void imc_step_cell(const CellGeom &g, int sy, int sz, double lam_a, double lam_s,
                                               Rng &rng, double &drem, double &px, double &py, double &pz,
                                               double ox, double oy, double oz, unsigned &qoff,
@@ -443,8 +443,8 @@ __device__ __forceinline__ void imc_step_cell(const CellGeom &g, int sy, int sz,
   // ---- transport_utils.hpp:118-134: distances to collision, census, cell faces
   double dx_abs = 0.0;
   if constexpr (NOABS) rng.skip();
-  else dx_abs = -lam_a * m_log_lean<true>(rng.drand());
-  const double dx_sc = -lam_s * m_log_lean<true>(rng.drand());
+  else dx_abs = -lam_a * m_log_lean<true, WIDELOG>(rng.drand());
+  const double dx_sc = -lam_s * m_log_lean<true, WIDELOG>(rng.drand());
   double dx_push = m_min(g.dxp, drem);
   double rx, ry = 0.0, rz = 0.0;
   if constexpr (three_d) {

@@ -116,6 +116,11 @@ def test_lean_operations_against_the_exact_ones(gpu_device):
     orc.set_math_mode(orc.MATH_PORTABLE)
     want = orc.math_log(u)
     assert (np.abs(got - want) / np.spacing(np.abs(want))).max() <= 3.0
+    # ... and on the 1024-row table the cell-local IMC kernel reads (series cut after r^5 / 5)
+    assert lib.jb_debug_math(ctx, 15, u.ctypes.data, u.size, got.ctypes.data) == _lib.JB_COMPLETE
+    err = (np.abs(got - want) / np.spacing(np.abs(want))).max()
+    print("lean log, 1024 rows: largest error", err, "ulp")
+    assert err <= 3.0
     # square root of 1 - mu^2 (scatter): one refinement of the hardware's reciprocal square root
     v = np.concatenate([1.0 - (2.0 * rng.random(n) - 1.0) ** 2, 2.0 ** rng.uniform(-52, 0, n // 4)])
     v = v[(v >= 2.0 ** -52) & (v <= 1.0)]
