@@ -37,6 +37,16 @@ CASES = [
                                                                 "mcblock/opacity_constant_value": 20.0,
                                                                 "jaybenne/do_emission": "true", "jaybenne/do_feedback": "false"}), "", 3),
 ]
+IMC3D = {"parthenon/mesh/nx1": 32, "parthenon/mesh/nx2": 32, "parthenon/mesh/nx3": 32, "parthenon/meshblock/nx1": 16,
+         "parthenon/meshblock/nx2": 16, "parthenon/meshblock/nx3": 16}
+CASES += [
+    ("3-D IMC, 8 blocks of 16^3 (x-space kernel)", "stepdiff", dict(IMC3D, **{"jaybenne/num_particles": 100000}), "", 2),
+    ("2-D SMR IMC", "stepdiff_smr", dict(SMR, **{"jaybenne/num_particles": 100000}), "", 2),
+    ("1-D IMC, 4 blocks, reflecting walls", "stepdiff", {"jaybenne/num_particles": 100000, "parthenon/meshblock/nx1": 25}, "", 3),
+]
+# (second round: the same decks with another seed -- other streams, other rare events)
+if len(sys.argv) > 1:
+    CASES = [(n + f", seed {sys.argv[1]}", d, dict(o, **{"jaybenne/seed": int(sys.argv[1])}), e, c) for n, d, o, e, c in CASES]
 ok = True
 for name, deck, ov, extra, cycles in CASES:
     def pin_():
