@@ -451,6 +451,19 @@ double jb_estimate_timestep(const jb_context *ctx);
 jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm, double t_start,
                             double dt, uint64_t *next_id, uint32_t *cycle, int32_t *prefix_dev);
 
+/* ---- trace ranges -- the reference's Kokkos::Profiling::pushRegion("Jaybenne::Timestep") ...
+ * popRegion() and "Jaybenne::TransportLoop" (jaybenne.cpp:87,115,127,145).  Every task entry point
+ * above opens a ROCTx range named after its reference task ("Jaybenne::TransportPhotons_DDMC", ...)
+ * for its own duration and jb_radiation_step opens the reference's two; a host that drives the
+ * tasks itself brackets its cycle and its iterate-sublist with these (jaybenne_amd/jaybenne.py,
+ * include/jaybenne_amd.hpp do).  `rocprofv3 --marker-trace --kernel-trace` shows them beside the
+ * kernels.  The marker library (librocprofiler-sdk-roctx / libroctx64) is dlopen()ed on first use:
+ * no link dependency; absent, or with JB_NO_ROCTX=1, the calls do nothing and return -1
+ * (jb_ranges_enabled() = 0).  push returns the nesting level as roctxRangePushA does. */
+int jb_range_push(const char *name);
+int jb_range_pop(void);
+int jb_ranges_enabled(void);
+
 /* ---- debug entry points (parity tests drive the device functions directly) ---------------- */
 jb_status jb_debug_philox(jb_context *ctx, const uint32_t ctr[4], const uint32_t key[2],
                           uint32_t out[4]);

@@ -138,6 +138,9 @@ PROTOTYPES = {
     "jb_estimate_timestep": (_f64, [_vp]),
     "jb_radiation_step": (_int, [_vp, _vp, C.POINTER(SwarmView), _f64, _f64,
                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), _vp]),
+    "jb_range_push": (_int, [C.c_char_p]),
+    "jb_range_pop": (_int, []),
+    "jb_ranges_enabled": (_int, []),
     "jb_debug_philox": (_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                C.POINTER(C.c_uint32)]),
     "jb_debug_rocrand_philox": (_int, [_vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),

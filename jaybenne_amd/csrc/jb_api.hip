@@ -64,6 +64,7 @@ struct jb_context {
   bool lean_arith = true;
   int blocks_per_cu_env = 0;  // JB_TRANSPORT_BLOCKS_PER_CU at jb_initialize (tuning aid), 0 = occupancy query
   bool no_ddmc_all = false;   // JB_NO_DDMC_ALL=1 at jb_initialize (tests: k_hybrid on all-DDMC meshes)
+  int max_classes = kMaxClasses;   // JB_DDMC_MAX_CLASSES: fewer (tests of the fall-back to the 64-byte gather)
   int coop_gather = -1;       // JB_COOP_GATHER=0 / 1 / 2: k_ddmc_all's quad-cooperative gather off / on / on with 64-bit addresses, whatever the table size
   bool no_imc_cell = false;   // JB_NO_IMC_CELL=1 at jb_initialize (tests, A/B): the lean step in x-space (k_transport<.., LEAN>) instead of k_imc_cell
   // jb_defrag_policy: HIP events around every transport call of the running cycle, and what the
@@ -112,9 +113,56 @@ struct jb_mesh {
   // UpdateDerivedTransportFields rewrote it (the first DDMC transport call of a cycle reads it back,
   // one synchronisation; the further transport iterations of a multi-rank cycle reuse the answer)
   int not_all_ddmc_host = -1;
+  int nclass_host = 0;   // ... and the number of distinct step records (DevMesh::ddmc_code), read with it
 };
 
 __global__ void k_rcp_refined(double b, double *out) { *out = m_rcp_refined(b); }
+
+// ------------------------------------------------------------------------------------------------
+// Trace ranges.  The reference brackets the cycle and its transport loop with
+// Kokkos::Profiling::pushRegion("Jaybenne::Timestep" / "Jaybenne::TransportLoop") (jaybenne.cpp:87,115,
+// 127,145), which Kokkos Tools hand to whatever profiler is attached.  Here every task entry point of
+// the C ABI opens a ROCTx range of its reference name ("Jaybenne::<task>"), jb_radiation_step opens the
+// reference's two, and a host that drives the tasks itself opens them through jb_range_push / _pop;
+// `rocprofv3 --marker-trace` shows them beside the kernels.  The marker library is dlopen()ed on first
+// use -- no link dependency -- and everything is a no-op when it is absent or JB_NO_ROCTX=1.
+struct RoctxApi {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+};
+static const RoctxApi &roctx_api() {
+  static const RoctxApi api = [] {
+    RoctxApi a;
+    const char *off = getenv("JB_NO_ROCTX");
+    if (off && off[0] == '1') return a;
+    // (rocprofv3 listens to the SDK's marker library; the roctracer one is what older tools attach to)
+    for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void *lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) continue;
+      a.push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+      a.pop = (int (*)())dlsym(lib, "roctxRangePop");
+      if (a.push && a.pop) break;
+      a = RoctxApi();
+    }
+    return a;
+  }();
+  return api;
+}
+struct TraceRange {
+  bool open;
+  explicit TraceRange(const char *name) : open(roctx_api().push != nullptr) { if (open) (void)roctx_api().push(name); }
+  ~TraceRange() { if (open) (void)roctx_api().pop(); }
+  TraceRange(const TraceRange &) = delete;
+  TraceRange &operator=(const TraceRange &) = delete;
+};
+#define JB_RANGE(name) TraceRange jb_trace_range_(name)
+
+extern "C" int jb_range_push(const char *name) {
+  if (!name || !roctx_api().push) return -1;
+  return roctx_api().push(name);
+}
+extern "C" int jb_range_pop(void) { return roctx_api().pop ? roctx_api().pop() : -1; }
+extern "C" int jb_ranges_enabled(void) { return roctx_api().push != nullptr ? 1 : 0; }
 
 extern "C" const char *jb_last_error(void) { return g_err; }
 extern "C" const char *jb_version(void) { return "jaybenne_amd 0.1 (gfx950)"; }
@@ -188,7 +236,11 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   if (const char *e = getenv("JB_TRANSPORT_BLOCKS_PER_CU")) ctx->blocks_per_cu_env = atoi(e);
   if (const char *e = getenv("JB_NO_DDMC_ALL")) ctx->no_ddmc_all = e[0] == '1';
   if (const char *e = getenv("JB_NO_IMC_CELL")) ctx->no_imc_cell = e[0] == '1';
-  if (const char *e = getenv("JB_COOP_GATHER")) ctx->coop_gather = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);  // (tests, A/B runs)
+  if (const char *e = getenv("JB_COOP_GATHER")) ctx->coop_gather = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : (e[0] == '4' ? 4 : 0));  // (tests, A/B runs)
+  if (const char *e = getenv("JB_DDMC_MAX_CLASSES")) {   // (tests: the fall-back when a mesh has more distinct step records)
+    const int v = atoi(e);
+    ctx->max_classes = v < 0 ? 0 : (v > kMaxClasses ? kMaxClasses : v);
+  }
   ctx->dp.key0 = (uint32_t)params->seed;  // RngPool rng_pool(seed): unadjusted (quirk 1)
   ctx->dp.use_ddmc = params->use_ddmc;
   ctx->dp.do_feedback = params->do_feedback;
@@ -502,11 +554,15 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
     if ((st = upload(m, x0.data(), x0.size(), &D.nbr_x0)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
   }
   {
-    const int one = 1;   // until UpdateDerivedTransportFields has looked at the cells
+    // [0] = 1 until UpdateDerivedTransportFields has looked at the cells; [1] = distinct step records (cell classes)
+    const int init[2] = {1, 0};
     const int *flag = nullptr;
-    if ((st = upload(m, &one, 1, &flag)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
+    if ((st = upload(m, init, 2, &flag)) != JB_COMPLETE) { jb_mesh_destroy(m); return st; }
     D.not_all_ddmc = (int *)flag;
   }
+  D.ddmc_code = nullptr;
+  D.ddmc_class = nullptr;
+  D.ddmc_class_slot = nullptr;
   D.ddmc_base = nullptr;
   D.ddmc_step = nullptr;
   D.lam_hyb = nullptr;
@@ -552,13 +608,32 @@ extern "C" jb_status jb_mesh_create(jb_context *ctx, const jb_mesh_view *v, jb_m
       e = hipMalloc(&step_rec, sizeof(double) * per * 8 * (size_t)v->nblocks);
       if (e != hipSuccess) { jb_mesh_destroy(m); return fail(JB_ERR_HIP, "hipMalloc of the DDMC step records failed: %s", hipGetErrorString(e)); }
       m->owned.push_back(step_rec);
-      (void)hipMemset(step_rec, 0, sizeof(double) * per * 8 * (size_t)v->nblocks);
+      // (on the context's stream, like k_lam_ghost_codes below: a null-stream memset is not ordered against a
+      // kernel on a non-blocking stream the host handed in with jb_set_stream, and would wipe the ghost codes)
+      (void)hipMemsetAsync(step_rec, 0, sizeof(double) * per * 8 * (size_t)v->nblocks, ctx->stream);
       D.ddmc_step = step_rec;
+      // cell codes + the table of distinct step records (k_ddmc_all<.., GATHER 4>); a code holds a record
+      // number in 29 bits
+      if ((unsigned long long)per * (unsigned long long)v->nblocks < (1ull << 29)) {
+        unsigned *code = nullptr;
+        e = hipMalloc(&code, sizeof(unsigned) * per * (size_t)v->nblocks);
+        if (e != hipSuccess) { jb_mesh_destroy(m); return fail(JB_ERR_HIP, "hipMalloc of the DDMC cell codes failed: %s", hipGetErrorString(e)); }
+        m->owned.push_back(code);
+        // (ghost cells that k_lam_ghost_codes leaves alone -- there are none -- would read "class 0")
+        (void)hipMemsetAsync(code, 0, sizeof(unsigned) * per * (size_t)v->nblocks, ctx->stream);
+        double *cls = nullptr;
+        e = hipMalloc(&cls, sizeof(double) * 8 * kMaxClasses + sizeof(int) * 2 * kClassSlots);
+        if (e != hipSuccess) { jb_mesh_destroy(m); return fail(JB_ERR_HIP, "hipMalloc of the DDMC class table failed: %s", hipGetErrorString(e)); }
+        m->owned.push_back(cls);
+        D.ddmc_code = code;
+        D.ddmc_class = cls;
+        D.ddmc_class_slot = (int *)(cls + 8 * kMaxClasses);
+      }
       double *hyb = nullptr;
       e = hipMalloc(&hyb, sizeof(double) * per * (size_t)v->nblocks);
       if (e != hipSuccess) { jb_mesh_destroy(m); return fail(JB_ERR_HIP, "hipMalloc of the hybrid mean-free-path array failed: %s", hipGetErrorString(e)); }
       m->owned.push_back(hyb);
-      (void)hipMemset(hyb, 0, sizeof(double) * per * (size_t)v->nblocks);
+      (void)hipMemsetAsync(hyb, 0, sizeof(double) * per * (size_t)v->nblocks, ctx->stream);
       D.lam_hyb = hyb;
     }
     // ghost cells of the scattering mean free path: which face of the block lies between them and
@@ -608,6 +683,7 @@ static jb_status check_swarm(const jb_swarm_view *s, const char *who) {
 
 // ------------------------------------------------------------------------------------------------
 extern "C" jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh *mesh, double dt) {
+  JB_RANGE("Jaybenne::UpdateDerivedTransportFields");
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
   const DevMesh &M = mesh->dm;
@@ -622,11 +698,14 @@ extern "C" jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh
     if (M.ddmc_cell) {
       // JB_NO_DDMC_ALL=1 keeps the general kernel also on all-DDMC meshes (tests, A/B)
       JB_HIP(hipMemsetAsync(M.not_all_ddmc, ctx->no_ddmc_all ? 1 : 0, sizeof(int), ctx->stream));
+      JB_HIP(hipMemsetAsync(M.not_all_ddmc + 1, 0, sizeof(int), ctx->stream));   // the distinct step records are numbered afresh
+      if (M.ddmc_class_slot) JB_HIP(hipMemsetAsync(M.ddmc_class_slot, 0, sizeof(int) * 2 * kClassSlots, ctx->stream));
       mesh->not_all_ddmc_host = -1;
       const int gp = grid_for(ctx, cells);
-      if (M.ndim == 1) hipLaunchKernelGGL(k_ddmc_pack<1>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
-      else if (M.ndim == 2) hipLaunchKernelGGL(k_ddmc_pack<2>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
-      else hipLaunchKernelGGL(k_ddmc_pack<3>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp);
+      const int mc = ctx->max_classes;
+      if (M.ndim == 1) hipLaunchKernelGGL(k_ddmc_pack<1>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp, mc);
+      else if (M.ndim == 2) hipLaunchKernelGGL(k_ddmc_pack<2>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp, mc);
+      else hipLaunchKernelGGL(k_ddmc_pack<3>, dim3(gp), dim3(kBlock), 0, ctx->stream, M, ctx->dp, mc);
     }
   }
   JB_HIP(hipGetLastError());
@@ -636,6 +715,7 @@ extern "C" jb_status jb_update_derived_transport_fields(jb_context *ctx, jb_mesh
 extern "C" jb_status jb_source_photons_count(jb_context *ctx, jb_mesh *mesh, int source_type,
                                              double dt, int blocks_in_call, uint32_t epoch,
                                              int32_t *nper_block_host, int32_t *prefix_dev) {
+  JB_RANGE("Jaybenne::SourcePhotons1");
   if (!ctx || !mesh || !nper_block_host || !prefix_dev) return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
   if (ctx->params.source_strategy == JB_STRATEGY_ENERGY)
@@ -683,6 +763,7 @@ extern "C" jb_status jb_source_photons_fill_range(jb_context *ctx, jb_mesh *mesh
                                                   const uint64_t *id_base_host,
                                                   const int32_t *first_in_block_host,
                                                   int set_energy_delta) {
+  JB_RANGE("Jaybenne::SourcePhotons2");
   if (!ctx || !mesh || !nper_block_host || !prefix_dev || !slot_base_host || !id_base_host)
     return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
@@ -809,10 +890,11 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
     if (gray && M.ddmc_cell && M.nblocks <= kLdsBlocks) {
       if (mesh->not_all_ddmc_host < 0) {
         int *flag_h = (int *)(ctx->counters_h + kCounterWords - 1);
-        *flag_h = 1;
-        (void)hipMemcpyAsync(flag_h, M.not_all_ddmc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        flag_h[0] = 1; flag_h[1] = 0;
+        (void)hipMemcpyAsync(flag_h, M.not_all_ddmc, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
         JB_HIP(hipStreamSynchronize(ctx->stream));
-        mesh->not_all_ddmc_host = *flag_h != 0 ? 1 : 0;
+        mesh->not_all_ddmc_host = flag_h[0] != 0 ? 1 : 0;
+        mesh->nclass_host = flag_h[1];
       }
       const bool noabs_h = ctx->dp.kappa_a == 0.0;
       if (mesh->not_all_ddmc_host == 0) {
@@ -829,7 +911,12 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         // ... and a mesh of at most kLdsRecCells cells (the reference's 1-D decks) keeps its records in
         // LDS: 12.3 -> 10.3 ms per 1e8 histories on BASELINE configs[2] as shipped
         const bool in_lds = !coop && ctx->coop_gather < 0 && (long long)M.nblocks * M.ntot <= (long long)kLdsRecCells;
-        const int gather = coop ? (wide ? 3 : 1) : (in_lds ? 2 : 0);
+        // ... and everything between with at most kMaxClasses DISTINCT step records (k_ddmc_pack counts them
+        // every cycle: the gray decks have a handful) gathers a 4-byte cell code per step, the records in LDS
+        // (JB_COOP_GATHER=4 also on the smallest meshes; 0 / 1 / 2 keep the 64-byte forms, for tests and A/B)
+        const bool codes = M.ddmc_code != nullptr && mesh->nclass_host >= 1 && mesh->nclass_host <= ctx->max_classes &&
+                           (ctx->coop_gather == 4 || (ctx->coop_gather < 0 && !in_lds));
+        const int gather = codes ? 4 : (coop ? (wide ? 3 : 1) : (in_lds ? 2 : 0));
         // A particle that sits at a face of its cell when it is loaded or relocated (one in ~1e8) needs
         // the albedo step: k_ddmc_all lists it, and k_hybrid<.., both loops>, launched behind it on
         // that list (its length read on the device: no synchronisation), tracks it to the end.
@@ -843,7 +930,7 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         const size_t ncell_all = (size_t)M.nblocks * (size_t)M.ntot;
         const size_t lds_tally_bytes =
             (tally && (long long)ncell_all <= (long long)kLdsTally ? sizeof(double) * ((ncell_all + 1) / 2 * 2) : 0) +
-            (in_lds ? 64 * ncell_all : 0);
+            (codes ? 64 * (size_t)mesh->nclass_host : (in_lds ? 64 * ncell_all : 0));
         (void)hipMemsetAsync(n_handed, 0, sizeof(unsigned long long), ctx->stream);
 #define JB_LAUNCH_DDMC_ALL(TL, CO)                                                                          \
   do {                                                                                                      \
@@ -866,23 +953,25 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
                        (const unsigned *)handed, (unsigned *)nullptr, (unsigned long long *)nullptr,         \
                        (const unsigned long long *)n_handed);                                               \
   } while (0)
-        static const char *const names[3][2][3] = {
-            {{"k_ddmc_all<1, false>", "k_ddmc_all<1, false, quad gather>", "k_ddmc_all<1, false, records in LDS>"},
-             {"k_ddmc_all<1, true>", "k_ddmc_all<1, true, quad gather>", "k_ddmc_all<1, true, records in LDS>"}},
-            {{"k_ddmc_all<2, false>", "k_ddmc_all<2, false, quad gather>", "k_ddmc_all<2, false, records in LDS>"},
-             {"k_ddmc_all<2, true>", "k_ddmc_all<2, true, quad gather>", "k_ddmc_all<2, true, records in LDS>"}},
-            {{"k_ddmc_all<3, false>", "k_ddmc_all<3, false, quad gather>", "k_ddmc_all<3, false, records in LDS>"},
-             {"k_ddmc_all<3, true>", "k_ddmc_all<3, true, quad gather>", "k_ddmc_all<3, true, records in LDS>"}}};
-        mesh->last_variant = names[NDIM - 1][tally ? 1 : 0][gather == 3 ? 1 : gather];
+        static const char *const names[3][2][4] = {
+            {{"k_ddmc_all<1, false>", "k_ddmc_all<1, false, quad gather>", "k_ddmc_all<1, false, records in LDS>", "k_ddmc_all<1, false, cell codes>"},
+             {"k_ddmc_all<1, true>", "k_ddmc_all<1, true, quad gather>", "k_ddmc_all<1, true, records in LDS>", "k_ddmc_all<1, true, cell codes>"}},
+            {{"k_ddmc_all<2, false>", "k_ddmc_all<2, false, quad gather>", "k_ddmc_all<2, false, records in LDS>", "k_ddmc_all<2, false, cell codes>"},
+             {"k_ddmc_all<2, true>", "k_ddmc_all<2, true, quad gather>", "k_ddmc_all<2, true, records in LDS>", "k_ddmc_all<2, true, cell codes>"}},
+            {{"k_ddmc_all<3, false>", "k_ddmc_all<3, false, quad gather>", "k_ddmc_all<3, false, records in LDS>", "k_ddmc_all<3, false, cell codes>"},
+             {"k_ddmc_all<3, true>", "k_ddmc_all<3, true, quad gather>", "k_ddmc_all<3, true, records in LDS>", "k_ddmc_all<3, true, cell codes>"}}};
+        mesh->last_variant = names[NDIM - 1][tally ? 1 : 0][gather == 4 ? 3 : (gather == 3 ? 1 : gather)];
         if (tally) {
-          if (gather == 1) JB_LAUNCH_DDMC_ALL(true, 1);
+          if (gather == 4) JB_LAUNCH_DDMC_ALL(true, 4);
+          else if (gather == 1) JB_LAUNCH_DDMC_ALL(true, 1);
           else if (gather == 2) JB_LAUNCH_DDMC_ALL(true, 2);
           else if (gather == 3) JB_LAUNCH_DDMC_ALL(true, 3);
           else JB_LAUNCH_DDMC_ALL(true, 0);
           if (noabs_h) JB_LAUNCH_HANDED(true, true);
           else JB_LAUNCH_HANDED(true, false);
         } else {
-          if (gather == 1) JB_LAUNCH_DDMC_ALL(false, 1);
+          if (gather == 4) JB_LAUNCH_DDMC_ALL(false, 4);
+          else if (gather == 1) JB_LAUNCH_DDMC_ALL(false, 1);
           else if (gather == 2) JB_LAUNCH_DDMC_ALL(false, 2);
           else if (gather == 3) JB_LAUNCH_DDMC_ALL(false, 3);
           else JB_LAUNCH_DDMC_ALL(false, 0);
@@ -1032,11 +1121,13 @@ static jb_status transport_impl(jb_context *ctx, jb_mesh *mesh, const jb_swarm_v
 extern "C" jb_status jb_transport_photons(jb_context *ctx, jb_mesh *mesh,
                                           const jb_swarm_view *swarm, double t_start, double dt,
                                           int64_t first, int64_t last, int fuse_census_tally) {
+  JB_RANGE("Jaybenne::TransportPhotons");
   return transport_impl(ctx, mesh, swarm, t_start, dt, first, last, fuse_census_tally, false);
 }
 extern "C" jb_status jb_transport_photons_ddmc(jb_context *ctx, jb_mesh *mesh,
                                                const jb_swarm_view *swarm, double t_start, double dt,
                                                int64_t first, int64_t last, int fuse_census_tally) {
+  JB_RANGE("Jaybenne::TransportPhotons_DDMC");
   return transport_impl(ctx, mesh, swarm, t_start, dt, first, last, fuse_census_tally, true);
 }
 
@@ -1098,6 +1189,7 @@ extern "C" jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats 
 extern "C" jb_status jb_sample_ddmc_block_face(jb_context *ctx, jb_mesh *mesh,
                                                const jb_swarm_view *swarm, int64_t first,
                                                int64_t last) {
+  JB_RANGE("Jaybenne::SampleDDMCBlockFace");
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_sample_ddmc_block_face");
@@ -1118,6 +1210,7 @@ extern "C" jb_status jb_sample_ddmc_block_face(jb_context *ctx, jb_mesh *mesh,
 
 extern "C" jb_status jb_check_completion(jb_context *ctx, const jb_swarm_view *swarm, double t_end,
                                          int64_t *unfinished) {
+  JB_RANGE("Jaybenne::CheckCompletion");
   if (!ctx || !unfinished) return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_check_completion");
@@ -1145,6 +1238,7 @@ extern "C" jb_status jb_zero_energy_tally(jb_context *ctx, jb_mesh *mesh) {
 
 extern "C" jb_status jb_evaluate_radiation_energy(jb_context *ctx, jb_mesh *mesh,
                                                   const jb_swarm_view *swarm) {
+  JB_RANGE("Jaybenne::EvaluateRadiationEnergy");
   jb_status st = jb_zero_energy_tally(ctx, mesh);
   if (st != JB_COMPLETE) return st;
   st = check_swarm(swarm, "jb_evaluate_radiation_energy");
@@ -1157,6 +1251,7 @@ extern "C" jb_status jb_evaluate_radiation_energy(jb_context *ctx, jb_mesh *mesh
 }
 
 extern "C" jb_status jb_update_fluid(jb_context *ctx, jb_mesh *mesh) {
+  JB_RANGE("Jaybenne::UpdateFluid");
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
   if (!ctx->params.do_feedback) return JB_COMPLETE;  // jaybenne.cpp:590
@@ -1169,6 +1264,7 @@ extern "C" jb_status jb_update_fluid(jb_context *ctx, jb_mesh *mesh) {
 
 extern "C" jb_status jb_photon_reflect_bc(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
                                           int face) {
+  JB_RANGE("Jaybenne::PhotonReflectBC");
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
   if (face < 0 || face > 5) return fail(JB_ERR_INVALID, "face must be 0..5");
@@ -1182,6 +1278,7 @@ extern "C" jb_status jb_photon_reflect_bc(jb_context *ctx, jb_mesh *mesh, const 
 }
 
 extern "C" jb_status jb_remove_marked_particles(jb_context *ctx, jb_swarm_view *swarm) {
+  JB_RANGE("Jaybenne::RemoveMarkedParticles");
   if (!ctx) return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_remove_marked_particles");
@@ -1219,6 +1316,7 @@ extern "C" jb_status jb_remove_marked_particles(jb_context *ctx, jb_swarm_view *
 }
 
 extern "C" jb_status jb_defrag_particles(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm) {
+  JB_RANGE("Jaybenne::DefragParticles");
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_defrag_particles");
@@ -1384,6 +1482,7 @@ extern "C" jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_s
 extern "C" jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_swarm_view *swarm,
                                       int64_t first, int64_t last, int nranks, int64_t *records_dev,
                                       int64_t record_capacity, int64_t *counts_host) {
+  JB_RANGE("Jaybenne::MeshSend");
   if (!ctx || !mesh || !counts_host) return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_pack_outgoing");
@@ -1427,6 +1526,7 @@ extern "C" jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_s
 
 extern "C" jb_status jb_unpack_incoming(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *swarm,
                                         const int64_t *records_dev, int64_t nrecords) {
+  JB_RANGE("Jaybenne::MeshReceive");
   if (!ctx || !mesh) return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
   jb_status st = check_swarm(swarm, "jb_unpack_incoming");
@@ -1454,6 +1554,7 @@ extern "C" jb_status jb_exchange(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *
                                  int64_t *send_dev, int64_t send_capacity, int64_t *recv_dev,
                                  int64_t recv_capacity, int64_t *nsent, int64_t *nreceived,
                                  int64_t *moved_anywhere) {
+  JB_RANGE("Jaybenne::MeshSendReceive");
   if (!ctx || !mesh || !tr || !tr->all_gather_u64 || !tr->all_to_all_v || !nsent || !nreceived || !moved_anywhere)
     return fail(JB_ERR_INVALID, "null argument");
   JB_HIP(hipSetDevice(ctx->device));
@@ -1685,6 +1786,7 @@ extern "C" jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_
   if (*cycle >= (1u << 19) - 1u)   // (SourceEpoch: emission keys k and in-cycle thermal keys (1 << 19) | k must not meet)
     return fail(JB_ERR_INVALID, "jb_radiation_step: cycle counter %u at the limit of the source epochs (2^19 - 1)", *cycle);
   *cycle += 1;   // (keys the per-cell rounding streams of this cycle's emission source: SourceEpoch)
+  JB_RANGE("Jaybenne::Timestep");               // jaybenne.cpp:87 ... :145
   jb_status st = jb_update_derived_transport_fields(ctx, mesh, dt);
   if (st != JB_COMPLETE) return st;
   if (ctx->params.do_emission) {
@@ -1715,7 +1817,10 @@ extern "C" jb_status jb_radiation_step(jb_context *ctx, jb_mesh *mesh, jb_swarm_
   jb_transport_stats before;
   st = jb_get_transport_stats(ctx, &before, 0);
   if (st != JB_COMPLETE) return st;
-  st = transport_impl(ctx, mesh, swarm, t_start, dt, 0, swarm->n, 1, ctx->params.use_ddmc != 0);
+  {
+    JB_RANGE("Jaybenne::TransportLoop");        // jaybenne.cpp:115 ... :127 (one pass: every crossing is resolved in flight)
+    st = transport_impl(ctx, mesh, swarm, t_start, dt, 0, swarm->n, 1, ctx->params.use_ddmc != 0);
+  }
   if (st != JB_COMPLETE) return st;
   jb_transport_stats after;
   st = jb_get_transport_stats(ctx, &after, 0);

@@ -44,6 +44,16 @@ struct DevMesh {
   double *const *ddmc_cell;
   const double *ddmc_base;  // ddmc_cell[b] = ddmc_base + 8 b ntot
   double *ddmc_step;        // step records of k_ddmc_all's event loop (DdmcStepRec), same indexing
+  // Cell codes (k_ddmc_all<.., GATHER 4>): one 32-bit word per cell, same indexing.  Interior cells: the
+  // CLASS of the cell's step record -- k_ddmc_pack numbers the DISTINCT step records of the resident
+  // blocks each cycle (gray decks: one per level x face-neighbour pattern) and keeps them in ddmc_class
+  // (8 doubles each), which the tracking kernel copies to LDS; the event loop then gathers 4 bytes per
+  // step instead of 64.  Ghost cells (k_lam_ghost_codes, once per mesh): kCodeGhost | flags | the record
+  // number of the cell a particle that leaks there really is in (jb_kernel_ddmc.hpp: kStepGhostTable).
+  // nullptr: no codes on this mesh (>= 2^29 resident cells).
+  unsigned *ddmc_code;
+  double *ddmc_class;       // [kMaxClasses][8]
+  int *ddmc_class_slot;     // [kClassSlots][2]: hash slots {state 0 empty / 1 being written / 2 valid, class id}
   // ... and one double per cell (block b at lam_hyb + b ntot) for the hybrid kernel: the cell's
   // scattering mean free path lam_sc, with the sign bit set when the cell takes DDMC steps
   // (dx_push (sigma_a + sigma_s) > tau_ddmc) -- a lane in an IMC cell gathers nothing else
@@ -55,6 +65,8 @@ struct DevMesh {
   // set to 1 by UpdateDerivedTransportFields when some interior cell of a resident block takes
   // IMC steps (dx_push (sigma_a + sigma_s) <= tau_ddmc, transport_ddmc.cpp:135); 0 = every step
   // of every particle is a DDMC step (k_ddmc_all)
+  // ([1]: the number of distinct step records k_ddmc_pack has numbered this cycle; > kMaxClasses = the
+  // mesh has more than the tracking kernel's LDS table holds and the codes are not valid)
   int *not_all_ddmc;
   // 1.0 / ntot, 1.0 / (ni nj), 1.0 / ni (host): k_ddmc_all turns a record number back into block and
   // cell indices with them (floor(x / d) as a product and one correction)
@@ -130,6 +142,11 @@ typedef const __attribute__((address_space(4))) struct DevMesh *MeshConstPtr;
 // (that kernel keeps the block index per lane, at most kLdsBlocks = 128 resident blocks); a DDMC
 // cell's datum there is negative too, with an ordinary exponent.
 constexpr int kGhostHi = (int)0xC3300000u, kGhostTable = 1 << 19;
+// cell codes of the all-DDMC kernel (DevMesh::ddmc_code)
+constexpr int kMaxClasses = 256;            // 16 KB of LDS per workgroup at most
+constexpr int kClassSlots = 4 * kMaxClasses;
+constexpr unsigned kCodeGhost = 0x80000000u, kCodeMirror = 0x40000000u, kCodeTable = 0x20000000u;
+constexpr unsigned kCodeRecMask = 0x1fffffffu;
 constexpr int kGhostCoarser = 1 << 8, kGhostFiner = 1 << 9;
 
 enum { ST_ACTIVE = 0, ST_ABSORBED = 1, ST_ESCAPED = 2, ST_OUTGOING = 3, ST_OUTGOING_ABSORBED = 4 };

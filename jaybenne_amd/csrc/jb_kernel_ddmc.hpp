@@ -118,7 +118,18 @@ __device__ __forceinline__ unsigned quad_bcast_add(unsigned v, unsigned add) {
 // start (<= kLdsRecCells cells, 64 B each: the reference's 1-D decks, BASELINE configs[2] as
 // shipped), after which the loop issues no vector-memory instruction at all.  Measured on that
 // deck the vector L1 was busy 95 % of the kernel's time serving 4.8e9 record look-ups.
+// GATHER 4 (round 6; the default wherever it applies): the loop gathers a 4-byte CELL CODE per step
+// (DevMesh::ddmc_code) -- the class of the cell's step record, whose <= kMaxClasses distinct values
+// (k_ddmc_pack numbers them every cycle: gray decks have one per level x face-neighbour pattern) sit in
+// LDS, or for a ghost cell where a particle that leaked there really is -- instead of the 64-byte record:
+// the table of BASELINE configs[2] in 3-D shrinks from 161 MB to 10 MB (what one XCD's photons touch:
+// from 1.8 MB to 110 KB -- L1 / L2 resident), the code for the NEXT pass is requested at the end of a pass,
+// and the workgroup's 16 KB landing buffer of the quad gather is not needed.
 constexpr int kLdsRecCells = 256;
+// (NDIM < 3) pd of a leak through the "z+" arm of transport_utils.hpp:254-263 on a mesh without a z axis
+// (xim rounds onto leak_tot: one event in ~1e16): the channel is z+, the cell does not change (:256,
+// kp += three_d)
+constexpr int kPdStay = 0x20000000;
 template <int NDIM, bool TALLY, int GATHER>
 #ifndef JB_DDMC_ALL_ATTR
 #define JB_DDMC_ALL_ATTR
@@ -141,6 +152,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   unsigned long long *const counters = g1(A.counters);
   constexpr bool COOP = GATHER == 1 || GATHER == 3;   // (3: COOP with 64-bit addresses, records >= 4 GiB)
   constexpr bool NT = GATHER != 2 && JB_DDMC_NT != 0;  // non-temporal swarm accesses (see swarm_ld)
+  constexpr bool CODES = GATHER == 4;
   // PF (records in LDS: the event loop issues no vector-memory load, so one requested before it is
   // not waited for until it is needed -- the counter of outstanding loads completes in order):
   // the wave keeps a WINDOW of the next 64 slots of the swarm it will hand to its lanes, requested
@@ -168,6 +180,11 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   if constexpr (GATHER == 2) {
     double *const dst = lds_dyn + (tally_in_lds ? (ncell_all + 1) / 2 * 2 : 0);
     for (int q = threadIdx.x; q < 8 * ncell_all; q += blockDim.x) dst[q] = ((gcptr)M.ddmc_step)[q];
+  }
+  if constexpr (CODES) {   // the distinct step records of this cycle (the launch sized the room for them)
+    double *const dst = lds_dyn + (tally_in_lds ? (ncell_all + 1) / 2 * 2 : 0);
+    const int ncls = ((gcptr_i)M.not_all_ddmc)[1];
+    for (int q = threadIdx.x; q < 8 * ncls; q += blockDim.x) dst[q] = ((gcptr)M.ddmc_class)[q];
   }
   __shared__ LdsBlockTableT<false> lds_blocks;
   // [wave][quad-lane k][quad q]: the record of lane 4 q + k of the wave (LDS-direct loads deposit
@@ -244,7 +261,10 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
   // arrive in 16-dword groups, and a group the compiler parks in VGPR lanes comes back whole
   // (16 v_readlane per pass for one dword of it).
   const unsigned ntot_u = sgpr_copy((unsigned)M.ntot);
-  const double *step_base = sgpr_copy_ptr(M.ddmc_step);    // step records (event loop)
+  // step records, or (CODES) the cell codes: what the event loop gathers from
+  const double *step_base = sgpr_copy_ptr(CODES ? (const double *)M.ddmc_code : M.ddmc_step);
+  typedef const unsigned __attribute__((address_space(1))) *gcptr_u;
+  unsigned code = 0u;   // (CODES) the code of the lane's cell, requested at the end of the pass before
   const int l_ni = (int)sgpr_copy((unsigned)M.ni), l_nj = (int)sgpr_copy((unsigned)M.nj);
   const int l_is = (int)sgpr_copy((unsigned)M.is), l_ie = (int)sgpr_copy((unsigned)M.ie);
   const int l_js = (int)sgpr_copy((unsigned)M.js), l_je = (int)sgpr_copy((unsigned)M.je);
@@ -632,6 +652,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     // block?" is read off the record the next pass gathers anyway (kStepGhostTable above).
     constexpr unsigned long long kMul2 = kLcgMul * kLcgMul, kInc2 = (kLcgMul + 1ull) * kLcgInc;
     constexpr unsigned long long kMul4 = kMul2 * kMul2, kInc4 = (kMul2 + 1ull) * kInc2;
+    if constexpr (CODES) code = ((gcptr_u)step_base)[ls == DS_VIRT ? rec : 0u];
     while (nrun >= thresh) {
       ++c_pass;
       c_ev += (unsigned int)nrun;
@@ -672,6 +693,14 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         nlog = -m_log(u52_to_double(s1 >> 12));
         r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
         r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
+      } else if constexpr (CODES) {
+        nlog = -m_log(u52_to_double(s1 >> 12));   // (the step's first draw, while the code is on its way)
+        // (a ghost cell has no record: any row will do for the arithmetic nobody commits)
+        const v4d *rp = (const v4d *)(lds_rec_tab + 8u * ((int)code < 0 ? 0u : code));
+        const v4d r0 = rp[0];
+        const v4d r1 = rp[1];
+        r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
+        r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
       } else {
         typedef const v4d __attribute__((address_space(1))) *grec;
         const grec rp = (grec)((gcptr)step_base + 8ull * (unsigned long long)rq);
@@ -681,7 +710,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
         r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
       }
-      const int rcp_hi = __double2hiint(r.rcp);
+      const int rcp_hi = CODES ? (int)code : __double2hiint(r.rcp);
       const bool ghost = rcp_hi < 0;
       // transport_utils.hpp:184-191
       const double a2 = r.ffaa + r.leak_tot;
@@ -698,7 +727,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       // the first threshold above xim, as the chain of :218-254 finds it (the leak opacities of an
       // inactive axis are exactly zero -- k_ddmc_pack -- so its two thresholds repeat the one before
       // them and their comparisons can never be the first to hold); 0: none (xim beyond leak_tot)
-      int delta = (xim <= r.leak_tot) ? l_nij : 0;
+      // (without a z axis the last arm, "z+", leaves the cell where it is -- kp += three_d, :256 --: kPdStay)
+      int delta = (xim <= r.leak_tot) ? (NDIM == 3 ? l_nij : kPdStay) : 0;
       if constexpr (NDIM == 3) delta = (xim < r.c5) ? -l_nij : delta;   // (2-D: c5 = c4; 1-D: c5 = c4 = c3 = c2)
       if constexpr (multi_d) {
         delta = (xim < r.c4) ? l_ni : delta;
@@ -717,7 +747,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         pzs = leak ? s2 : pzs;
         pd = leak ? delta : pd;
         if constexpr (NDIM == 1) mir = mir && !leak;   // (a new leak: a new direction)
-        rec = leak ? rec + (unsigned)delta : rec;
+        if constexpr (NDIM == 3) rec = leak ? rec + (unsigned)delta : rec;
+        else rec = (leak && delta != kPdStay) ? rec + (unsigned)delta : rec;
         const bool done = !(t_new < t_end);
         ls = (ev && absorbed) ? DS_ABS : (done ? (ev ? DS_DONE : DS_CENSUS) : DS_VIRT);
       }
@@ -734,12 +765,16 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         // (selects, not branches with stores to one of two variables: the compiler merges such stores into
         // one store through a selected ADDRESS, which pins both variables in scratch memory)
         const bool gl = run && ghost;
-        const bool tab = gl && (rcp_hi & kStepGhostTable) != 0;
-        rec = tab ? (unsigned)__double2loint(r.rcp) : rec;
+        const bool tab = gl && (CODES ? (code & kCodeTable) != 0u : (rcp_hi & kStepGhostTable) != 0);
+        rec = tab ? (CODES ? code & kCodeRecMask : (unsigned)__double2loint(r.rcp)) : rec;
         if constexpr (multi_d) pd = tab ? kPdZero : pd;
-        if constexpr (NDIM == 1) mir = (tab && (rcp_hi & kStepGhostMirror) != 0) ? !mir : mir;
+        if constexpr (NDIM == 1)
+          mir = (tab && (CODES ? (code & kCodeMirror) != 0u : (rcp_hi & kStepGhostMirror) != 0)) ? !mir : mir;
         ls = (gl && !tab) ? DS_RELOC : ls;
       }
+      // (the code of the cell the lane is in now, for the next pass: on its way through the loop's tail and
+      // the next step's logarithm)
+      if constexpr (CODES) code = ((gcptr_u)step_base)[ls == DS_VIRT ? rec : 0u];
       nrun = __popcll(__ballot(ls == DS_VIRT));
       waste += running - nrun;
       if (waste >= kBudget) thresh = 65;
@@ -753,7 +788,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       const unsigned jj = udiv(rr, (unsigned)l_ni, inv_ni, ii);
       b = (int)bb; kp = (int)kk; jp = (int)jj; ip = (int)ii;
       const int ad = pd < 0 ? -pd : pd;
-      const int axis = ad == 1 ? 0 : (ad == l_ni ? 1 : 2);
+      const int axis = ad == 1 ? 0 : ((NDIM >= 2 && ad == l_ni) ? 1 : 2);   // (kPdStay: z+)
       pend = pd == 0 ? -1 : (pd == kPdZero ? -2 : 2 * axis + (pd > 0 ? 1 : 0));
       status = ST_ACTIVE;
       real_pos = false;

@@ -199,6 +199,10 @@ __global__ void __launch_bounds__(kBlock) k_lam_ghost_codes(DevMesh M, const int
         }
       }
       M.ddmc_step[8 * ((long long)b * M.ntot + q) + 7] = __hiloint2double((int)(0x80000000u | (unsigned)sflag), (int)srec);
+      // ... and the same as a cell code (DevMesh::ddmc_code)
+      if (M.ddmc_code != nullptr)
+        M.ddmc_code[(long long)b * M.ntot + q] =
+            kCodeGhost | ((sflag & 1) ? kCodeTable : 0u) | ((sflag & 2) ? kCodeMirror : 0u) | (srec & kCodeRecMask);
     }
     M.lam_sc[b][q] = __hiloint2double(kGhostHi | bits, (int)(16u * ntot * (unsigned)dest + 8u * dcell));
     M.lam_abs[b][q] = 1.0;
@@ -256,8 +260,79 @@ __global__ void __launch_bounds__(kBlock) k_face_prob(DevMesh M, DevParams P) {
 // {f sigma_a, sigma_a + sigma_s, leak opacities P_face / dx_d of the six faces} (instead of nine
 // gathers from seven arrays and six divisions per step).  Same values: the products, sums and
 // quotients are the ones the step functions form, from the same operands.
+// The class of one cell's step record (DevMesh::ddmc_code): its number among the DISTINCT records of this
+// cycle, found or entered in a small hash table in device memory.  The lanes of a wave that hold bit-equal
+// records are served together by one of them (on the gray decks a wave holds one or two distinct records,
+// and the table is read, not written, by all waves but the first few).  Entering a record: the slot is
+// claimed by compare-and-swap, the record and its number are written, the slot is published; a wave that
+// finds a claimed slot waits for its publication (the writer waits for nobody).  Numbers beyond
+// max_classes are handed out but not stored: the host sees the count and keeps the 64-byte gather.
+// The numbering depends on who comes first; nothing downstream does.
+__device__ __forceinline__ int classify_step_record(const DevMesh &M, const double (&r)[8], int max_classes) {
+  int *const count = M.not_all_ddmc + 1;
+  int cls = -1;
+  unsigned long long todo = __ballot(true);
+  const int lane = threadIdx.x & 63;
+  while (todo != 0ull) {
+    const int leader = __ffsll((long long)todo) - 1;
+    bool same = true;
+    unsigned h = 0x9E3779B9u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(r[q]), leader);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(r[q]), leader);
+      same = same && lo == __double2loint(r[q]) && hi == __double2hiint(r[q]);
+      h = (h ^ (unsigned)lo) * 0x85EBCA6Bu;
+      h = (h ^ (unsigned)hi) * 0xC2B2AE35u;
+    }
+    h ^= h >> 15;
+    int found = -1;
+    if (lane == leader) {
+      if (*(volatile int *)count > max_classes) {
+        found = max_classes;    // (hopeless: every cell its own record, e.g. a material with feedback)
+      } else {
+        unsigned slot = h % (unsigned)kClassSlots;
+        for (int probe = 0; probe < kClassSlots && found < 0; ++probe, slot = (slot + 1u) % (unsigned)kClassSlots) {
+          int *const st = M.ddmc_class_slot + 2 * slot;
+          int s = __hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if (s == 0) s = atomicCAS(st, 0, 1);
+          if (s == 0) {           // ours: number it, store it, publish it
+            const int id = atomicAdd(count, 1);
+            if (id < max_classes) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) M.ddmc_class[8 * id + q] = r[q];
+            }
+            st[1] = id;
+            __hip_atomic_store(st, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            found = id < max_classes ? id : max_classes;
+            break;
+          }
+          while (s == 1) s = __hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          const int id = ((volatile int *)st)[1];
+          if (id >= max_classes) { found = max_classes; break; }
+          bool eq = true;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const long long a = __double_as_longlong(((volatile double *)M.ddmc_class)[8 * id + q]);
+            eq = eq && a == __double_as_longlong(r[q]);
+          }
+          if (eq) found = id;
+        }
+        if (found < 0) {          // (table full of other records: count it as an overflow)
+          atomicAdd(count, max_classes + 1);
+          found = max_classes;
+        }
+      }
+    }
+    found = __builtin_amdgcn_readlane(found, leader);
+    cls = same ? found : cls;
+    todo &= ~__ballot(same);
+  }
+  return cls;
+}
+
 template <int NDIM>
-__global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P) {
+__global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P, int max_classes) {
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   const long long total = (long long)M.nblocks * M.ncell;
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
@@ -304,6 +379,10 @@ __global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P) {
       const double cdf_ddmc = o[0] + leak_tot + DBL_MIN;
       r[0] = o[0]; r[1] = o[2]; r[2] = c2; r[3] = c3; r[4] = c4; r[5] = c5; r[6] = leak_tot;
       r[7] = m_rcp_refined(P.c * cdf_ddmc);
+      if (M.ddmc_code != nullptr) {
+        const double rec8[8] = {r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]};
+        M.ddmc_code[(long long)b * M.ntot + q] = (unsigned)classify_step_record(M, rec8, max_classes);
+      }
     }
   }
 }

@@ -574,6 +574,22 @@ def _exchange(md: MeshData, first: int, last: int):
     return nrecv, total
 
 
+class _Range:
+    """A trace range around a part of the task list (``jb_range_push`` / ``jb_range_pop``: ROCTx, shown by
+    ``rocprofv3 --marker-trace``) -- the reference's ``Kokkos::Profiling::pushRegion("Jaybenne::Timestep")``
+    and ``("Jaybenne::TransportLoop")``, jaybenne.cpp:87,115,127,145.  Does nothing without the marker library."""
+
+    def __init__(self, md, name: str):
+        self.lib, self.name = md.lib, name.encode()
+
+    def __enter__(self):
+        self.lib.jb_range_push(self.name)
+
+    def __exit__(self, *exc):
+        self.lib.jb_range_pop()
+        return False
+
+
 class _Phase:
     """Optional wall-clock accounting of the phases of RadiationStep (``md.phase_times = {}`` to
     switch it on; each phase then ends with a device synchronisation, so leave it off when
@@ -604,20 +620,14 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
     for another rank's blocks, SampleDDMCBlockFace on the arrivals, and the global completion
     test (one all-reduced integer) -- repeated until no particle is in flight anywhere.
     """
+    with _Range(md, "Jaybenne::Timestep"):          # jaybenne.cpp:87 ... :145
+        return _radiation_step(md, t_start, dt)
+
+
+def _transport_loop(md: MeshData, transport, use_ddmc: bool, t_start: float, dt: float) -> bool:
+    """The iterate-sublist of jaybenne.cpp:113-131; False when max_transport_iterations passes did
+    not finish it (TaskStatus.iterate)."""
     pkg = md.pkg
-    use_ddmc = bool(pkg.Param("use_ddmc"))
-    transport = TransportPhotons_DDMC if use_ddmc else TransportPhotons
-    md.cycle += 1
-    with _Phase(md, "derived+source"):
-        UpdateDerivedTransportFields(md, dt)
-        SourcePhotons(md, SourceType.emission, t_start, dt)
-        # (the ddmc_face_prob ghost exchange of jaybenne.cpp:108-110 has no consumer: every face
-        # the transport and resampling kernels read belongs to the block itself)
-        md._sync_stream()
-        _lib.check(md.lib.jb_zero_energy_tally(pkg.ctx, md.handle))
-        # (the counters are cumulative: the previous step's closing read is this step's opening one,
-        # one device synchronisation per step instead of two)
-        before = md._stats_cache if md._stats_cache is not None else md.stats()
     first = 0
     md.transport_iterations = 0
     for it in range(int(pkg.Param("max_transport_iterations"))):
@@ -627,8 +637,8 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
         md.transport_iterations += 1
         md.transport_iterations_total += 1
         if (md.nranks == 1 or md.replicated) and not (md.force_exchange and md.comm is not None):
-            break
-        with _Phase(md, "exchange"):
+            return True
+        with _Phase(md, "exchange"), _Range(md, "Jaybenne::MeshSendReceive"):
             # the hand-off clock starts when the transport launch has finished (its first device
             # read-back would otherwise be charged with the whole kernel)
             t_w = time.perf_counter()
@@ -640,13 +650,39 @@ def RadiationStep(md: MeshData, t_start: float, dt: float) -> TaskStatus:
             nrecv, moved = _exchange(md, first, last)
             md.exchange_seconds += time.perf_counter() - t_x
         if moved == 0:
-            break
+            return True
         first = md.n - nrecv        # the arrivals, appended at the end of the swarm
         if use_ddmc and nrecv:
             with _Phase(md, "block_face"):
                 SampleDDMCBlockFace(md, first, md.n)
-    else:
-        return TaskStatus.iterate
+    return False
+
+
+def _radiation_step(md: MeshData, t_start: float, dt: float) -> TaskStatus:
+    pkg = md.pkg
+    use_ddmc = bool(pkg.Param("use_ddmc"))
+    transport = TransportPhotons_DDMC if use_ddmc else TransportPhotons
+    md.cycle += 1
+    with _Phase(md, "derived+source"):
+        UpdateDerivedTransportFields(md, dt)
+        SourcePhotons(md, SourceType.emission, t_start, dt)
+        if md.replicated and md.rank != 0 and not pkg.Param("do_emission"):
+            # Replicated mesh without the emission source: nothing resets energy_delta (sourcing.cpp:41-43
+            # returns before :165-166 -- SURVEY App. C quirk 5), so behind last cycle's all-reduce EVERY rank
+            # holds the global sum of all cycles so far.  One rank keeps carrying it; the others start the
+            # cycle at zero and contribute their increment only -- the sum over ranks is then "everything so
+            # far + this cycle's absorptions" once, not nranks times.
+            md.fields["edelta"].zero_()
+        # (the ddmc_face_prob ghost exchange of jaybenne.cpp:108-110 has no consumer: every face
+        # the transport and resampling kernels read belongs to the block itself)
+        md._sync_stream()
+        _lib.check(md.lib.jb_zero_energy_tally(pkg.ctx, md.handle))
+        # (the counters are cumulative: the previous step's closing read is this step's opening one,
+        # one device synchronisation per step instead of two)
+        before = md._stats_cache if md._stats_cache is not None else md.stats()
+    with _Range(md, "Jaybenne::TransportLoop"):     # jaybenne.cpp:115 ... :127
+        if not _transport_loop(md, transport, use_ddmc, t_start, dt):
+            return TaskStatus.iterate
     with _Phase(md, "compaction+fluid"):
         after = md.stats()
         md._stats_cache = after

@@ -174,6 +174,68 @@ def test_full_size_invariants_c3(gpu_device):
         assert bool((b.md.swarm[k][:n0] == ref).all()), k
 
 
+def test_full_size_invariants_c3_1d(gpu_device):
+    """BASELINE configs[2] AS SHIPPED (inputs/stepdiff_ddmc.in: 1-D, 128 cells in one block, every step a
+    DDMC step) at its full 1e8 photons -- 7.8e5 per cell, the LDS-tally / atomics stress case: the
+    property set of test_full_size_invariants_c3 after one cycle (conservation, census, |v| = c, cell <->
+    position, tally integral, run-to-run determinism of every particle state), then the reference's own
+    acceptance test at that size: ten cycles and the weighted error against the erf profile under the 0.05
+    gate of tst/stepdiff.py:29-55 (at 1e8 photons the Monte Carlo noise is gone: what is left is the
+    method's own discretisation error on 128 cells)."""
+    import torch
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    from jaybenne_amd import analysis, mcblock
+    n_target = 100_000_000
+
+    def run():
+        drv = mcblock.McblockDriver(bench.make_deck(1, n_target, 64, "c3-1d"), device=gpu_device,
+                                    capacity_factor=1.05)
+        n0 = drv.md.n
+        e0 = float(drv.md.swarm["w"][:n0].sum())
+        drv.Step()
+        return drv, n0, e0
+
+    a, n0, e0 = run()
+    md, m = a.md, a.mesh
+    assert m.ndim == 1 and m.nblocks == 1 and m.nx[0] == 128
+    assert abs(n0 - n_target) < 100_000
+    assert md.n == n0
+    assert "k_ddmc_all<1" in md.lib.jb_last_transport_variant(md.handle).decode()
+    st = md.stats()
+    assert st["n_absorbed"] == st["n_escaped"] == st["n_outgoing"] == 0 and st["n_census"] == n0
+    assert 5 < st["n_events"] / n0 < 25
+    sw = md.swarm
+    assert float(sw["w"][:n0].sum()) == e0
+    assert bool((sw["t"][:n0] >= a.time * (1 - 1e-15)).all())
+    v = torch.sqrt(sw["vx"][:n0] ** 2 + sw["vy"][:n0] ** 2 + sw["vz"][:n0] ** 2)
+    assert float((v / 2.99792458e10 - 1).abs().max()) < 1e-14
+    del v
+    assert bool((sw["status"][:n0] == 0).all())
+    sl = m.interior()
+    dv = m.cell_volume(0)
+    assert float(md.fields["tally"][sl].sum()) * dv == pytest.approx(e0, rel=1e-11)
+    cell = torch.floor((sw["x"][:n0] - float(m.blk_xmin[0, 0])) / float(m.blk_dx[0, 0])).int() + m.ng
+    assert bool((cell == sw["ip"][:n0]).all())
+    assert int(cell.min()) >= m.ng and int(cell.max()) < m.ng + m.nx[0]
+    del cell
+    keep = {k: sw[k][:n0].clone() for k in ("x", "y", "z", "vx", "rng", "id")}
+    # ... on to the end of the deck: ten cycles, the erf gate
+    for _ in range(9):
+        a.Step()
+    assert md.n == n0 and float(sw["w"][:n0].sum()) == e0
+    err = analysis.analytic_errors(m, md.get_field("tally"), a.time)["mean_frac_error_weighted"]
+    print("configs[2] as shipped, 1e8 photons, 10 cycles: weighted error against the erf profile", err)
+    assert np.isfinite(err) and err <= 0.05
+    del a, md, sw
+    torch.cuda.empty_cache()
+    b, n1, _ = run()
+    assert n1 == n0
+    for k, ref in keep.items():
+        assert bool((b.md.swarm[k][:n0] == ref).all()), k
+
+
 def _full_size_smr_invariants(gpu_device, workload, n_target, ev_lo, ev_hi):
     """The property set of test_full_size_invariants_c3 on a statically refined 2-D mesh: particle and
     energy conservation (sigma_a = 0, reflecting / periodic walls), every history at census, |v| = c,

@@ -230,7 +230,7 @@ FEEDBACK = dict(SMR, **{"jaybenne/num_particles": 30000, "jaybenne/do_emission":
                         "mcblock/opacity_constant_value": 20.0})
 
 
-def _feedback_worker(rank, world, port, outdir, decomposition="blocks"):
+def _feedback_worker(rank, world, port, outdir, decomposition="blocks", overrides=None):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -238,7 +238,7 @@ def _feedback_worker(rank, world, port, outdir, decomposition="blocks"):
     try:
         from jaybenne_amd import mcblock
         from jaybenne_amd.comm import Comm
-        drv = mcblock.McblockDriver(load_deck("stepdiff_smr_hybrid", FEEDBACK), rank=rank,
+        drv = mcblock.McblockDriver(load_deck("stepdiff_smr_hybrid", dict(FEEDBACK, **(overrides or {}))), rank=rank,
                                     nranks=world, comm=Comm(), device=torch.device("cuda", 0),
                                     capacity_factor=8.0, decomposition=decomposition)
         if decomposition == "blocks":
@@ -249,7 +249,8 @@ def _feedback_worker(rank, world, port, outdir, decomposition="blocks"):
         g["gblk"] = drv.md.gids[g["blk"]]
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), gids=drv.md.gids,
                  u=drv.md.fields["u"].cpu().numpy(), resident=drv.md.resident_gids,
-                 tally=drv.md.get_field("tally"), fleck=drv.md.get_field("fleck"), **g)
+                 tally=drv.md.get_field("tally"), fleck=drv.md.get_field("fleck"),
+                 edelta=drv.md.get_field("edelta"), **g)
     finally:
         dist.destroy_process_group()
 
@@ -321,6 +322,38 @@ def test_replicated_mesh_with_material_feedback(gpu_device, tmp_path):
         assert np.array_equal(p["u"], parts[0]["u"])
         np.testing.assert_allclose(p["u"], O.fields["u"], rtol=1e-12, atol=0)
         np.testing.assert_allclose(p["tally"][sl], O.fields["tally"][sl], rtol=1e-11)
+
+
+def test_replicated_mesh_feedback_without_the_emission_source(gpu_device, tmp_path):
+    """do_emission = false, do_feedback = true on two ranks with the mesh replicated, three cycles: nothing
+    resets energy_delta then (sourcing.cpp:41-43 returns before :165-166), it ACCUMULATES over the cycles
+    and UpdateFluid deposits the running sum every cycle (jaybenne.cpp:583-615) -- so behind cycle 1's
+    all-reduce every rank holds the global sum, and cycle 2's all-reduce must add only the cycle's own
+    absorptions to it, not nranks copies of what is already there.  energy_delta and u of every
+    rank against the single-process oracle."""
+    from oracle import orc
+    sys.path.insert(0, os.path.dirname(__file__))
+    ov = {"jaybenne/do_emission": "false"}
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_feedback_worker, args=(r, 2, port, str(tmp_path), "replicated", ov)) for r in range(2)]
+    _run_workers(procs)
+    pin = load_deck("stepdiff_smr_hybrid", dict(FEEDBACK, **ov))
+    O, mesh, _ = make_oracle(pin, orc.MATH_PORTABLE, capacity_factor=8.0)
+    run_oracle_cycles(O, pin, 3)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    sl = mesh.interior()
+    assert np.abs(O.fields["edelta"][sl]).max() > 0.0, "the case must absorb something"
+    for p in parts:
+        np.testing.assert_allclose(p["edelta"][sl], O.fields["edelta"][sl], rtol=1e-11, atol=0)
+        np.testing.assert_allclose(p["u"], O.fields["u"], rtol=1e-11, atol=0)
+        assert np.array_equal(p["u"], parts[0]["u"])
+    ids = np.concatenate([p["id"] for p in parts])
+    order = np.argsort(ids)
+    oo = np.argsort(O.sw["id"][:O.n])
+    assert len(ids) == O.n and np.array_equal(ids[order], O.sw["id"][:O.n][oo])
+    for k in ("ip", "jp", "kp", "rng"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts])[order], O.sw[k][:O.n][oo]), k
 
 
 def _read_photon_dumps(prefix, nranks):

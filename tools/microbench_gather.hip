@@ -23,6 +23,8 @@ constexpr unsigned long long kMul = 6364136223846793005ull, kInc = 1442695040888
 
 struct Args {
   const double *rec;        // 8 doubles per record
+  const unsigned *code;     // FORM 2 / 3: one 32-bit code per cell (class id; bit 31: ghost)
+  const unsigned char *code8;  // FORM 4: one byte per cell (class id; bit 7: ghost)
   unsigned long long *queue;  // kQueues cursors
   double *sink;
   long long nwalk;
@@ -42,14 +44,26 @@ __device__ __forceinline__ unsigned quad_bcast_add(unsigned v, unsigned add) {
   return (unsigned)__builtin_amdgcn_mov_dpp((int)v, ctrl, 0xf, 0xf, true) + add;
 }
 
-// FORM 0: quad-cooperative LDS-direct gather; 1: four 16-byte loads per lane (two dwordx4 pairs)
+// FORM 0: quad-cooperative LDS-direct gather; 1: four 16-byte loads per lane (two dwordx4 pairs);
+// 2: a 4-byte CELL CODE gathered per step, the (few) distinct records in LDS, addressed by the code;
+// 3: the code gathered, ONE record held in scalar registers; 4: a 1-byte code, records in LDS; 5: no gather at all
 template <int FORM, int FILL, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_walk(Args A) {
-  __shared__ __attribute__((aligned(16))) char lds_rec[4][4][1024];
+  __shared__ __attribute__((aligned(16))) char lds_rec[FORM == 0 ? 4 : 1][4][FORM == 0 ? 1024 : 16];
+  __shared__ __attribute__((aligned(16))) double lds_cls[(FORM == 2 || FORM == 4) ? 8 * 16 : 8];
+  if constexpr (FORM == 2 || FORM == 4) {
+    if (threadIdx.x < 8 * 16) lds_cls[threadIdx.x] = A.rec[(size_t)8 * (size_t)(2 * A.ni * A.nj + 2 * A.ni + 2) + (threadIdx.x & 7)];
+    __syncthreads();
+  }
+  double sr[8];
+  if constexpr (FORM == 3 || FORM == 5) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sr[q] = A.rec[(size_t)8 * (size_t)(2 * A.ni * A.nj + 2 * A.ni + 2) + q];
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   typedef __attribute__((address_space(3))) char *lchar;
-  lchar const wave_buf = (lchar)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lchar)&lds_rec[wv][0][0]);
-  const v4d *my_rec = (const v4d *)&lds_rec[wv][lane & 3][64 * (lane >> 2)];
+  lchar const wave_buf = (lchar)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lchar)&lds_rec[FORM == 0 ? wv : 0][0][0]);
+  const v4d *my_rec = (const v4d *)&lds_rec[FORM == 0 ? wv : 0][lane & 3][FORM == 0 ? 64 * (lane >> 2) : 0];
   const unsigned sub16 = 16u * (unsigned)(lane & 3);
   const int ni = A.ni, nij = A.ni * A.nj, ntot = nij * A.nk;
   const int nx = A.ni - 2 * A.ng, ny = A.nj - 2 * A.ng, nz = A.nk - 2 * A.ng;
@@ -115,11 +129,27 @@ __global__ void __launch_bounds__(256, WAVES) k_walk(Args A) {
       __builtin_amdgcn_s_waitcnt(0x0f70);
       r0 = my_rec[0];
       r1 = my_rec[1];
-    } else {
+    } else if constexpr (FORM == 1) {
       const v4d *rp = (const v4d *)(A.rec + 8ull * rq);
       r0 = rp[0];
       r1 = rp[1];
       s = s * kMul + kInc;
+    } else if constexpr (FORM == 2 || FORM == 4) {
+      unsigned code;
+      if constexpr (FORM == 2) code = A.code[rq];
+      else { const unsigned c8 = A.code8[rq]; code = (c8 & 0x7fu) | ((c8 & 0x80u) << 24); }
+      s = s * kMul + kInc;
+      const v4d *rp = (const v4d *)(lds_cls + 8u * (code & 15u));
+      r0 = rp[0];
+      r1 = rp[1];
+      if ((int)code < 0) r1.w = -1.0;
+    } else {
+      unsigned code = 0u;
+      if constexpr (FORM == 3) code = A.code[rq];
+      else code = (rq * 2654435761u) < 40000000u ? 0x80000000u : 0u;   // (about 1 % "ghosts", from arithmetic)
+      s = s * kMul + kInc;
+      r0.x = sr[0]; r0.y = sr[1]; r0.z = sr[2]; r0.w = sr[3];
+      r1.x = sr[4]; r1.y = sr[5]; r1.z = sr[6]; r1.w = (int)code < 0 ? -1.0 : sr[7];
     }
     double u = (double)(s >> 11) * 0x1.0p-53;
     double f = r0.x + r1.w;
@@ -182,13 +212,19 @@ int main(int argc, char **argv) {
     const int i = (int)(c % A.ni), j = (int)((c / A.ni) % A.nj), k = (int)(c / ((size_t)A.ni * A.nj));
     if (i < A.ng || i >= A.ni - A.ng || j < A.ng || j >= A.nj - A.ng || k < A.ng || k >= A.nk - A.ng) r[7] = -1.0;
   }
+  std::vector<unsigned> hc(nrec);
+  std::vector<unsigned char> hc8(nrec);
+  for (size_t q = 0; q < nrec; ++q) { hc[q] = h[8 * q + 7] < 0.0 ? 0x80000000u : 0u; hc8[q] = h[8 * q + 7] < 0.0 ? 0x80u : 0u; }
+  unsigned *code_d; unsigned char *code8_d;
+  HIP_OK(hipMalloc(&code_d, nrec * 4)); HIP_OK(hipMemcpy(code_d, hc.data(), nrec * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&code8_d, nrec)); HIP_OK(hipMemcpy(code8_d, hc8.data(), nrec, hipMemcpyHostToDevice));
   double *rec_d, *sink;
   unsigned long long *queue;
   HIP_OK(hipMalloc(&rec_d, h.size() * 8));
   HIP_OK(hipMemcpy(rec_d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMalloc(&sink, 8));
   HIP_OK(hipMalloc(&queue, kQueues * 8));
-  A.rec = rec_d; A.sink = sink; A.queue = queue;
+  A.rec = rec_d; A.sink = sink; A.queue = queue; A.code = code_d; A.code8 = code8_d;
   std::printf("%lld walkers, ~%d moves each, %d per cell, %zu records of 64 B (%.0f MB)\n", A.nwalk, A.steps, A.per_cell,
               nrec, nrec * 64 / 1e6);
   std::printf("form  fill  waves/SIMD   ms\n");
@@ -198,6 +234,8 @@ int main(int argc, char **argv) {
     A.mode = mode;
     std::printf("mode %d (%s)\n", mode, mode == 0 ? "the walk" : mode == 1 ? "gathers within 16 KB" : "gathers scattered over the table");
     RUN(0, 0, 4); RUN(0, 0, 8); RUN(0, 100, 4); RUN(1, 0, 4);
+    RUN(2, 0, 4); RUN(2, 0, 8); RUN(2, 60, 4); RUN(2, 100, 4); RUN(3, 0, 4); RUN(3, 100, 4); RUN(4, 0, 4); RUN(4, 100, 4);
+    if (mode == 0) { RUN(5, 0, 4); RUN(5, 100, 4); RUN(2, 100, 5); RUN(2, 100, 6); RUN(2, 100, 8); RUN(3, 100, 8); }
   }
   A.mode = 0;
   RUN(0, 0, 2); RUN(0, 0, 3); RUN(0, 0, 6); RUN(0, 60, 4); RUN(0, 100, 2); RUN(0, 100, 3); RUN(0, 100, 6); RUN(0, 100, 8);
