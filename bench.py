@@ -31,8 +31,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-L2_GATHER_PEAK_GBS = 16800.0  # MI355X_MICROARCH.md, "Indexed rows": rows shared through the XCDs' L2,
-                              # 16.8-18.8 TB/s chip-wide (the lower figure)
 BYTES_PER_DDMC_STEP = 64.0   # one cell record {f sigma_a, sigma, six leak opacities} per DDMC step
 FP64_VALU_PEAK_TF = 78.6     # vector FP64, 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 BYTES_PER_HISTORY = 168.0    # 84 B read + 68 B write-back + 16 B census tally RMW
@@ -612,7 +610,7 @@ def main() -> None:
         # counters of this very command under rocprofv3 (separate --pmc passes), if a committed
         # summary matches workload and size: labelled as read from that file, not measured now
         pmc, pmc_file = None, None
-        for rnd in ("r05", "r05_exact", "r04", "r04_exact", "r03", "r03_exact", "r02", "r02_exact", "r01_g"):
+        for rnd in ("r06", "r06_exact", "r05", "r05_exact", "r04", "r04_exact", "r03", "r03_exact", "r02", "r02_exact", "r01_g"):
             f = os.path.join(ROOT, "profiles", f"{rnd.split('_exact')[0]}_pmc_summary_{args.workload}"
                                                f"{'_exact' if rnd.endswith('_exact') else ''}.json")
             try:
@@ -632,45 +630,47 @@ def main() -> None:
         fp64 = k_events * FLOPS_PER_EVENT / k_time / 1e12 if k_time > 0 else 0.0
         l2_gbs = k_bytes / k_time / 1e9 if k_time > 0 else 0.0
         if ddmc_bound:
-            # DDMC regime: the bytes HBM has to move per launch are the particle stream (168 B per
-            # history) plus one pass over the cell records (72 B per cell) -- a few
-            # hundred GB/s.
-            # (what binds this kernel is the rate at which the cache hierarchy serves
-            # the per-step gather of one 64-byte cell record -- L2 first, Infinity Cache behind it --
-            # not HBM: that is the roofline reported; the HBM-side figure stays beside it)
-            cells = float(md.nblocks) * float(np.prod(md.mesh.nx))
-            alg = k_hist * BYTES_PER_HISTORY + len(kt) * cells * 72.0
+            # DDMC regime: the bound reported is HBM -- what the kernel HAS to move per launch is
+            # the particle stream (168 B per history) and its per-cell table once (cell codes: 4 B per cell
+            # incl. ghosts; the 64-byte record forms: 64 B) -- and `frac` is that rate over 8 TB/s, small by
+            # the nature of the path (a history is ~34 dependent steps of ~110 FP64-heavy instructions each for
+            # 168 bytes).  What the steps gather through L1 / L2 is reported beside it, as a rate, against the
+            # guide's figure for a table of that size -- a secondary figure, not the bound.
+            codes = "cell codes" in variant
+            in_lds = "records in LDS" in variant
+            cells_all = float(md.nblocks) * float(md.mesh.field_shape[1] * md.mesh.field_shape[2] * md.mesh.field_shape[3])
+            per_cell = 4.0 if codes else 64.0
+            alg = k_hist * BYTES_PER_HISTORY + len(kt) * cells_all * per_cell
             hbm = alg / k_time / 1e9 if k_time > 0 else 0.0
-            gather = k_events * BYTES_PER_DDMC_STEP / k_time / 1e9 if k_time > 0 else 0.0
-            roof = {"bound": "l2_gather", "achieved": gather, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
-                    "frac": gather / L2_GATHER_PEAK_GBS,
+            per_step = 0.0 if in_lds else (4.0 if codes else BYTES_PER_DDMC_STEP)
+            gather = k_events * per_step / k_time / 1e9 if k_time > 0 else 0.0
+            table_mb = cells_all * per_cell / 1e6
+            roof = {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm / HBM_PEAK_GBS,
                     "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
-                    "definition": "DDMC steps x 64 B (one cell record gathered per step) / k_ddmc_all "
-                                  "time (HIP events, this run), against the chip-wide rate at which "
-                                  "the XCDs' L2 serve gathered rows (MI355X_MICROARCH.md: 16.8-18.8 "
-                                  "TB/s; 8.6 TB/s from the Infinity Cache)",
-                    "hbm_GBps_algorithmic": hbm, "hbm_frac": hbm / HBM_PEAK_GBS,
-                    "hbm_definition": "168 B per history + 72 B per cell record, each moved once / "
-                                      "kernel time, against 8 TB/s",
-                    "l2_served_GBps": l2_gbs,
-                    "l2_served_definition": "168 B per history + 72 B of cell gathers per DDMC step / "
-                                            "kernel time"}
-            if "records in LDS" in variant:
-                # a mesh of <= 256 cells: the kernel copies the step records into LDS once and its
-                # event loop issues no vector-memory instruction -- nothing is gathered through L2;
-                # what HBM has to move is the particle stream, and that is the bound reported
-                roof.update({"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "frac": hbm / HBM_PEAK_GBS,
-                             "definition": "168 B per history (84 B read, 68 B write-back, 16 B tally) / "
-                                           "k_ddmc_all time (HIP events, this run), against 8 TB/s: the "
-                                           "cell records live in LDS (copied once per launch), the only "
-                                           "HBM traffic is the particle stream",
-                             "lds_served_GBps": gather,
-                             "lds_served_definition": "DDMC steps x 64 B read from the LDS copy of the "
-                                                      "records / kernel time"})
+                    "definition": "(168 B per history: 84 B read, 68 B write-back, 16 B tally + the kernel's "
+                                  f"per-cell table read once: {per_cell:.0f} B per cell) / k_ddmc_all time (HIP events, "
+                                  "this run), against 8 TB/s",
+                    "algorithmic_hbm_bytes_per_launch": alg / max(len(kt), 1),
+                    "gathered_GBps": gather,
+                    "gathered_table_MB": table_mb,
+                    "gathered_definition": ("nothing: the step records of all cells sit in LDS" if in_lds else
+                                            f"DDMC steps x {per_step:.0f} B "
+                                            + ("(one 4-byte cell code per step; the distinct step records, "
+                                               f"{int(md.lib.jb_mesh_ddmc_classes(md.handle))} of them, are read from LDS)" if codes
+                                               else "(one 64-byte step record per step)")
+                                            + " / kernel time; the guide's gather rates for comparison "
+                                              "(MI355X_MICROARCH.md, 'Indexed rows'): 16.8-18.8 TB/s for rows "
+                                              "shared through L2, 8.6 TB/s from a 38 MB table, 7.4-7.9 TB/s from "
+                                              "a 151 MB one"),
+                    "lds_served_GBps": k_events * 64.0 / k_time / 1e9 if (k_time > 0 and (codes or in_lds)) else 0.0}
         else:
+            cells_all = float(md.nblocks) * float(md.mesh.field_shape[1] * md.mesh.field_shape[2] * md.mesh.field_shape[3])
             roof = {"bound": "fp64_valu", "achieved": fp64, "peak": FP64_VALU_PEAK_TF,
                     "unit": "TFLOP/s", "frac": fp64 / FP64_VALU_PEAK_TF,
                     "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                    # what HBM has to move per launch: the particle stream + the per-cell mean free paths once
+                    "algorithmic_hbm_bytes_per_launch": (k_hist * BYTES_PER_HISTORY + len(kt) * cells_all * 16.0) / max(len(kt), 1),
                     "definition": "events x 200 FP64 flop-equivalents (SURVEY 8d) / k_transport time "
                                   "(HIP events, this run), against the vector FP64 peak; the IMC "
                                   "regime is bound by VALU instruction issue, not by HBM",
@@ -703,6 +703,8 @@ def main() -> None:
             "stored_bytes_per_launch": 84.0 * finished / max(main_stats_launches, 1),
             "note": "cumulative counters of the library since the process started (warm-up and timed launches "
                     "alike) divided by the number of launches they cover"}
+        if pmc and roof.get("traffic") and roof.get("algorithmic_hbm_bytes_per_launch"):
+            roof["wasted_traffic_ratio"] = roof["traffic"] / roof["algorithmic_hbm_bytes_per_launch"]
         if pmc:
             roof["counters"] = {"source": pmc_file + " (rocprofv3 --pmc passes of this command; "
                                                      "not measured in this run)",

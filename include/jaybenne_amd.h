@@ -284,13 +284,21 @@ int jb_get_arithmetic(const jb_context *ctx);
  * absorption), EXACT (exact cell-face arithmetic, 32-bit cell offsets), LEAN (lean arithmetic)>;
  * "k_ddmc_all<3, true>" = <NDIM, TALLY> on a mesh whose every cell takes DDMC steps (", quad gather"
  * appended when its cell records, more than 1 MiB of them, are fetched quad-cooperatively,
- * ", records in LDS" when the mesh has at most 256 cells and the kernel keeps them in LDS);
+ * ", records in LDS" when the mesh has at most 256 cells and the kernel keeps them in LDS,
+ * ", cell codes" when the mesh has at most 256 DISTINCT step records: jb_mesh_ddmc_classes);
  * "k_hybrid<2, lean, exact geometry>" on a mesh that mixes IMC and DDMC cells (three launches: IMC
  * phase, DDMC phase, remainder); "" before the first launch.  jb_mesh_exact_geometry: 1 if every
  * resident block has power-of-two cell widths and a lower corner that is a whole number of them
  * (and the per-cell arrays of the resident blocks span less than 4 GiB). */
 const char *jb_last_transport_variant(const jb_mesh *mesh);
 int jb_mesh_exact_geometry(const jb_mesh *mesh);
+/* All-DDMC meshes: the number of DISTINCT step records UpdateDerivedTransportFields found among the
+ * resident cells this cycle, as the last jb_transport_photons_ddmc call read it back (0 before the
+ * first; gray decks: one per level x face-neighbour pattern).  Up to 256 of them the tracking kernel
+ * keeps the records in LDS and gathers a 4-byte cell code per step (variant "..., cell codes");
+ * beyond (e.g. a material whose Fleck factor differs from cell to cell) it gathers the 64-byte step
+ * record of the cell.  Same results either way. */
+int jb_mesh_ddmc_classes(const jb_mesh *mesh);
 /* counters accumulated by the transport tasks since the last reset (synchronises) */
 jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats *stats, int reset);
 

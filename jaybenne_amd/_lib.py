@@ -116,6 +116,7 @@ PROTOTYPES = {
                                          _int]),
     "jb_last_transport_variant": (C.c_char_p, [_vp]),
     "jb_mesh_exact_geometry": (_int, [_vp]),
+    "jb_mesh_ddmc_classes": (_int, [_vp]),
     "jb_get_transport_stats": (_int, [_vp, C.POINTER(TransportStats), _int]),
     "jb_sample_ddmc_block_face": (_int, [_vp, _vp, C.POINTER(SwarmView), _i64, _i64]),
     "jb_check_completion": (_int, [_vp, C.POINTER(SwarmView), _f64, C.POINTER(_i64)]),

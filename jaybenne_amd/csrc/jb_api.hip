@@ -1135,6 +1135,7 @@ extern "C" const char *jb_last_transport_variant(const jb_mesh *mesh) {
   return mesh ? mesh->last_variant : "";
 }
 extern "C" int jb_mesh_exact_geometry(const jb_mesh *mesh) { return mesh && mesh->exact_geom; }
+extern "C" int jb_mesh_ddmc_classes(const jb_mesh *mesh) { return mesh ? mesh->nclass_host : 0; }
 extern "C" jb_status jb_set_arithmetic(jb_context *ctx, int mode) {
   if (!ctx || (mode != JB_ARITH_EXACT && mode != JB_ARITH_LEAN)) return fail(JB_ERR_INVALID, "bad argument");
   ctx->lean_arith = mode == JB_ARITH_LEAN;

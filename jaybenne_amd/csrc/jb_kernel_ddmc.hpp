@@ -84,6 +84,10 @@ __device__ __forceinline__ T swarm_ld(const T *p) {
 }
 template <bool NT, class T, class V>
 __device__ __forceinline__ void swarm_st(T *p, V v) {
+#ifdef JB_DDMC_EXP_NOSTORE   // (timing experiment, tools/dev/ab1.sh: what the write-back costs; results are wrong)
+  if (v == (V)-12345) *p = (T)v;
+  return;
+#endif
   if constexpr (NT) __builtin_nontemporal_store((T)v, p);
   else *p = (T)v;
 }
@@ -652,10 +656,90 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
     // block?" is read off the record the next pass gathers anyway (kStepGhostTable above).
     constexpr unsigned long long kMul2 = kLcgMul * kLcgMul, kInc2 = (kLcgMul + 1ull) * kLcgInc;
     constexpr unsigned long long kMul4 = kMul2 * kMul2, kInc4 = (kMul2 + 1ull) * kInc2;
-    if constexpr (CODES) code = ((gcptr_u)step_base)[ls == DS_VIRT ? rec : 0u];
+    if constexpr (CODES) {
+      // (nothing of the service phase is left in flight when the loop starts: the compiler places a full wait
+      // at the loop's top otherwise -- for registers the service phase's loads were headed for -- and that wait
+      // would then be taken in every pass, in front of the code's first use)
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+      code = ((gcptr_u)step_base)[ls == DS_VIRT ? rec : 0u];
+    }
     while (nrun >= thresh) {
       ++c_pass;
       c_ev += (unsigned int)nrun;
+      if constexpr (CODES) {
+        // The same step (transport_utils.hpp:184-263 on the virtual state: see the general form below) arranged
+        // around ONE 4-byte gather whose result is not needed until a third of the way into the NEXT pass: what
+        // does not depend on the cell -- the three stream states, the two uniforms, the logarithm -- comes first;
+        // then the code that was requested at the end of the pass before is read (its register is dead from
+        // there on: the request for the next pass can land in it without a copy, i.e. without a wait at the
+        // loop's tail); everything is committed through selects, no branch but the ghost lanes' block.
+        const bool run = ls == DS_VIRT;
+        const unsigned long long s0 = rng.s;
+        const unsigned long long s1 = s0 * kLcgMul + kLcgInc;
+        const unsigned long long s2 = s0 * kMul2 + kInc2;
+        const unsigned long long s4 = s0 * kMul4 + kInc4;
+        const double u2 = u52_to_double(s2 >> 12);
+        const double nlog = -m_log(u52_to_double(s1 >> 12));
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned cd = code;
+        const bool ghost = (int)cd < 0;
+        // (a ghost cell has no record: any row will do for the arithmetic nobody commits)
+        const v4d *rp = (const v4d *)(lds_rec_tab + 8u * (ghost ? 0u : cd));
+        const v4d r0 = rp[0];
+        const v4d r1 = rp[1];
+        DdmcStepRec r;
+        r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
+        r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
+        const bool gl = run && ghost;
+        const unsigned long long gm = __ballot(gl);
+        c_ghost += (unsigned int)__popcll(gm);   // (no step taken: not an event)
+        if (gm != 0ull) {   // a leak through a block face: see the general form below
+          const bool tab = gl && (cd & kCodeTable) != 0u;
+          rec = tab ? cd & kCodeRecMask : rec;
+          if constexpr (multi_d) pd = tab ? kPdZero : pd;
+          if constexpr (NDIM == 1) mir = (tab && (cd & kCodeMirror) != 0u) ? !mir : mir;
+          ls = (gl && !tab) ? DS_RELOC : ls;
+        }
+        const bool live = run && !ghost;
+        // transport_utils.hpp:184-191
+        const double a2 = r.ffaa + r.leak_tot;
+        const double cdf_ddmc = a2 + DBL_MIN;
+        const double dt_ddmc = m_div_r(nlog, vv * cdf_ddmc, r.rcp);
+        const double dt_end = t_end - t;
+        const bool ev = dt_ddmc < dt_end;
+        const double t_new = t + dmin(dt_ddmc, dt_end);
+        // :196-254
+        const double xi = cdf_ddmc * u2;
+        const bool absorbed = xi < r.ffaa;
+        const double xim = xi - r.ffaa;
+        int delta = (xim <= r.leak_tot) ? (NDIM == 3 ? l_nij : kPdStay) : 0;
+        if constexpr (NDIM == 3) delta = (xim < r.c5) ? -l_nij : delta;
+        if constexpr (multi_d) {
+          delta = (xim < r.c4) ? l_ni : delta;
+          delta = (xim < r.c3) ? -l_ni : delta;
+        }
+        delta = (xim < r.c2) ? 1 : delta;
+        delta = (xim < r.c1) ? -1 : delta;
+        const bool leak = live && ev && !absorbed && xi < a2 && delta != 0;
+        const bool done = !(t_new < t_end);
+        t = live ? t_new : t;
+        rng.s = live ? (leak ? s4 : (ev ? s2 : s1)) : rng.s;
+        pzs = leak ? s2 : pzs;
+        pd = leak ? delta : pd;
+        if constexpr (NDIM == 1) mir = mir && !leak;   // (a new leak: a new direction)
+        if constexpr (NDIM == 3) rec = leak ? rec + (unsigned)delta : rec;
+        else rec = (leak && delta != kPdStay) ? rec + (unsigned)delta : rec;
+        ls = live ? ((ev && absorbed) ? DS_ABS : (done ? (ev ? DS_DONE : DS_CENSUS) : DS_VIRT)) : ls;
+        // the code of the cell the lane is in now, for the next pass (a lane that has left the loop asks for word 0)
+        code = ((gcptr_u)step_base)[ls == DS_VIRT ? rec : 0u];
+        // (keeps the request HERE: left to itself the compiler merges it with the one in front of the loop into
+        // the loop's header, where its result is needed a dozen instructions later)
+        __builtin_amdgcn_sched_barrier(0);
+        nrun = __popcll(__ballot(ls == DS_VIRT));
+        waste += running - nrun;
+        if (waste >= kBudget) thresh = 65;
+        continue;
+      }
       const bool run = ls == DS_VIRT;
       // (every lane takes part in the gather; one without a particle in the loop asks for record 0)
       const unsigned rq = run ? rec : 0u;
@@ -693,14 +777,6 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         nlog = -m_log(u52_to_double(s1 >> 12));
         r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
         r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
-      } else if constexpr (CODES) {
-        nlog = -m_log(u52_to_double(s1 >> 12));   // (the step's first draw, while the code is on its way)
-        // (a ghost cell has no record: any row will do for the arithmetic nobody commits)
-        const v4d *rp = (const v4d *)(lds_rec_tab + 8u * ((int)code < 0 ? 0u : code));
-        const v4d r0 = rp[0];
-        const v4d r1 = rp[1];
-        r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
-        r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
       } else {
         typedef const v4d __attribute__((address_space(1))) *grec;
         const grec rp = (grec)((gcptr)step_base + 8ull * (unsigned long long)rq);
@@ -710,7 +786,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
         r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
       }
-      const int rcp_hi = CODES ? (int)code : __double2hiint(r.rcp);
+      const int rcp_hi = __double2hiint(r.rcp);
       const bool ghost = rcp_hi < 0;
       // transport_utils.hpp:184-191
       const double a2 = r.ffaa + r.leak_tot;
@@ -765,16 +841,12 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         // (selects, not branches with stores to one of two variables: the compiler merges such stores into
         // one store through a selected ADDRESS, which pins both variables in scratch memory)
         const bool gl = run && ghost;
-        const bool tab = gl && (CODES ? (code & kCodeTable) != 0u : (rcp_hi & kStepGhostTable) != 0);
-        rec = tab ? (CODES ? code & kCodeRecMask : (unsigned)__double2loint(r.rcp)) : rec;
+        const bool tab = gl && (rcp_hi & kStepGhostTable) != 0;
+        rec = tab ? (unsigned)__double2loint(r.rcp) : rec;
         if constexpr (multi_d) pd = tab ? kPdZero : pd;
-        if constexpr (NDIM == 1)
-          mir = (tab && (CODES ? (code & kCodeMirror) != 0u : (rcp_hi & kStepGhostMirror) != 0)) ? !mir : mir;
+        if constexpr (NDIM == 1) mir = (tab && (rcp_hi & kStepGhostMirror) != 0) ? !mir : mir;
         ls = (gl && !tab) ? DS_RELOC : ls;
       }
-      // (the code of the cell the lane is in now, for the next pass: on its way through the loop's tail and
-      // the next step's logarithm)
-      if constexpr (CODES) code = ((gcptr_u)step_base)[ls == DS_VIRT ? rec : 0u];
       nrun = __popcll(__ballot(ls == DS_VIRT));
       waste += running - nrun;
       if (waste >= kBudget) thresh = 65;

@@ -374,7 +374,38 @@ def test_quad_cooperative_gather_on_all_ddmc_meshes(gpu_device, deck, overrides,
     assert drv.md.events == O.events
 
 
-@pytest.mark.parametrize("coop", ["0", "1", "2", "lds"])
+@pytest.mark.parametrize("mode", ["forced", "one class allowed", "no class allowed"])
+@pytest.mark.parametrize("deck,overrides,cycles", [c for c in CASES if c[0].endswith("_ddmc")])
+def test_cell_codes_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, mode, monkeypatch):
+    """k_ddmc_all<.., cell codes> (round 6): the event loop gathers a 4-byte code per step -- the number of the
+    cell's step record among the DISTINCT records of the cycle, which k_ddmc_pack counts and the kernel keeps
+    in LDS -- instead of the 64-byte record.  "forced": also on the meshes small enough for the whole record
+    table to sit in LDS (JB_COOP_GATHER=4).  When a mesh has more distinct records than the table holds the
+    library keeps the 64-byte gather: JB_DDMC_MAX_CLASSES = 1 / 0 lower the limit so that the SMR decks (several
+    classes: level x neighbour pattern) and every deck take that way out.  Same bits in all of them."""
+    from oracle import orc
+    if mode == "forced":
+        monkeypatch.setenv("JB_COOP_GATHER", "4")
+    else:
+        monkeypatch.delenv("JB_COOP_GATHER", raising=False)
+        monkeypatch.setenv("JB_DDMC_MAX_CLASSES", "1" if mode == "one class allowed" else "0")
+    pin = load_deck(deck, overrides)
+    drv = _gpu_problem(pin, gpu_device)
+    O, mesh, _ = make_oracle(load_deck(deck, overrides), orc.MATH_PORTABLE)
+    for _ in range(cycles):
+        drv.Step()
+    run_oracle_cycles(O, pin, cycles)
+    variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
+    if mode == "forced":
+        assert "cell codes" in variant
+    elif mode == "no class allowed":
+        assert "k_ddmc_all" in variant and "cell codes" not in variant
+    _compare_swarm(drv.md, O)
+    _compare_fields(drv.md, O)
+    assert drv.md.events == O.events
+
+
+@pytest.mark.parametrize("coop", ["0", "1", "2", "4", "lds"])
 def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel(gpu_device, coop, monkeypatch):
     """k_ddmc_all's event loop starts every step from the cell centre, which is what the albedo
     step leaves behind unless the photon sits within 2.5 eps_imc dx of a face of its cell
