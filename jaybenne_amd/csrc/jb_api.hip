@@ -19,6 +19,7 @@
 #include "../../include/jaybenne_amd.h"
 #include "jb_kernels.hpp"
 #include "jb_kernel_hybrid.hpp"
+#include "jb_kernel_ddmc_q.hpp"
 #include "jb_kernel_imc.hpp"
 
 using namespace jb;
@@ -64,6 +65,7 @@ struct jb_context {
   bool lean_arith = true;
   int blocks_per_cu_env = 0;  // JB_TRANSPORT_BLOCKS_PER_CU at jb_initialize (tuning aid), 0 = occupancy query
   bool no_ddmc_all = false;   // JB_NO_DDMC_ALL=1 at jb_initialize (tests: k_hybrid on all-DDMC meshes)
+  int ddmc_queues = 1;             // JB_DDMC_QUEUES=0: k_ddmc_all instead of k_ddmc_q where both apply (tests, A/B)
   int max_classes = kMaxClasses;   // JB_DDMC_MAX_CLASSES: fewer (tests of the fall-back to the 64-byte gather)
   int coop_gather = -1;       // JB_COOP_GATHER=0 / 1 / 2: k_ddmc_all's quad-cooperative gather off / on / on with 64-bit addresses, whatever the table size
   bool no_imc_cell = false;   // JB_NO_IMC_CELL=1 at jb_initialize (tests, A/B): the lean step in x-space (k_transport<.., LEAN>) instead of k_imc_cell
@@ -237,6 +239,7 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   if (const char *e = getenv("JB_NO_DDMC_ALL")) ctx->no_ddmc_all = e[0] == '1';
   if (const char *e = getenv("JB_NO_IMC_CELL")) ctx->no_imc_cell = e[0] == '1';
   if (const char *e = getenv("JB_COOP_GATHER")) ctx->coop_gather = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : (e[0] == '4' ? 4 : 0));  // (tests, A/B runs)
+  if (const char *e = getenv("JB_DDMC_QUEUES")) ctx->ddmc_queues = e[0] != '0';
   if (const char *e = getenv("JB_DDMC_MAX_CLASSES")) {   // (tests: the fall-back when a mesh has more distinct step records)
     const int v = atoi(e);
     ctx->max_classes = v < 0 ? 0 : (v > kMaxClasses ? kMaxClasses : v);
@@ -914,8 +917,13 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         // ... and everything between with at most kMaxClasses DISTINCT step records (k_ddmc_pack counts them
         // every cycle: the gray decks have a handful) gathers a 4-byte cell code per step, the records in LDS
         // (JB_COOP_GATHER=4 also on the smallest meshes; 0 / 1 / 2 keep the 64-byte forms, for tests and A/B)
-        const bool codes = M.ddmc_code != nullptr && mesh->nclass_host >= 1 && mesh->nclass_host <= ctx->max_classes &&
-                           (ctx->coop_gather == 4 || (ctx->coop_gather < 0 && !in_lds));
+        const bool codes_ok = M.ddmc_code != nullptr && mesh->nclass_host >= 1 && mesh->nclass_host <= ctx->max_classes;
+        // ... and, with the codes, the wave's photons staged through queues in LDS (k_ddmc_q, jb_kernel_ddmc_q.hpp:
+        // the event loop at full width, the service phase in whole batches) -- any mesh size, up to kQBlocks
+        // resident blocks and 2^32 slots; JB_DDMC_QUEUES=0 keeps k_ddmc_all
+        const bool queues = codes_ok && ctx->ddmc_queues && ctx->coop_gather < 0 && M.nblocks <= kQBlocks &&
+                            last <= (1ll << 32);
+        const bool codes = queues || (codes_ok && (ctx->coop_gather == 4 || (ctx->coop_gather < 0 && !in_lds)));
         const int gather = codes ? 4 : (coop ? (wide ? 3 : 1) : (in_lds ? 2 : 0));
         // A particle that sits at a face of its cell when it is loaded or relocated (one in ~1e8) needs
         // the albedo step: k_ddmc_all lists it, and k_hybrid<.., both loops>, launched behind it on
@@ -945,6 +953,14 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
     hipLaunchKernelGGL((k_ddmc_all<NDIM, TL, CO>), dim3(g), dim3(kBlock), lds_tally_bytes, ctx->stream, mesh->dm_dev, ctx->dp, S, \
                        t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc, handed, n_handed); \
   } while (0)
+#define JB_LAUNCH_DDMC_Q(TL)                                                                               \
+  do {                                                                                                      \
+    int oc = 0;                                                                                             \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, k_ddmc_q<NDIM, TL>, kBlock, lds_tally_bytes) != hipSuccess || oc < 1) oc = 3; \
+    const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : oc);                            \
+    hipLaunchKernelGGL((k_ddmc_q<NDIM, TL>), dim3(g), dim3(kBlock), lds_tally_bytes, ctx->stream, mesh->dm_dev, ctx->dp, S, \
+                       t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc, handed, n_handed); \
+  } while (0)
 #define JB_LAUNCH_HANDED(TL, NA)                                                                            \
   do {                                                                                                      \
     (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream); \
@@ -960,9 +976,15 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
              {"k_ddmc_all<2, true>", "k_ddmc_all<2, true, quad gather>", "k_ddmc_all<2, true, records in LDS>", "k_ddmc_all<2, true, cell codes>"}},
             {{"k_ddmc_all<3, false>", "k_ddmc_all<3, false, quad gather>", "k_ddmc_all<3, false, records in LDS>", "k_ddmc_all<3, false, cell codes>"},
              {"k_ddmc_all<3, true>", "k_ddmc_all<3, true, quad gather>", "k_ddmc_all<3, true, records in LDS>", "k_ddmc_all<3, true, cell codes>"}}};
-        mesh->last_variant = names[NDIM - 1][tally ? 1 : 0][gather == 4 ? 3 : (gather == 3 ? 1 : gather)];
+        static const char *const qnames[3][2] = {
+            {"k_ddmc_all<1, false, cell codes, queues>", "k_ddmc_all<1, true, cell codes, queues>"},
+            {"k_ddmc_all<2, false, cell codes, queues>", "k_ddmc_all<2, true, cell codes, queues>"},
+            {"k_ddmc_all<3, false, cell codes, queues>", "k_ddmc_all<3, true, cell codes, queues>"}};
+        mesh->last_variant = queues ? qnames[NDIM - 1][tally ? 1 : 0]
+                                    : names[NDIM - 1][tally ? 1 : 0][gather == 4 ? 3 : (gather == 3 ? 1 : gather)];
         if (tally) {
-          if (gather == 4) JB_LAUNCH_DDMC_ALL(true, 4);
+          if (queues) JB_LAUNCH_DDMC_Q(true);
+          else if (gather == 4) JB_LAUNCH_DDMC_ALL(true, 4);
           else if (gather == 1) JB_LAUNCH_DDMC_ALL(true, 1);
           else if (gather == 2) JB_LAUNCH_DDMC_ALL(true, 2);
           else if (gather == 3) JB_LAUNCH_DDMC_ALL(true, 3);
@@ -970,7 +992,8 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
           if (noabs_h) JB_LAUNCH_HANDED(true, true);
           else JB_LAUNCH_HANDED(true, false);
         } else {
-          if (gather == 4) JB_LAUNCH_DDMC_ALL(false, 4);
+          if (queues) JB_LAUNCH_DDMC_Q(false);
+          else if (gather == 4) JB_LAUNCH_DDMC_ALL(false, 4);
           else if (gather == 1) JB_LAUNCH_DDMC_ALL(false, 1);
           else if (gather == 2) JB_LAUNCH_DDMC_ALL(false, 2);
           else if (gather == 3) JB_LAUNCH_DDMC_ALL(false, 3);
@@ -979,6 +1002,7 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
           else JB_LAUNCH_HANDED(false, false);
         }
 #undef JB_LAUNCH_HANDED
+#undef JB_LAUNCH_DDMC_Q
 #undef JB_LAUNCH_DDMC_ALL
         return JB_COMPLETE;
       }
@@ -1443,7 +1467,22 @@ extern "C" jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_s
   // land in the cycle that first sorts: 400 ms on BASELINE configs[2]) are asked for as soon as the cycles
   // START to slow down (0.5 %: at least one cycle before the 1.5 % a sort needs) -- a run whose swarm keeps
   // its order never allocates them (12.8 GB at 1e8 photons); one that has no room learns so here.
-  if (!ctx->sort_scratch_tried && ctx->rate_ref > 0.0 && rate > 1.005 * ctx->rate_ref) {
+  // Where memory is plentiful (the records would take less than a quarter of what is free: 12.8 GB of an
+  // MI355X's 288) they are taken at the FIRST cycle the policy sees -- a host's warm-up -- so that no later
+  // cycle of the run pays for the allocation at all.  And a cycle that meets the sort's own condition without
+  // them (a slow-down from under 0.5 % to over 1.5 % within one cycle) takes the allocation, not the sort:
+  // the sort follows a cycle later (below).
+  bool scratch_now = !ctx->sort_scratch_tried && ctx->rate_ref > 0.0 && rate > 1.005 * ctx->rate_ref;
+  if (!ctx->sort_scratch_tried && !scratch_now && ctx->rate_ref == 0.0) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+        (double)free_b > 4.0 * 8.0 * (double)kSortRecWords * (double)swarm->n)
+      scratch_now = true;
+    (void)hipGetLastError();
+  }
+  bool allocated_this_cycle = false;
+  if (scratch_now) {
+    allocated_this_cycle = true;
     ctx->sort_scratch_tried = true;
     const DevMesh &M0 = mesh->dm;
     const unsigned long long nbins0 = (unsigned long long)M0.nblocks * (unsigned long long)M0.ntot + 1ull;
@@ -1471,6 +1510,22 @@ extern "C" jb_status jb_defrag_policy(jb_context *ctx, jb_mesh *mesh, const jb_s
   const double excess_next = p > 1 ? excess_now * (double)p / (double)(p - 1) : excess_now;
   if (p >= ctx->min_interval && rate > 1.015 * ctx->rate_ref &&
       excess_next * (double)p >= sort_ms + ctx->excess_ms) {
+    if (!ctx->sort_scratch_tried) {   // (never asked for: this cycle takes the allocation, the next one the sort)
+      ctx->sort_scratch_tried = true;
+      const DevMesh &M1 = mesh->dm;
+      const unsigned long long nbins1 = (unsigned long long)M1.nblocks * (unsigned long long)M1.ntot + 1ull;
+      const unsigned long long ntiles1 = (nbins1 + kScanTile - 1) / kScanTile;
+      if (swarm->n < (1ll << 32) && nbins1 < (1ull << 32)) {
+        const size_t words = (size_t)kSortRecWords * (size_t)swarm->n + (size_t)((nbins1 + ntiles1 + swarm->n) / 2 + 16);
+        if (ensure_scratch(ctx, words, /*slack=*/false) != JB_COMPLETE) {
+          fprintf(stderr, "jaybenne_amd: no room for the scratch records of DefragParticles (%s): the swarm stays unsorted\n", g_err);
+          (void)hipGetLastError();
+          ctx->min_interval = 256;
+        }
+      }
+      return JB_COMPLETE;
+    }
+    if (allocated_this_cycle && mode != JB_DEFRAG_SORT_NOW) return JB_COMPLETE;
     if (mode == JB_DEFRAG_DECIDE) {
       *sorted = 1;  // (this rank would sort: the host asks the others, then calls again with SORT_NOW)
       return JB_COMPLETE;

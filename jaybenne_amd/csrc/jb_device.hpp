@@ -207,19 +207,20 @@ __device__ __forceinline__ void load_block(const DevMesh &M, int b, Blk &B) {
 constexpr int kLdsBlocks = JB_LDS_BLOCKS;
 // (X0: also the coordinate of cell index 0, xmin - first dx, per block and axis -- 3 KB that
 // k_ddmc_all, which needs the room for a fourth workgroup per CU, forms where it reads it)
-template <bool X0>
+template <bool X0, int NB = kLdsBlocks>
 struct LdsBlockTableT {
   static constexpr bool has_x0 = X0;
-  double xmin[kLdsBlocks][3], dx[kLdsBlocks][3], inv_dx[kLdsBlocks][3];
-  double x0[X0 ? kLdsBlocks : 1][3];
-  double *tally[kLdsBlocks];
-  int owned[kLdsBlocks];
-  int nbr_ent[kLdsBlocks][6];
+  static constexpr int capacity = NB;
+  double xmin[NB][3], dx[NB][3], inv_dx[NB][3];
+  double x0[X0 ? NB : 1][3];
+  double *tally[NB];
+  int owned[NB];
+  int nbr_ent[NB][6];
 };
 using LdsBlockTable = LdsBlockTableT<true>;
 template <class Tab>
 __device__ __forceinline__ void fill_block_table(const DevMesh &M, Tab &T) {
-  if (M.nblocks > kLdsBlocks) return;
+  if (M.nblocks > Tab::capacity) return;
   for (int q = threadIdx.x; q < 3 * M.nblocks; q += blockDim.x) {
     (&T.xmin[0][0])[q] = M.blk_xmin[q];
     (&T.dx[0][0])[q] = M.blk_dx[q];

@@ -374,7 +374,7 @@ def test_quad_cooperative_gather_on_all_ddmc_meshes(gpu_device, deck, overrides,
     assert drv.md.events == O.events
 
 
-@pytest.mark.parametrize("mode", ["forced", "one class allowed", "no class allowed"])
+@pytest.mark.parametrize("mode", ["forced", "queues", "one class allowed", "no class allowed"])
 @pytest.mark.parametrize("deck,overrides,cycles", [c for c in CASES if c[0].endswith("_ddmc")])
 def test_cell_codes_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, mode, monkeypatch):
     """k_ddmc_all<.., cell codes> (round 6): the event loop gathers a 4-byte code per step -- the number of the
@@ -382,10 +382,16 @@ def test_cell_codes_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, mode
     in LDS -- instead of the 64-byte record.  "forced": also on the meshes small enough for the whole record
     table to sit in LDS (JB_COOP_GATHER=4).  When a mesh has more distinct records than the table holds the
     library keeps the 64-byte gather: JB_DDMC_MAX_CLASSES = 1 / 0 lower the limit so that the SMR decks (several
-    classes: level x neighbour pattern) and every deck take that way out.  Same bits in all of them."""
+    classes: level x neighbour pattern) and every deck take that way out.  "queues": the library's default where
+    the codes apply and at most 64 blocks are resident -- k_ddmc_q (jb_kernel_ddmc_q.hpp): finished histories
+    and new photons pass through two queues in LDS, the event loop runs at full width; "forced" is k_ddmc_all on
+    the same codes.  Same bits in all of them."""
     from oracle import orc
     if mode == "forced":
         monkeypatch.setenv("JB_COOP_GATHER", "4")
+    elif mode == "queues":
+        monkeypatch.delenv("JB_COOP_GATHER", raising=False)
+        monkeypatch.setenv("JB_DDMC_QUEUES", "1")
     else:
         monkeypatch.delenv("JB_COOP_GATHER", raising=False)
         monkeypatch.setenv("JB_DDMC_MAX_CLASSES", "1" if mode == "one class allowed" else "0")
@@ -397,7 +403,9 @@ def test_cell_codes_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, mode
     run_oracle_cycles(O, pin, cycles)
     variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
     if mode == "forced":
-        assert "cell codes" in variant
+        assert "cell codes" in variant and "queues" not in variant
+    elif mode == "queues":    # (the 3-D SMR deck keeps 72 blocks resident: more than the kernel's LDS table holds)
+        assert "cell codes" in variant and ("queues" in variant) == (drv.md.nblocks <= 64)
     elif mode == "no class allowed":
         assert "k_ddmc_all" in variant and "cell codes" not in variant
     _compare_swarm(drv.md, O)
@@ -405,7 +413,7 @@ def test_cell_codes_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, mode
     assert drv.md.events == O.events
 
 
-@pytest.mark.parametrize("coop", ["0", "1", "2", "4", "lds"])
+@pytest.mark.parametrize("coop", ["0", "1", "2", "4", "lds", "queues", "queues-1d"])
 def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel(gpu_device, coop, monkeypatch):
     """k_ddmc_all's event loop starts every step from the cell centre, which is what the albedo
     step leaves behind unless the photon sits within 2.5 eps_imc dx of a face of its cell
@@ -417,10 +425,15 @@ def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel
     into the neighbouring cell."""
     import torch
     from oracle import orc
-    if coop == "lds":   # the 1-D deck as shipped: 136 cells, step records in LDS
+    if coop in ("lds", "queues-1d"):   # the 1-D deck as shipped: 136 cells (k_ddmc_all: step records in LDS)
         deck, ov = "stepdiff_ddmc", {"jaybenne/num_particles": 20000}
+        monkeypatch.delenv("JB_COOP_GATHER", raising=False)
+        monkeypatch.setenv("JB_DDMC_QUEUES", "0" if coop == "lds" else "1")
     else:
-        monkeypatch.setenv("JB_COOP_GATHER", coop)
+        if coop == "queues":            # the library's default: cell codes + the wave's photons staged through LDS queues
+            monkeypatch.delenv("JB_COOP_GATHER", raising=False)
+        else:
+            monkeypatch.setenv("JB_COOP_GATHER", coop)
         deck, ov, _ = [c for c in CASES if c[0] == "stepdiff_ddmc" and "parthenon/mesh/nx3" in c[1]][0]
     pin = load_deck(deck, ov)
     drv = _gpu_problem(pin, gpu_device)
@@ -450,7 +463,8 @@ def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel
         drv.Step()
     run_oracle_cycles(O, pin, 2)
     variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
-    assert ("k_ddmc_all<1, true, records in LDS>" if coop == "lds" else "k_ddmc_all<3") in variant
+    assert {"lds": "k_ddmc_all<1, true, records in LDS>", "queues-1d": "k_ddmc_all<1, true, cell codes, queues>",
+            "queues": "k_ddmc_all<3, true, cell codes, queues>"}.get(coop, "k_ddmc_all<3") in variant
     _compare_swarm(drv.md, O)
     _compare_fields(drv.md, O)
     assert drv.md.events == O.events
