@@ -445,6 +445,14 @@ def main() -> None:
                          "every rank holds the whole mesh and follows its share of every block's photons, "
                          "one all-reduce of the tally per cycle; 'auto' (default) = replicated only where "
                          "the mesh is tiny and no contiguous split of its blocks balances (configs[4])")
+    ap.add_argument("--handoff", default=os.environ.get("JB_HANDOFF", "c"), choices=("c", "c-torch", "c-rccl", "python"),
+                    help="several GPUs, block partition: how photons are handed to other ranks.  'c' (default) = the "
+                         "library's one C call jb_exchange per transport iteration, over an RCCL communicator of its "
+                         "own (falls back, labelled, to the process group's collectives through callbacks: "
+                         "'c-torch'); 'python' = the same protocol driven step by step from Python (comm.py)")
+    ap.add_argument("--no-blocks-variant", action="store_true",
+                    help="several GPUs, c5: skip the extra run on the block partition when 'auto' chose the "
+                         "replicated mesh (config.blocks_variant)")
     ap.add_argument("--no-other-variant", action="store_true",
                     help="skip the one extra step in the other arithmetic variant (profiling runs)")
     ap.add_argument("--arithmetic", choices=("lean", "exact"), default=None,
@@ -525,6 +533,7 @@ def main() -> None:
         work_by_rank = np.bincount(owner, weights=cost, minlength=world)
     md.force_exchange = bool(args.force_exchange)
     md.defrag_interval = int(args.defrag_interval)
+    md.handoff = args.handoff
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -587,6 +596,44 @@ def main() -> None:
                  "kernel": md.lib.jb_last_transport_variant(md.handle).decode()}
         md.pkg.set_arithmetic(mode)
         md.kernel_events = kept
+
+    handoff_path = md.handoff_path() if (comm is not None and drv.decomposition != "replicated") else "none (nothing is handed over)"
+
+    # BASELINE configs[4] on several GPUs: 'auto' answers with the replicated mesh (no contiguous split of its 32
+    # blocks balances better than 1.23 x the mean) -- SURVEY 8e calls that a cross-check, north_star mandates the
+    # block partition with hand-off: run that too, a few steps, and report it beside
+    blocks_variant = None
+    if (world > 1 and args.workload == "c5" and args.decomposition == "auto" and drv.decomposition == "replicated"
+            and not args.no_blocks_variant):
+        rank_log("the same workload on the block partition (config.blocks_variant)")
+        drv_b = mcblock.McblockDriver(make_deck(args.gpus, args.particles_per_gpu, args.block_nx, args.workload),
+                                      rank=rank, nranks=world, comm=comm, device=device, capacity_factor=3.0,
+                                      decomposition="blocks")
+        mb = drv_b.md
+        mb.defrag_interval = int(args.defrag_interval)
+        mb.handoff = args.handoff
+        drv_b.Step()                       # warm-up
+        sync_all()
+        mb.handoff_records, mb.transport_iterations_total = 0, 0
+        k_b = max(1, min(args.steps, 5))
+        hist_b = 0
+        tb = time.perf_counter()
+        for _ in range(k_b):
+            hist_b += mb.n
+            drv_b.Step()
+        sync_all()
+        wall_b = comm.allreduce_max_float(time.perf_counter() - tb)
+        hist_b, rec_b = (int(v) for v in comm.allreduce_sum_int64(np.array([hist_b, mb.handoff_records])))
+        owner_b = mb.mesh.owner
+        work_b = np.bincount(owner_b, weights=cost, minlength=world)
+        blocks_variant = {"decomposition": "blocks", "value": hist_b / wall_b, "ms_per_step": 1e3 * wall_b / k_b,
+                          "steps": k_b, "warmup": 1,
+                          "estimated_work_per_rank_max_over_mean": float(work_b.max() / work_b.mean()),
+                          "transport_iterations_per_step": mb.transport_iterations_total / k_b,
+                          "handoff_records_per_step": rec_b / k_b, "handoff_path": mb.handoff_path()}
+        mb.close()
+        del drv_b, mb
+        torch.cuda.empty_cache()
 
     # hand-off statistics of the timed steps (all ranks): records are 104 bytes
     if comm is not None:
@@ -746,6 +793,7 @@ def main() -> None:
                        "defrag_sorts_in_run": int(md.defrags),
                        "kernel_ms_by_step": [round(1e3 * t, 2) for t, _ in kt][:64],
                        "decomposition": drv.decomposition if world > 1 else "one rank",
+                       "blocks_variant": blocks_variant,
                        "photons_per_rank_min": int(photons_by_rank.min()),
                        "photons_per_rank_max": int(photons_by_rank.max()),
                        "estimated_work_per_rank_max_over_mean": float(work_by_rank.max() / work_by_rank.mean()),
@@ -758,7 +806,8 @@ def main() -> None:
             "events_per_s": events / wall,
             "events_per_history": ev_per_hist,
             "transport_iterations_per_step": iters / max(args.steps, 1),
-            "handoff": {"records_per_step": handoff_records / max(args.steps, 1),
+            "handoff": {"path": handoff_path,
+                        "records_per_step": handoff_records / max(args.steps, 1),
                         "bytes_per_step": 104.0 * handoff_records / max(args.steps, 1),
                         "exchange_ms_per_step_max_rank": 1e3 * exchange_s / max(args.steps, 1),
                         "transport_wait_ms_per_step_max_rank": 1e3 * wait_s / max(args.steps, 1),

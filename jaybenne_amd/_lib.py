@@ -92,6 +92,16 @@ class DebugStep(C.Structure):
                                           "is_rejected")])
 
 
+# jb_exchange_transport (include/jaybenne_amd.h): the two collectives of the hand-off on device buffers
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+ALL_TO_ALL_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                              C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_void_p)
+
+
+class ExchangeTransport(C.Structure):
+    _fields_ = [("handle", C.c_void_p), ("all_gather_u64", ALL_GATHER_FN), ("all_to_all_v", ALL_TO_ALL_V_FN)]
+
+
 # every entry point include/jaybenne_amd.h declares: name -> (restype, argtypes)
 _vp, _i64, _f64, _int = C.c_void_p, C.c_int64, C.c_double, C.c_int
 PROTOTYPES = {

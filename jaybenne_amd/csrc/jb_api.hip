@@ -54,6 +54,8 @@ struct jb_context {
   int num_cu = 256;
   unsigned long long *counters_d = nullptr;   // CNT_N + 2 cursors + per-rank counters
   unsigned long long *counters_h = nullptr;   // pinned
+  unsigned long long *xch_d = nullptr;        // jb_exchange: the gathered count matrix + pack offsets
+  int xch_ranks = 0;                          // ... sized for this many ranks
   long long *scratch_d = nullptr;             // holes / movers / small tables
   bool scratch_alloc_failed = false;          // set by ensure_scratch when hipMalloc itself said no
   std::vector<unsigned long long> xch_matrix;  // jb_exchange: the rank x rank record counts (host copy)
@@ -314,6 +316,7 @@ extern "C" jb_status jb_finalize(jb_context *ctx) {
   if (ctx->counters_d) (void)hipFree(ctx->counters_d);
   if (ctx->counters_h) (void)hipHostFree(ctx->counters_h);
   if (ctx->scratch_d) (void)hipFree(ctx->scratch_d);
+  if (ctx->xch_d) (void)hipFree(ctx->xch_d);
   for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->sort_ev) if (e) (void)hipEventDestroy(e);
   delete ctx;
@@ -1640,9 +1643,22 @@ extern "C" jb_status jb_exchange(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *
   // 2. ... gathered from every rank straight from that buffer (no read-back in front of the collective):
   // the rank x rank matrix carries this rank's receive sizes AND the answer to "did anything move
   // anywhere" (the completion test of jaybenne.cpp:130-131 needs no collective of its own) ...
-  st = ensure_scratch(ctx, (size_t)nranks * (size_t)row + 4 * (size_t)nranks + 8);
-  if (st != JB_COMPLETE) return st;
-  unsigned long long *matrix_d = (unsigned long long *)ctx->scratch_d;
+  // (the count matrix lives in a buffer of its own, taken on the FIRST call of a context -- before any rank has
+  // entered a collective of the run's hot loop; a rank that cannot get its few KB fails there, and says so
+  // in the gathered row of every later call: a rank-local failure must not leave the others in a collective)
+  if (!ctx->xch_d || ctx->xch_ranks < nranks) {
+    if (ctx->xch_d) (void)hipFree(ctx->xch_d);
+    const size_t R = nranks > 64 ? (size_t)nranks : 64;
+    if (hipMalloc(&ctx->xch_d, R * (R + 8) * sizeof(unsigned long long)) == hipSuccess) {
+      ctx->xch_ranks = (int)R;
+    } else {
+      ctx->xch_d = nullptr;
+      ctx->xch_ranks = 0;
+      (void)hipGetLastError();
+      return fail(JB_ERR_HIP, "jb_exchange: hipMalloc of the count matrix failed");
+    }
+  }
+  unsigned long long *matrix_d = ctx->xch_d;
   if (tr->all_gather_u64(tr->handle, (const uint64_t *)per_rank, (uint64_t *)matrix_d, row, (void *)ctx->stream) != 0)
     return fail(JB_ERR_HIP, "jb_exchange: the transport's all-gather of the record counts failed");
   // 3. ... and read back ONCE per call: nranks (nranks + 3) words
@@ -1664,7 +1680,9 @@ extern "C" jb_status jb_exchange(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *
   }
   *moved_anywhere = total;
   *nsent = mine_out; *nreceived = mine_in;
-  if (sc[rank] != 0) return fail(JB_ERR_INVALID, "jb_exchange: a rank does not hand particles to itself");
+  // (every rank looks at every rank's diagonal: the same verdict everywhere)
+  for (int q = 0; q < nranks; ++q)
+    if (cnt(q, q) != 0) return fail(JB_ERR_INVALID, "jb_exchange: rank %d hands particles to itself", q);
   if (total == 0) return JB_COMPLETE;
   // the same verdict on every rank: does EVERY rank have room for what it sends and takes in?
   for (int q = 0; q < nranks; ++q) {

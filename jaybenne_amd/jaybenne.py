@@ -9,6 +9,7 @@ stream and ``torch.distributed``; every field / particle update runs in the HIP 
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 import enum
 import sys
@@ -230,6 +231,14 @@ class MeshData:
         # measurement aid (bench.py --force-exchange): run the hand-off phase of the iterate-sublist
         # also when this rank holds the whole mesh (nothing moves; its fixed cost becomes visible)
         self.force_exchange = False
+        # How particles are handed to other ranks: "c" (default) = the library's jb_exchange in one call, over a
+        # communicator of its own on an RCCL process group and over torch.distributed callbacks otherwise
+        # ("c-rccl" / "c-torch" force one); "python" = the same protocol driven from here (comm.py: count
+        # kernel, read-back, all-gather, all-to-all-v from Python), kept for A/B.  JB_HANDOFF overrides.
+        self.handoff = os.environ.get("JB_HANDOFF", "c")
+        if self.handoff not in ("c", "c-torch", "c-rccl", "python"):
+            raise ValueError(f"JB_HANDOFF = {self.handoff!r}: one of c, c-torch, c-rccl, python")
+        self._chandoff = None
         # DefragParticles after every k-th RadiationStep (0: never; the reference schedules none)
         # DefragParticles: -1 (default) on the library's schedule (jb_defrag_policy: when a cycle costs
         # 10 % more per event than the best one since the last sort), k > 0 after every k-th cycle,
@@ -309,7 +318,16 @@ class MeshData:
     def n(self) -> int:
         return int(self.sv.n)
 
+    def handoff_path(self) -> str:
+        """What the hand-off of this MeshData runs through (bench.py: ``handoff.path``)."""
+        if self.handoff == "python":
+            return "python: comm.py (count kernel, read-back, all-gather and all-to-all-v driven from Python)"
+        return self._chandoff.path if self._chandoff is not None else "c: jb_exchange (no exchange has run yet)"
+
     def close(self) -> None:
+        if getattr(self, "_chandoff", None) is not None:
+            self._chandoff.close()
+            self._chandoff = None
         if getattr(self, "handle", None) is not None:
             self.lib.jb_mesh_destroy(self.handle)
             self.handle = None
@@ -539,6 +557,15 @@ def _exchange(md: MeshData, first: int, last: int):
     all-to-all-v of 104-byte records and one unpack kernel.  Departed particles stay behind as
     holes until the swarm is compacted."""
     lib, ctx = md.lib, md.pkg.ctx
+    if md.handoff != "python":
+        # the library's one C call (jb_exchange; jaybenne_amd/handoff.py): the default
+        if md._chandoff is None:
+            from .handoff import CHandoff
+            md._chandoff = CHandoff.make(md, {"c": "auto", "c-torch": "torch", "c-rccl": "rccl"}[md.handoff])
+        t_c = time.perf_counter()
+        out = md._chandoff.exchange(first, last)
+        md.collective_seconds += time.perf_counter() - t_c   # (the whole call: the collectives are inside it)
+        return out
     md._sync_stream()
     counts = np.zeros(md.nranks, dtype=np.int64)
     if md.records is None:

@@ -221,6 +221,10 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         "all-DDMC, 3-D, quad-cooperative gather (configs[2] in 3-D)": "k_ddmc_allILi3ELb1ELi1E",
         "all-DDMC, 3-D, small mesh": "k_ddmc_allILi3ELb1ELi0E",
         "all-DDMC, 1-D, records in LDS (configs[2] as shipped)": "k_ddmc_allILi1ELb1ELi2E",
+        "all-DDMC, 3-D, cell codes": "k_ddmc_allILi3ELb1ELi4E",
+        "all-DDMC, 3-D, cell codes + LDS queues (configs[2] in 3-D: the default)": "k_ddmc_qILi3ELb1E",
+        "all-DDMC, 2-D, cell codes + LDS queues": "k_ddmc_qILi2ELb1E",
+        "all-DDMC, 1-D, cell codes + LDS queues (configs[2] as shipped: the default)": "k_ddmc_qILi1ELb1E",
         "hybrid, 2-D, IMC phase in cell-local coordinates (configs[4])": "k_hybridILi2ELb1ELb1ELi3ELi1E",
         "hybrid, 1-D, IMC phase in cell-local coordinates": "k_hybridILi1ELb1ELb1ELi3ELi1E",
         "hybrid, 3-D, IMC phase in cell-local coordinates": "k_hybridILi3ELb1ELb1ELi3ELi1E",
@@ -270,6 +274,13 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
             if "remainder" not in what:
                 assert vgpr <= 128, f"{what}: {vgpr} vector registers (> 128: three waves per SIMD)"
             assert not scratch_in_inner_loops(names[0]), f"{what}: register spills inside an event loop"
+        elif "k_ddmc_q" in key:
+            # four waves per SIMD AND four workgroups per CU: 128 registers without a spill, static LDS (block
+            # table, math tables, the waves' READY / DONE queues) + the dynamic part of a typical launch (a
+            # handful of 64-byte class records, the 1-D decks' 1 KB tally) within 40 KB
+            assert vgpr <= 128 and scratch == 0, f"{what}: {vgpr} registers, {scratch} bytes of scratch"
+            lds = int(re.search(r"\.amdhsa_kernel %s.*?\.amdhsa_group_segment_fixed_size (\d+)" % re.escape(names[0]), text, re.S).group(1))
+            assert lds + 2048 <= 40 * 1024, f"{what}: {lds} bytes of static LDS"
         elif "k_ddmc_all" in key:
             # four waves per SIMD (128 registers): the event loop -- one record number, time, stream state and
             # the pending leak per lane -- is free of scratch; the service phase of the 3-D forms parks up to

@@ -84,10 +84,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, outdir, decomposition="blocks"):
+def _worker(rank, world, port, case, outdir, decomposition="blocks", handoff="c"):
     import torch
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), JB_HANDOFF=handoff)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from jaybenne_amd import mcblock
@@ -100,6 +100,8 @@ def _worker(rank, world, port, case, outdir, decomposition="blocks"):
         n0 = drv.md.n
         for _ in range(cycles):
             drv.Step()
+        if decomposition == "blocks":   # the hand-off ran through the path asked for
+            assert drv.md.handoff_path().startswith("python" if handoff == "python" else "c: jb_exchange, its two collectives as torch"), drv.md.handoff_path()
         g = drv.md.get_swarm()
         g["gblk"] = drv.md.gids[g["blk"]]
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), tally=drv.md.get_field("tally"),
@@ -112,7 +114,16 @@ def _worker(rank, world, port, case, outdir, decomposition="blocks"):
 
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_two_ranks_equal_the_oracle(gpu_device, case, tmp_path):
+    """(the hand-off through the library's one C call, jb_exchange -- the default; its two collectives are
+    torch.distributed calls over gloo here: jaybenne_amd/handoff.py)"""
     _ranks_equal_the_oracle(case, 2, tmp_path)
+
+
+@pytest.mark.parametrize("case,world", [(0, 2), (3, 2), (7, 2), (6, 4)])
+def test_ranks_equal_the_oracle_with_the_hand_off_driven_from_python(gpu_device, case, world, tmp_path):
+    """The same protocol driven from Python (comm.py: count kernel, read-back, all-gather, all-to-all-v as
+    separate steps; JB_HANDOFF=python), kept for A/B against the C call: same particles."""
+    _ranks_equal_the_oracle(case, world, tmp_path, handoff="python")
 
 
 # 2-D hybrid SMR deck (20 blocks), 3-D SMR DDMC (72 blocks), pure-IMC SMR (configs[3]: the deck
@@ -153,12 +164,12 @@ def test_replicated_mesh_split_particles_equals_the_oracle(gpu_device, case, wor
     _ranks_equal_the_oracle(case, world, tmp_path, decomposition="replicated")
 
 
-def _ranks_equal_the_oracle(case, world, tmp_path, decomposition="blocks"):
+def _ranks_equal_the_oracle(case, world, tmp_path, decomposition="blocks", handoff="c"):
     from oracle import orc
     sys.path.insert(0, os.path.dirname(__file__))
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, str(tmp_path), decomposition))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, str(tmp_path), decomposition, handoff))
              for r in range(world)]
     _run_workers(procs)
     pin, cycles = _deck(case)
