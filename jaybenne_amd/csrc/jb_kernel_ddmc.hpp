@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
       // at the loop's top otherwise -- for registers the service phase's loads were headed for -- and that wait
       // would then be taken in every pass, in front of the code's first use)
       __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-      code = ((gcptr_u)step_base)[ls == DS_VIRT ? rec : 0u];
+      code = *(gcptr_u)((const char *)step_base + ((ls == DS_VIRT ? rec : 0u) << 2));
     }
     while (nrun >= thresh) {
       ++c_pass;
@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD) JB_DDMC_AL
         else rec = (leak && delta != kPdStay) ? rec + (unsigned)delta : rec;
         ls = live ? ((ev && absorbed) ? DS_ABS : (done ? (ev ? DS_DONE : DS_CENSUS) : DS_VIRT)) : ls;
         // the code of the cell the lane is in now, for the next pass (a lane that has left the loop asks for word 0)
-        code = ((gcptr_u)step_base)[ls == DS_VIRT ? rec : 0u];
+        code = *(gcptr_u)((const char *)step_base + ((ls == DS_VIRT ? rec : 0u) << 2));   // (32-bit byte offset: < 2 GiB of codes)
         // (keeps the request HERE: left to itself the compiler merges it with the one in front of the loop into
         // the loop's header, where its result is needed a dozen instructions later)
         __builtin_amdgcn_sched_barrier(0);

@@ -138,6 +138,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     if constexpr (NDIM == 3) on = on && k >= l_ks && k <= l_ke;
     return on;
   };
+  auto load_code = [&](unsigned recno) {
+    return *(gcptr_u)((const char *)code_base + (recno << 2));
+  };
   auto below = [&](unsigned long long m) {   // set bits of m below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
   };
@@ -482,8 +485,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
 
     // ================================ EVENTS =================================
     retire_refill();
-    int nrun = __popcll(__ballot(r_ls == DS_VIRT));
-    if (nrun == 0) {
+    if (__ballot(r_ls == DS_VIRT) == 0ull) {
       // (nothing to follow: finished histories that found no room, photons still to be loaded, or the end)
       if (__ballot(r_ls >= DS_DONE) != 0ull || done_cnt > 0 || ready_cnt > 0 || more) continue;
       break;
@@ -491,7 +493,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     int waste = 0;
     // (nothing of the service phase is left in flight when the loop starts: see k_ddmc_all)
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-    code = ((gcptr_u)code_base)[r_ls == DS_VIRT ? r_rec : 0u];
+    code = load_code(r_ls == DS_VIRT ? r_rec : 0u);
     for (;;) {
       ++c_pass;
       // One DDMC step per running lane (transport_utils.hpp:184-263 on the virtual state): k_ddmc_all's pass for
@@ -555,17 +557,20 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       r_ls = live ? ((ev && absorbed) ? DS_ABS : (done ? (ev ? DS_DONE : DS_CENSUS) : DS_VIRT)) : r_ls;
       // ---- histories that ended in this pass leave for the DONE queue, their lanes take the next photons
       if (__ballot(r_ls != DS_VIRT) != 0ull) retire_refill();
-      // the code of the cell every lane is in now, for the next pass
-      code = ((gcptr_u)code_base)[r_ls == DS_VIRT ? r_rec : 0u];
+      // the code of the cell every lane is in now, for the next pass (32-bit byte offset from a scalar base: the
+      // codes of < 2^29 cells span < 2 GiB)
+      code = load_code(r_ls == DS_VIRT ? r_rec : 0u);
       __builtin_amdgcn_sched_barrier(0);
-      nrun = __popcll(__ballot(r_ls == DS_VIRT));
       // leave the loop: a finished history found no room (the DONE queue is full: a whole batch for the service
       // phase), nothing runs, or lanes stand idle and there are photons to be loaded (at the tail of the launch:
-      // once they have idled long enough)
-      if (done_cnt == kQDone || nrun == 0) break;
-      if (nrun < 64 && ready_cnt == 0) {
+      // once they have idled long enough).  The common case -- room, and all 64 lanes running -- first.
+      const unsigned long long vm = __ballot(r_ls == DS_VIRT);
+      if (done_cnt == kQDone) break;
+      if (vm == ~0ull) continue;
+      if (vm == 0ull) break;
+      if (ready_cnt == 0) {
         if (more) break;
-        waste += 64 - nrun;
+        waste += 64 - __popcll(vm);
         if (waste >= JB_DDMC_Q_BUDGET && done_cnt > 0) break;
       }
     }

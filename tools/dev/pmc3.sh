@@ -24,7 +24,7 @@ for p in "123456":
     names = collections.Counter()
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_transport" in r["Kernel_Name"] or "k_ddmc_all" in r["Kernel_Name"]:
+            if "k_transport" in r["Kernel_Name"] or "k_ddmc_all" in r["Kernel_Name"] or "k_ddmc_q" in r["Kernel_Name"]:
                 names[r["Kernel_Name"]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     if not names: continue
     main = names.most_common(1)[0][0]; dur[p] = names[main] * 1e-6

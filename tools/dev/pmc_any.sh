@@ -16,7 +16,7 @@ import csv, glob, os, sys, collections
 tot = collections.Counter()
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if any(k in r["Kernel_Name"] for k in ("k_transport", "k_ddmc_all", "k_imc_cell", "k_hybrid")):
+        if any(k in r["Kernel_Name"] for k in ("k_transport", "k_ddmc_all", "k_ddmc_q", "k_imc_cell", "k_hybrid")):
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
 for k in sorted(tot): print(f"  {k:32s} {tot[k]:.5g}")
 P

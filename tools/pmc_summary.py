@@ -8,7 +8,7 @@ for p in "ABC":
     d = f"gpurun_out/pmc2_{w}_{name}_{p}"
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if not any(k_ in r["Kernel_Name"] for k_ in ("k_transport", "k_ddmc_all", "k_imc_cell", "k_hybrid")):
+            if not any(k_ in r["Kernel_Name"] for k_ in ("k_transport", "k_ddmc_all", "k_ddmc_q", "k_imc_cell", "k_hybrid")):
                 continue
             per_pass.setdefault(r["Counter_Name"], {}).setdefault(p, 0.0)
             per_pass[r["Counter_Name"]][p] += float(r["Counter_Value"])
@@ -16,7 +16,7 @@ for p in "ABC":
             tot["_kernel"] = r["Kernel_Name"][:60]
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if any(k_ in r["Kernel_Name"] for k_ in ("k_transport", "k_ddmc_all", "k_imc_cell", "k_hybrid")):
+            if any(k_ in r["Kernel_Name"] for k_ in ("k_transport", "k_ddmc_all", "k_ddmc_q", "k_imc_cell", "k_hybrid")):
                 dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 # a counter collected in several passes (SQ_INSTS_VALU): the mean over those passes
 for c, by_pass in per_pass.items():
