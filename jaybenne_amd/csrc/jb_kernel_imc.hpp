@@ -57,11 +57,16 @@ namespace jb {
 #ifndef JB_IMC_WAVES_PER_SIMD
 #define JB_IMC_WAVES_PER_SIMD 4
 #endif
-// 1-D / 2-D: five waves per SIMD (96 registers); what does not fit is stored and reloaded around the
-// event loop, never inside it (tests/test_cabi.py) -- BASELINE configs[3] 43.6 -> 43.0 ms; six: 43.3.
-// (The 3-D kernel at five waves loses: 57.3 -> 59.9 ms on configs[1].)
+// 1-D / 2-D: four waves as well (122 / 108 registers: no scratch).  Rounds 4 and 5 ran five (96 registers, the
+// rest stored and reloaded around the event loop) for 43.6 -> 43.0 ms on BASELINE configs[3]; measured again in
+// round 6 on one box (tools/dev/c4_waves.sh): 43.10 (five) against 43.02 ms (four) -- and the five-wave form's
+// scratch traffic is 2.9 GB read + 12.9 GB written per 1e7 histories against 0.44 + 1.96 GB: not worth a
+// memory system that eight ranks and RCCL share.  (The 3-D kernel at five waves loses: 57.3 -> 59.9 ms.)
 #ifndef JB_IMC_WAVES_PER_SIMD_LOWD
-#define JB_IMC_WAVES_PER_SIMD_LOWD 5
+#define JB_IMC_WAVES_PER_SIMD_LOWD 4
+#endif
+#ifndef JB_IMC_NT_STORES
+#define JB_IMC_NT_STORES 1
 #endif
 #ifndef JB_IMC_SERVICE_BUDGET
 #define JB_IMC_SERVICE_BUDGET 96
@@ -261,13 +266,24 @@ __global__ void __launch_bounds__(kBlock, NDIM < 3 ? JB_IMC_WAVES_PER_SIMD_LOWD
         if (status == ST_ACTIVE) status = ST_OUTGOING;
         bw = M.gid[b];
       }
-      g1(S.blk)[n] = bw;
-      g1(S.t)[n] = t;
-      g1(S.x)[n] = x; g1(S.y)[n] = y; g1(S.z)[n] = z;
-      g1(S.vx)[n] = vx; g1(S.vy)[n] = vy; g1(S.vz)[n] = vz;
-      g1(S.ip)[n] = ip; g1(S.jp)[n] = jp; g1(S.kp)[n] = kp;
-      g1(S.status)[n] = status;
-      g1(S.rng)[n] = rng.s;
+      // (the write-back with the non-temporal hint -- the swarm is a stream, written once per launch: BASELINE
+      // configs[1], counters of one launch: 1.91 + 5.03 GB read + written without it, 1.35 + 4.61 GB with it,
+      // the time unchanged, tools/dev/c2_stores.sh.  What is left of the write side is 13 scattered 4- and 8-byte
+      // stores per finished history at 32 bytes of memory traffic each: the price of a structure-of-arrays swarm
+      // whose photons finish one by one.  -DJB_IMC_NT_STORES=0 switches the hint off.)
+#if JB_IMC_NT_STORES
+#define JB_WST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define JB_WST(p, v) (*(p) = (v))
+#endif
+      JB_WST(&g1(S.blk)[n], bw);
+      JB_WST(&g1(S.t)[n], t);
+      JB_WST(&g1(S.x)[n], x); JB_WST(&g1(S.y)[n], y); JB_WST(&g1(S.z)[n], z);
+      JB_WST(&g1(S.vx)[n], vx); JB_WST(&g1(S.vy)[n], vy); JB_WST(&g1(S.vz)[n], vz);
+      JB_WST(&g1(S.ip)[n], ip); JB_WST(&g1(S.jp)[n], jp); JB_WST(&g1(S.kp)[n], kp);
+      JB_WST(&g1(S.status)[n], status);
+      JB_WST(&g1(S.rng)[n], (uint64_t)rng.s);
+#undef JB_WST
       if (status == ST_ACTIVE) {
         ++c_census;
         if constexpr (TALLY) {  // jaybenne.cpp:547-561

@@ -254,10 +254,9 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         vgpr, scratch = found[names[0]]
         assert vgpr <= 168, f"{what}: {vgpr} vector registers (> 168: two waves per SIMD)"
         if "k_imc_cell" in key and "3-D" not in what:
-            # 1-D / 2-D: five waves per SIMD (96 registers); registers that do not fit are stored and
-            # reloaded around the event loop (BASELINE configs[3]: 43.6 -> 43.0 ms), never inside it
-            assert vgpr <= 96, f"{what}: {vgpr} vector registers (> 96: four waves per SIMD)"
-            assert not scratch_in_inner_loops(names[0]), f"{what}: register spills inside the event loop"
+            # 1-D / 2-D: four waves per SIMD (128 registers) without any scratch (round 6: the five-wave form of
+            # rounds 4 - 5 moved 16 GB of scratch per 1e7 histories for no measurable time, tools/dev/c4_waves.sh)
+            assert vgpr <= 128 and scratch == 0, f"{what}: {vgpr} vector registers, {scratch} bytes of scratch"
             continue
         if "k_imc_cell" in key:
             # four waves per SIMD (128 registers): without a spill on wave-uniform geometry, with

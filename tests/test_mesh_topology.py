@@ -125,3 +125,45 @@ def test_uniform_3d_periodic_mesh_matches_the_listed_neighbour_table():
     # table's faces plus edges and corners: 26 distinct blocks around an interior block
     assert set(int(g) for g in mesh.neighbours([21])) >= {g for g in tab["blocks"][21]["faces"] if g >= 0}
     assert len(mesh.neighbours([21])) == 26
+
+
+@pytest.mark.parametrize("deck,overrides,ndim,mesh_nx,block_nx,gmin,gmax,box,periodic", [
+    # the 3-D SMR deck of the parity tests (tests/test_gpu_parity.py: SMR3D): 4 x 2 x 2 root blocks of 8^3, the
+    # middle of the domain at level 1 -> 72 blocks
+    ("stepdiff_smr_ddmc", {"parthenon/mesh/nx1": 32, "parthenon/mesh/nx2": 16, "parthenon/mesh/nx3": 16,
+                           "parthenon/meshblock/nx1": 8, "parthenon/meshblock/nx2": 8, "parthenon/meshblock/nx3": 8},
+     3, (32, 16, 16), (8, 8, 8), (-0.5, -0.25, -0.25), (0.5, 0.25, 0.25),
+     ((-0.25, 0.25), (-0.25, 0.25), (-0.25, 0.25)), (False, True, True)),
+    # the 2-D SMR deck at the parity tests' size
+    ("stepdiff_smr_ddmc", {"parthenon/mesh/nx1": 64, "parthenon/mesh/nx2": 32,
+                           "parthenon/meshblock/nx1": 16, "parthenon/meshblock/nx2": 16},
+     2, (64, 32, 1), (16, 16, 1), (-0.5, -0.25, -0.25), (0.5, 0.25, 0.25),
+     ((-0.25, 0.25), (-0.25, 0.25), (-0.25, 0.25)), (False, True, True)),
+    # 1-D in 32 blocks of 4 cells (tests/test_gpu_multirank.py)
+    ("stepdiff_ddmc", {"parthenon/mesh/nx1": 128, "parthenon/meshblock/nx1": 4},
+     1, (128, 1, 1), (4, 1, 1), (-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), None, (False, True, True)),
+])
+def test_mesh_against_the_independent_builder_of_the_oracle(deck, overrides, ndim, mesh_nx, block_nx, gmin, gmax,
+                                                            box, periodic):
+    """oracle/meshcheck.py (no code of jaybenne_amd; geometry typed in here from the decks) against
+    Mesh.from_deck on the decks the hand-written fixtures above do not cover: the same set of leaf blocks
+    (level, logical location), the same bounds, the same neighbour level behind every face -- the tables both
+    the oracle and the product are handed."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import meshcheck
+    mesh = Mesh.from_deck(load_deck(deck, overrides))
+    assert mesh.ndim == ndim
+    blocks = meshcheck.leaf_blocks(ndim, mesh_nx, block_nx, gmin, gmax, box)
+    nbr = meshcheck.neighbour_levels(ndim, blocks, gmin, gmax, periodic)
+    assert mesh.nblocks == len(blocks)
+    mine = {(int(mesh.blk_level[b]), tuple(int(v) for v in mesh.blk_lloc[b])): b for b in range(mesh.nblocks)}
+    assert len(mine) == mesh.nblocks
+    for lev, loc, lo, hi in blocks:
+        assert (lev, loc) in mine, (lev, loc)
+        b = mine[(lev, loc)]
+        assert np.array_equal(mesh.blk_xmin[b, :ndim], np.array(lo[:ndim])), (lev, loc)
+        assert np.array_equal(mesh.blk_xmax[b, :ndim], np.array(hi[:ndim])), (lev, loc)
+        assert [int(v) for v in mesh.blk_nbr_lev[b]] == nbr[(lev, loc)], (lev, loc)
+    if box is not None:
+        assert len(set(b[0] for b in blocks)) == 2

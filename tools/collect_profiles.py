@@ -14,7 +14,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/{tag}prof"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
-KERNELS = ("k_transport", "k_imc_cell", "k_ddmc_all", "k_hybrid")
+KERNELS = ("k_transport", "k_imc_cell", "k_ddmc_all", "k_ddmc_q", "k_hybrid")
 HYBRID_MS = {}
 
 
@@ -54,7 +54,8 @@ def pmc_pass(d):
     return tot, ms, name
 
 
-for wl, particles in (("c2", 10_000_000), ("c2x", 10_000_000), ("c3", 100_000_000), ("c4", 10_000_000), ("c5", 10_000_000)):
+for wl, particles in (("c2", 10_000_000), ("c2x", 10_000_000), ("c3", 100_000_000), ("c3-1d", 100_000_000),
+                      ("c4", 10_000_000), ("c5", 10_000_000)):
     counters, ms_by_pass, kernel = {}, {}, None
     for p in "ABCDEFGHI":
         d = os.path.join(src, f"pmc_{wl}_{p}")
@@ -74,11 +75,18 @@ for wl, particles in (("c2", 10_000_000), ("c2x", 10_000_000), ("c3", 100_000_00
     g = lambda c: counters.get(c, float("nan"))
     clk = g("GRBM_GUI_ACTIVE") / 8 / (ms_by_pass.get("B", ms) * 1e-3)
     hbm = (g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024
+    # Share of the SIMDs' cycles in which a VALU instruction was being issued: SQ_ACTIVE_INST_VALU counts
+    # quad-cycles summed over the waves, the chip has 1024 SIMDs, the launch lasted GRBM_GUI_ACTIVE / 8 cycles
+    # (pass B; scaled to pass A's duration).  (Rounds 2 - 5 took (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES) x
+    # SQ_WAVES / 1024, which assumes every wave resident for the whole launch and read 1.02 on configs[3].)
+    simd_cycles_a = 1024.0 * (g("GRBM_GUI_ACTIVE") / 8.0) * (ms / ms_by_pass.get("B", ms)) if ms else float("nan")
+    valu_busy = min(1.0, 4.0 * g("SQ_ACTIVE_INST_VALU") / simd_cycles_a) if simd_cycles_a == simd_cycles_a else float("nan")
+    alg_hbm = (b.get("roofline") or {}).get("algorithmic_hbm_bytes_per_launch")
     summary = {
         "workload": "c2" if wl == "c2x" else wl, "particles_per_gpu": particles, "kernel": kernel,
         "command": "rocprofv3 --kernel-trace --pmc <one group per pass> --output-format csv -- python3 bench.py "
                    + ("" if wl == "c2" else ("--arithmetic exact " if wl == "c2x" else f"--workload {wl} --particles-per-gpu {particles} "))
-                   + "--steps 1 --warmup 0 --no-cpu-baseline" + ("" if wl in ("c3", "c5") else " --no-other-variant"),
+                   + "--steps 1 --warmup 0 --no-cpu-baseline" + ("" if wl in ("c3", "c3-1d", "c5") else " --no-other-variant"),
         "launch_ms_by_pass": ms_by_pass, "events_per_launch": ev, "wave_passes": passes,
         "service_phases": services,
         "hbm_bytes_per_launch": hbm,
@@ -92,7 +100,7 @@ for wl, particles in (("c2", 10_000_000), ("c2x", 10_000_000), ("c3", 100_000_00
         "wave_time_fraction_waiting_to_issue": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
         "wave_time_fraction_waiting_on_memory": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"),
         "waves_per_simd": g("SQ_WAVES") / 1024.0,
-        "simd_valu_busy_fraction": (g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")) * g("SQ_WAVES") / 1024.0,
+        "simd_valu_busy_fraction": valu_busy,
         "cycles_per_valu_instruction_per_wave": 4 * g("SQ_ACTIVE_INST_VALU") / g("SQ_INSTS_VALU"),
         "effective_clock_GHz": clk / 1e9,
         "l2_hit_rate": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")),
@@ -106,7 +114,10 @@ for wl, particles in (("c2", 10_000_000), ("c2x", 10_000_000), ("c3", 100_000_00
         #    issue limit FOR THE INSTRUCTION STREAM IT EXECUTES;
         #  * FP64 flop actually executed (fma = 2, add / mul = 1, x 64 lanes x lane utilisation) over
         #    the vector FP64 peak, 78.6 TF/s
-        "valu_issue_frac": (g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")) * g("SQ_WAVES") / 1024.0,
+        "valu_issue_frac": valu_busy,
+        "valu_issue_frac_note": "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), clamped to 1",
+        "algorithmic_hbm_bytes_per_launch": alg_hbm,
+        "wasted_traffic_ratio": (hbm / alg_hbm) if alg_hbm else None,
         "fp64_counter_frac": ((2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64"))
                               * 64.0 * g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_ACTIVE_INST_VALU"))
                               / (ms_by_pass.get("C", ms) * 1e-3) / 78.6e12) if ms else None,

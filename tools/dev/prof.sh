@@ -4,11 +4,12 @@
 # and the bench lines of every workload.  `python tools/collect_profiles.py <tag>` turns
 # gpurun_out/<tag>prof/ into profiles/<tag>_*.
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=gpurun_out/${TAG}prof
 mkdir -p $O && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 C2="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
 C3="python3 bench.py --workload c3 --particles-per-gpu 100000000 --steps 1 --warmup 0 --no-cpu-baseline"
+C31="python3 bench.py --workload c3-1d --particles-per-gpu 100000000 --steps 1 --warmup 0 --no-cpu-baseline"
 C4="python3 bench.py --workload c4 --particles-per-gpu 10000000 --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
 C5="python3 bench.py --workload c5 --particles-per-gpu 10000000 --steps 1 --warmup 0 --no-cpu-baseline"
 C2X="python3 bench.py --arithmetic exact --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
@@ -27,14 +28,18 @@ PF="TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum"
 PG="TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum"
 PH="TCC_BUSY_sum TCC_CYCLE_sum TCC_TAG_STALL_sum"
 PI="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"
-for wl in c2 c3 c5 c4 c2x; do
-  case $wl in c2) CMD=$C2;; c3) CMD=$C3;; c4) CMD=$C4;; c5) CMD=$C5;; c2x) CMD=$C2X;; esac
+for wl in c2 c3 c3-1d c5 c4 c2x; do
+  case $wl in c2) CMD=$C2;; c3) CMD=$C3;; c3-1d) CMD=$C31;; c4) CMD=$C4;; c5) CMD=$C5;; c2x) CMD=$C2X;; esac
   for p in A B C D E F G H I; do
     eval "CN=\$P$p"
     timeout -k 5 100 rocprofv3 --kernel-trace --pmc $CN --output-format csv -d $O/pmc_${wl}_$p -o runc -- $CMD > $O/pmc_${wl}_$p.json 2> $O/pmc_${wl}_$p.err || echo "pass $wl $p FAILED"
     echo "pmc $wl $p done"
   done
 done
+# the reference's trace ranges (Jaybenne::Timestep, Jaybenne::TransportLoop, one per task) beside the kernels of a
+# configs[4] cycle
+timeout -k 10 300 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $O/markers_c5 -o runc -- python3 bench.py --workload c5 --particles-per-gpu 10000000 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c5_markers.json 2> $O/markers_c5.err || echo "marker trace FAILED"
+echo "marker trace done"
 timeout -k 10 400 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 for w in "c1 100000" "c3 100000000" "c3-1d 100000000" "c4 10000000" "c5 10000000"; do
   set -- $w
