@@ -189,10 +189,18 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
   constexpr unsigned long long kMul2 = kLcgMul * kLcgMul, kInc2 = (kLcgMul + 1ull) * kLcgInc;
   constexpr unsigned long long kMul4 = kMul2 * kMul2, kInc4 = (kMul2 + 1ull) * kInc2;
 
+#ifdef JB_TIMING   // (diagnostic build, tools/dev/timing.sh: wave-cycles in the DONE batches / the fills / the event loop)
+  unsigned long long cyc_ph[4] = {0, 0, 0, 0}, cyc_mark = __builtin_readcyclecounter();
+  unsigned c_epi = 0;
+#define JB_QT(k) { const unsigned long long now_ = __builtin_readcyclecounter(); cyc_ph[k] += now_ - cyc_mark; cyc_mark = now_; }
+#else
+#define JB_QT(k)
+#endif
   for (;;) {
     // ================================ SERVICE ================================
     // two batches, each at full width: the DONE queue (phase 0), then new photons for the READY queue (phase 1)
     for (int phase = 0; phase < 2; ++phase) {
+      JB_QT(phase == 0 ? 2 : 0)
       if (phase == 0 ? done_cnt == 0 : !(ready_cnt < 64 && more)) continue;
       ++c_service;
       // ---- one item per lane: what k_ddmc_all's service phase calls the lane's own state
@@ -483,6 +491,10 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       }
     }
 
+    JB_QT(1)
+#ifdef JB_TIMING
+    ++c_epi;
+#endif
     // ================================ EVENTS =================================
     retire_refill();
     if (__ballot(r_ls == DS_VIRT) == 0ull) {
@@ -594,7 +606,17 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     if (r_ev) atomicAdd(&counters[CNT_EVENTS], r_ev);
     atomicAdd(&counters[CNT_PASSES], (unsigned long long)c_pass);
     atomicAdd(&counters[CNT_SERVICE], (unsigned long long)c_service);
+#ifdef JB_TIMING   // (the words jb_api.hip prints as "reloc claim done take real | episodes passes services": here
+    // DONE batches, fills, event loop, - , - | loop entries, passes, batches)
+    atomicAdd(&counters[24], cyc_ph[0] >> 10);
+    atomicAdd(&counters[25], cyc_ph[1] >> 10);
+    atomicAdd(&counters[26], cyc_ph[2] >> 10);
+    atomicAdd(&counters[29], (unsigned long long)c_epi);
+    atomicAdd(&counters[30], (unsigned long long)c_pass);
+    atomicAdd(&counters[31], (unsigned long long)c_service);
+#endif
   }
+#undef JB_QT
 }
 
 }  // namespace jb

@@ -66,7 +66,7 @@ namespace jb {
 #define JB_IMC_WAVES_PER_SIMD_LOWD 4
 #endif
 #ifndef JB_IMC_NT_STORES
-#define JB_IMC_NT_STORES 1
+#define JB_IMC_NT_STORES 0
 #endif
 #ifndef JB_IMC_SERVICE_BUDGET
 #define JB_IMC_SERVICE_BUDGET 96
@@ -266,11 +266,13 @@ __global__ void __launch_bounds__(kBlock, NDIM < 3 ? JB_IMC_WAVES_PER_SIMD_LOWD
         if (status == ST_ACTIVE) status = ST_OUTGOING;
         bw = M.gid[b];
       }
-      // (the write-back with the non-temporal hint -- the swarm is a stream, written once per launch: BASELINE
-      // configs[1], counters of one launch: 1.91 + 5.03 GB read + written without it, 1.35 + 4.61 GB with it,
-      // the time unchanged, tools/dev/c2_stores.sh.  What is left of the write side is 13 scattered 4- and 8-byte
-      // stores per finished history at 32 bytes of memory traffic each: the price of a structure-of-arrays swarm
-      // whose photons finish one by one.  -DJB_IMC_NT_STORES=0 switches the hint off.)
+      // (-DJB_IMC_NT_STORES=1: the write-back with the non-temporal hint.  Measured in round 6, counters of one launch,
+      // read + written: BASELINE configs[1] (two 161 MB per-cell arrays going through L2) 1.91 + 5.03 GB plain,
+      // 1.35 + 4.61 GB with the hint; configs[3] (a 0.4 MB mesh: L2 keeps a line until its neighbours' stores have
+      // arrived) 0.44 + 1.96 GB plain, 0.41 + 5.28 GB with it; the time the same in all four (tools/dev/c2_stores.sh).
+      // Plain stores it is.  What is left of the write side is 13 scattered 4- and 8-byte stores per finished
+      // history at 32 bytes of memory traffic each where L2 cannot merge them: the price of a structure-of-arrays
+      // swarm whose photons finish one at a time.)
 #if JB_IMC_NT_STORES
 #define JB_WST(p, v) __builtin_nontemporal_store((v), (p))
 #else

@@ -1,0 +1,23 @@
+# the all-DDMC kernel's swarm accesses with and without the non-temporal hint (variants/libjb_nont.so = -DJB_DDMC_NT=0):
+# time (3 steps behind a warm-up cycle) and the memory-side counters of one launch, c3 and c3-1d
+set -e
+for w in c3 c3-1d; do bash tools/dev/ab2.sh $w 100000000 cur nont; done
+mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for w in c3 c3-1d; do
+for tag in cur nont; do
+  if [ "$tag" = cur ]; then L=$PWD/jaybenne_amd/libjaybenne_amd.so; else L=$PWD/variants/libjb_$tag.so; fi
+  export JAYBENNE_AMD_LIB=$L
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmcw_${w}_${tag}_$c
+    timeout -k 10 100 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmcw_${w}_${tag}_$c -o runc -- python3 bench.py --workload $w --particles-per-gpu 100000000 --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant > gpurun_out/pmcw_c3.json 2> gpurun_out/pmcw_err.txt
+    python3 - gpurun_out/pmcw_${w}_${tag}_$c $w/$tag $c <<'P'
+import csv, glob, os, sys
+tot = 0.0
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_ddmc" in r["Kernel_Name"] and r["Counter_Name"] == sys.argv[3]: tot += float(r["Counter_Value"])
+print(sys.argv[2], sys.argv[3], "%.3f GB" % (tot * 1024 / 1e9))
+P
+  done
+done
+done
