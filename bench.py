@@ -534,6 +534,11 @@ def main() -> None:
     md.force_exchange = bool(args.force_exchange)
     md.defrag_interval = int(args.defrag_interval)
     md.handoff = args.handoff
+    if comm is not None and world > 1 and drv.decomposition != "replicated":
+        # (the hand-off's transport -- the library's own RCCL communicator -- is made here, before any cycle, not
+        # inside the first exchange of the first cycle: a driver that asks for no warm-up still times no bootstrap)
+        md.ensure_handoff()
+        rank_log("hand-off: " + md.handoff_path())
 
     def sync_all():
         torch.cuda.synchronize(device)

@@ -318,6 +318,13 @@ class MeshData:
     def n(self) -> int:
         return int(self.sv.n)
 
+    def ensure_handoff(self) -> None:
+        """Makes the C hand-off's transport now (collective over the ranks: jaybenne_amd/handoff.py) instead of
+        inside the first exchange."""
+        if self.handoff != "python" and self._chandoff is None and self.comm is not None:
+            from .handoff import CHandoff
+            self._chandoff = CHandoff.make(self, {"c": "auto", "c-torch": "torch", "c-rccl": "rccl"}[self.handoff])
+
     def handoff_path(self) -> str:
         """What the hand-off of this MeshData runs through (bench.py: ``handoff.path``)."""
         if self.handoff == "python":
@@ -559,9 +566,7 @@ def _exchange(md: MeshData, first: int, last: int):
     lib, ctx = md.lib, md.pkg.ctx
     if md.handoff != "python":
         # the library's one C call (jb_exchange; jaybenne_amd/handoff.py): the default
-        if md._chandoff is None:
-            from .handoff import CHandoff
-            md._chandoff = CHandoff.make(md, {"c": "auto", "c-torch": "torch", "c-rccl": "rccl"}[md.handoff])
+        md.ensure_handoff()
         t_c = time.perf_counter()
         out = md._chandoff.exchange(first, last)
         md.collective_seconds += time.perf_counter() - t_c   # (the whole call: the collectives are inside it)
