@@ -29,6 +29,9 @@ constexpr int kQReady = 128;   // entries: up to 64 left over + 64 photons per f
 constexpr int kQDone = 64;     // one full-width batch for the service phase
 constexpr int kQBlocks = 64;   // per-block tables in LDS (k_ddmc_all: 128): with the queues the workgroup stays under
                                // 40 KB of LDS, i.e. four workgroups per CU
+#ifndef JB_DDMC_Q_RETIRE_MIN   // lanes without a running photon before the loop exchanges them (3-D / 2-D; 1-D: 1)
+#define JB_DDMC_Q_RETIRE_MIN 1
+#endif
 #ifndef JB_DDMC_Q_BUDGET       // idle lane-passes the loop's tail (no photons left to load) spends before it is left
 #define JB_DDMC_Q_BUDGET 256
 #endif
@@ -58,6 +61,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
   unsigned long long *const counters = g1(A.counters);
   constexpr bool NT = JB_DDMC_NT != 0;   // non-temporal swarm accesses (see swarm_ld)
   constexpr bool multi_d = NDIM >= 2;
+  constexpr int kRetireMin = NDIM == 1 ? 1 : JB_DDMC_Q_RETIRE_MIN;
   typedef double v4d __attribute__((ext_vector_type(4)));
   typedef const unsigned __attribute__((address_space(1))) *gcptr_u;
 
@@ -567,8 +571,10 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       if constexpr (NDIM == 3) r_rec = leak ? r_rec + (unsigned)delta : r_rec;
       else r_rec = (leak && delta != kPdStay) ? r_rec + (unsigned)delta : r_rec;
       r_ls = live ? ((ev && absorbed) ? DS_ABS : (done ? (ev ? DS_DONE : DS_CENSUS) : DS_VIRT)) : r_ls;
-      // ---- histories that ended in this pass leave for the DONE queue, their lanes take the next photons
-      if (__ballot(r_ls != DS_VIRT) != 0ull) retire_refill();
+      // ---- histories that have ended leave for the DONE queue and their lanes take the next photons -- once
+      //      kRetireMin lanes stand still (the ~40 instructions of that exchange are the same for one lane and for
+      //      eight: a lane that waits a pass for company costs 1/64 of a pass)
+      if (__popcll(__ballot(r_ls != DS_VIRT)) >= kRetireMin) retire_refill();
       // the code of the cell every lane is in now, for the next pass (32-bit byte offset from a scalar base: the
       // codes of < 2^29 cells span < 2 GiB)
       code = load_code(r_ls == DS_VIRT ? r_rec : 0u);
