@@ -150,7 +150,7 @@ for wl in ("c2", "c3", "c5"):
     p = os.path.join(src, f"bench_{wl}_under_rocprof.json")
     if os.path.exists(p) and last_json_line(p):
         json.dump(last_json_line(p), open(os.path.join(out, f"{tag}_bench_{wl}_under_rocprof.json"), "w"), indent=1)
-for wl in ("c1", "c2", "c3", "c3-1d", "c4", "c5"):
+for wl in ("c1", "c2", "c2_20steps", "c2_12500k", "c3", "c3-1d", "c4", "c5"):
     p = os.path.join(src, f"bench_{wl}.json")
     if os.path.exists(p) and last_json_line(p):
         json.dump(last_json_line(p), open(os.path.join(out, f"{tag}_bench_{wl}.json"), "w"), indent=1)
