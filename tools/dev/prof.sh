@@ -16,7 +16,7 @@ C31="python3 bench.py --workload c3-1d --particles-per-gpu 100000000 --steps 1 -
 C4="python3 bench.py --workload c4 --particles-per-gpu 10000000 --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
 C5="python3 bench.py --workload c5 --particles-per-gpu 10000000 --steps 1 --warmup 0 --no-cpu-baseline"
 C2X="python3 bench.py --arithmetic exact --steps 1 --warmup 0 --no-cpu-baseline --no-other-variant"
-if [ "$PART" != 2 ]; then
+if [ "$PART" != 2 ] && [ "$PART" != pmc ]; then
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o runc -- python3 bench.py > $O/bench_c2_under_rocprof.json 2> $O/stats_c2.err
 echo "stats c2 done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -o runc -- python3 bench.py --workload c3 --particles-per-gpu 100000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c3_under_rocprof.json 2> $O/stats_c3.err
@@ -33,7 +33,8 @@ PF="TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum"
 PG="TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum"
 PH="TCC_BUSY_sum TCC_CYCLE_sum TCC_TAG_STALL_sum"
 PI="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"
-case $PART in 1) WLS="c2 c3 c3-1d";; 2) WLS="c5 c4 c2x";; *) WLS="c2 c3 c3-1d c5 c4 c2x";; esac
+# PART=pmc WLS="c2 c4": only the --pmc passes of the workloads named
+case $PART in 1) WLS="c2 c3 c3-1d";; 2) WLS="c5 c4 c2x";; pmc) ;; *) WLS="c2 c3 c3-1d c5 c4 c2x";; esac
 for wl in $WLS; do
   case $wl in c2) CMD=$C2;; c3) CMD=$C3;; c3-1d) CMD=$C31;; c4) CMD=$C4;; c5) CMD=$C5;; c2x) CMD=$C2X;; esac
   for p in A B C D E F G H I; do
@@ -43,6 +44,7 @@ for wl in $WLS; do
   done
 done
 [ "$PART" = 1 ] && { echo "part 1 done"; exit 0; }
+[ "$PART" = pmc ] && { echo "pmc passes done"; exit 0; }
 # the reference's trace ranges (Jaybenne::Timestep, Jaybenne::TransportLoop, one per task) beside the kernels of a
 # configs[4] cycle
 timeout -k 10 300 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $O/markers_c5 -o runc -- python3 bench.py --workload c5 --particles-per-gpu 10000000 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c5_markers.json 2> $O/markers_c5.err || echo "marker trace FAILED"
