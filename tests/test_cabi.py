@@ -274,10 +274,12 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
                 assert vgpr <= 128, f"{what}: {vgpr} vector registers (> 128: three waves per SIMD)"
             assert not scratch_in_inner_loops(names[0]), f"{what}: register spills inside an event loop"
         elif "k_ddmc_q" in key:
-            # four waves per SIMD AND four workgroups per CU: 128 registers without a spill, static LDS (block
-            # table, math tables, the waves' READY / DONE queues) + the dynamic part of a typical launch (a
-            # handful of 64-byte class records, the 1-D decks' 1 KB tally) within 40 KB
-            assert vgpr <= 128 and scratch == 0, f"{what}: {vgpr} registers, {scratch} bytes of scratch"
+            # four waves per SIMD AND four workgroups per CU: 128 registers -- the 3-D form parks up to five
+            # values per lane around the event loop, never inside it --, static LDS (block table, math tables, the
+            # waves' READY / DONE queues) + the dynamic part of a typical launch (a handful of 64-byte class
+            # records, the 1-D decks' 1 KB tally) within 40 KB
+            assert vgpr <= 128 and scratch <= 48, f"{what}: {vgpr} registers, {scratch} bytes of scratch"
+            assert not scratch_in_inner_loops(names[0]), f"{what}: register spills inside the event loop"
             lds = int(re.search(r"\.amdhsa_kernel %s.*?\.amdhsa_group_segment_fixed_size (\d+)" % re.escape(names[0]), text, re.S).group(1))
             assert lds + 2048 <= 40 * 1024, f"{what}: {lds} bytes of static LDS"
         elif "k_ddmc_all" in key:
