@@ -408,7 +408,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           s.vv = vv;
           faces_of(s, Bd, ip, jp, kp);
           if (resample) {  // transport_utils.hpp:265-276, once per history
+#ifndef JB_DDMC_EXP_NORESAMPLE   // (timing experiment: results are wrong)
             ddmc_census_resample(s, rng);
+#endif
             x = s.x; y = s.y; z = s.z; vx = s.vx; vy = s.vy; vz = s.vz;
             pend = -1;
             write_v = true;
@@ -437,9 +439,13 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           } else if (status == ST_ACTIVE) {
             if constexpr (TALLY) {  // jaybenne.cpp:547-561
               const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
+#ifndef JB_DDMC_EXP_NOTALLY      // (timing experiment: results are wrong)
               const double wgt = swarm_ld<NT>(&g1(S.w)[n]);
               if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
               else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], wgt / dv);
+#else
+              (void)dv;
+#endif
             }
           }
         }
