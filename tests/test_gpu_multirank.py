@@ -84,10 +84,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, outdir, decomposition="blocks", handoff="c"):
+def _worker(rank, world, port, case, outdir, decomposition="blocks", handoff="c", min_records=None):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), JB_HANDOFF=handoff)
+    if min_records is not None:
+        os.environ["JB_HANDOFF_MIN_RECORDS"] = str(min_records)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from jaybenne_amd import mcblock
@@ -100,6 +102,8 @@ def _worker(rank, world, port, case, outdir, decomposition="blocks", handoff="c"
         n0 = drv.md.n
         for _ in range(cycles):
             drv.Step()
+        if min_records is not None:     # the record buffers started too small: the capacity protocol has run
+            assert drv.md._chandoff.grown > 2, drv.md._chandoff.grown
         if decomposition == "blocks":   # the hand-off ran through the path asked for
             assert drv.md.handoff_path().startswith("python" if handoff == "python" else "c: jb_exchange, its two collectives as torch"), drv.md.handoff_path()
         g = drv.md.get_swarm()
@@ -117,6 +121,14 @@ def test_two_ranks_equal_the_oracle(gpu_device, case, tmp_path):
     """(the hand-off through the library's one C call, jb_exchange -- the default; its two collectives are
     torch.distributed calls over gloo here: jaybenne_amd/handoff.py)"""
     _ranks_equal_the_oracle(case, 2, tmp_path)
+
+
+@pytest.mark.parametrize("case,world", [(3, 2), (6, 4)])
+def test_c_hand_off_grows_its_record_buffers_through_the_capacity_protocol(gpu_device, case, world, tmp_path):
+    """jb_exchange with record buffers of 16 entries to start with (JB_HANDOFF_MIN_RECORDS): JB_ERR_CAPACITY comes
+    out on every rank in the same call (the ranks' room travels in the count matrix), each rank grows what IT
+    lacks, all call again (jaybenne_amd/handoff.py) -- and the photons are the oracle's."""
+    _ranks_equal_the_oracle(case, world, tmp_path, min_records=16)
 
 
 @pytest.mark.parametrize("case,world", [(0, 2), (3, 2), (7, 2), (6, 4)])
@@ -164,12 +176,12 @@ def test_replicated_mesh_split_particles_equals_the_oracle(gpu_device, case, wor
     _ranks_equal_the_oracle(case, world, tmp_path, decomposition="replicated")
 
 
-def _ranks_equal_the_oracle(case, world, tmp_path, decomposition="blocks", handoff="c"):
+def _ranks_equal_the_oracle(case, world, tmp_path, decomposition="blocks", handoff="c", min_records=None):
     from oracle import orc
     sys.path.insert(0, os.path.dirname(__file__))
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, str(tmp_path), decomposition, handoff))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, str(tmp_path), decomposition, handoff, min_records))
              for r in range(world)]
     _run_workers(procs)
     pin, cycles = _deck(case)
