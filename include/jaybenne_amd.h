@@ -285,7 +285,9 @@ int jb_get_arithmetic(const jb_context *ctx);
  * "k_ddmc_all<3, true>" = <NDIM, TALLY> on a mesh whose every cell takes DDMC steps (", quad gather"
  * appended when its cell records, more than 1 MiB of them, are fetched quad-cooperatively,
  * ", records in LDS" when the mesh has at most 256 cells and the kernel keeps them in LDS,
- * ", cell codes" when the mesh has at most 256 DISTINCT step records: jb_mesh_ddmc_classes);
+ * ", cell codes" when the mesh has at most 256 DISTINCT step records: jb_mesh_ddmc_classes -- and
+ * ", cell codes, queues" when, with at most 64 resident blocks, the wave's photons are also staged
+ * through queues in LDS: k_ddmc_q, the default on such meshes);
  * "k_hybrid<2, lean, exact geometry>" on a mesh that mixes IMC and DDMC cells (three launches: IMC
  * phase, DDMC phase, remainder); "" before the first launch.  jb_mesh_exact_geometry: 1 if every
  * resident block has power-of-two cell widths and a lower corner that is a whole number of them

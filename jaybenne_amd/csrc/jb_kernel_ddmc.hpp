@@ -122,7 +122,8 @@ __device__ __forceinline__ unsigned quad_bcast_add(unsigned v, unsigned add) {
 // start (<= kLdsRecCells cells, 64 B each: the reference's 1-D decks, BASELINE configs[2] as
 // shipped), after which the loop issues no vector-memory instruction at all.  Measured on that
 // deck the vector L1 was busy 95 % of the kernel's time serving 4.8e9 record look-ups.
-// GATHER 4 (round 6; the default wherever it applies): the loop gathers a 4-byte CELL CODE per step
+// GATHER 4 (round 6; the gather of k_ddmc_q, jb_kernel_ddmc_q.hpp -- the default on meshes with <= 64 resident
+// blocks -- and of this kernel where that one does not apply): the loop gathers a 4-byte CELL CODE per step
 // (DevMesh::ddmc_code) -- the class of the cell's step record, whose <= kMaxClasses distinct values
 // (k_ddmc_pack numbers them every cycle: gray decks have one per level x face-neighbour pattern) sit in
 // LDS, or for a ghost cell where a particle that leaked there really is -- instead of the 64-byte record:
