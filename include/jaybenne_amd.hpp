@@ -508,8 +508,18 @@ inline void InitializeRadiation(MeshData *md, bool is_thermal) {
   EvaluateRadiationEnergy(md);
 }
 
+// A trace range for the lifetime of the object (jb_range_push / jb_range_pop: ROCTx, a no-op without the marker
+// library) -- the reference's Kokkos::Profiling::pushRegion / popRegion, jaybenne.cpp:87,115,127,145
+struct TraceRange {
+  explicit TraceRange(const char *name) { jb_range_push(name); }
+  ~TraceRange() { jb_range_pop(); }
+  TraceRange(const TraceRange &) = delete;
+  TraceRange &operator=(const TraceRange &) = delete;
+};
+
 // jaybenne::RadiationStep(pmesh, t_start, dt) for one rank -- jaybenne.cpp:68-151
 inline TaskStatus RadiationStep(MeshData *md, const Real t_start, const Real dt) {
+  TraceRange timestep("Jaybenne::Timestep");
   const jb_params &p = md->pkg().params();
   md->cycle += 1;
   UpdateDerivedTransportFields(md, dt);
@@ -517,8 +527,11 @@ inline TaskStatus RadiationStep(MeshData *md, const Real t_start, const Real dt)
   Check(jb_zero_energy_tally(md->ctx(), md->mesh()));
   jb_transport_stats before{}, after{};
   Check(jb_get_transport_stats(md->ctx(), &before, 0));
-  if (p.use_ddmc) TransportPhotons_DDMC(md, t_start, dt, /*fuse_census_tally=*/true);
-  else TransportPhotons(md, t_start, dt, /*fuse_census_tally=*/true);
+  {
+    TraceRange loop("Jaybenne::TransportLoop");   // (one pass: every block crossing is resolved in flight)
+    if (p.use_ddmc) TransportPhotons_DDMC(md, t_start, dt, /*fuse_census_tally=*/true);
+    else TransportPhotons(md, t_start, dt, /*fuse_census_tally=*/true);
+  }
   Check(jb_get_transport_stats(md->ctx(), &after, 0));
   if (after.n_outgoing != before.n_outgoing)
     throw Error(JB_ERR_INVALID, "particles left for another rank in a single-rank step");
