@@ -219,6 +219,56 @@ def lean_vs_exact_after_10_cycles(device):
 LOG_DIR = os.path.join(ROOT, "gpurun_out", "bench_logs")
 
 
+def live_traffic(args):
+    """HBM bytes per launch of the tracking kernel(s), measured NOW: two child runs of this command for ONE step
+    under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md
+    prescribes: the two counters do not fit one pass), the counters summed over the tracking kernel's launches of
+    that step.  KB x 1024, raw: the guide's x2 correction of FETCH_SIZE on gfx950 is calibrated for 16 B / lane
+    coalesced streams, not for this kernel's 8-byte gathers and stores.  Returns None when the profiler is not
+    there, fails or takes too long -- the line then quotes the committed summary, labelled."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None          # (no profiler, or this run is itself being profiled)
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="jb_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", JB_BENCH_CHILD="1")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", args.workload,
+                   "--particles-per-gpu", str(args.particles_per_gpu), "--block-nx", str(args.block_nx),
+                   "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-other-variant", "--no-live-traffic"]
+            if args.arithmetic:
+                cmd += ["--arithmetic", args.arithmetic]
+            res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=150)
+            if res.returncode != 0:
+                return None
+            tot, seen = 0.0, False
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in
+                                                            ("k_transport", "k_imc_cell", "k_ddmc_all", "k_ddmc_q", "k_hybrid")):
+                        tot += float(r["Counter_Value"])
+                        seen = True
+            if not seen:
+                return None
+            out[counter] = tot * 1024.0
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"fetch_bytes": out["FETCH_SIZE"], "write_bytes": out["WRITE_SIZE"],
+            "bytes": out["FETCH_SIZE"] + out["WRITE_SIZE"],
+            "how": "two child runs of this command for one step (first cycle) under rocprofv3 --kernel-trace --pmc "
+                   "FETCH_SIZE / WRITE_SIZE, summed over the tracking kernel's launches; KB x 1024, raw"}
+
+
 def self_launch(args) -> int:
     """--gpus N > 1 from a plain `python bench.py`: N fresh rank processes, started before this
     process has imported torch or made any HIP call (re-executing a process that has initialised
@@ -453,6 +503,9 @@ def main() -> None:
     ap.add_argument("--no-blocks-variant", action="store_true",
                     help="several GPUs, c5: skip the extra run on the block partition when 'auto' chose the "
                          "replicated mesh (config.blocks_variant)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with two child runs under rocprofv3 (1 GPU); the line then "
+                         "quotes the committed counter summary, labelled")
     ap.add_argument("--no-other-variant", action="store_true",
                     help="skip the one extra step in the other arithmetic variant (profiling runs)")
     ap.add_argument("--arithmetic", choices=("lean", "exact"), default=None,
@@ -755,7 +808,16 @@ def main() -> None:
             "stored_bytes_per_launch": 84.0 * finished / max(main_stats_launches, 1),
             "note": "cumulative counters of the library since the process started (warm-up and timed launches "
                     "alike) divided by the number of launches they cover"}
-        if pmc and roof.get("traffic") and roof.get("algorithmic_hbm_bytes_per_launch"):
+        roof["traffic_source"] = ((pmc_file + " (rocprofv3 --pmc passes of this command; not measured in this run)")
+                                  if pmc else None)
+        if args.gpus == 1 and not args.no_live_traffic and not args.no_cpu_baseline:
+            # (the default run: measure it now -- the GPU is idle, the timed region is over)
+            live = live_traffic(args)
+            if live is not None:
+                roof["traffic"] = live["bytes"]
+                roof["traffic_source"] = "measured in this run: " + live["how"]
+                roof["traffic_fetch_write"] = [live["fetch_bytes"], live["write_bytes"]]
+        if roof.get("traffic") and roof.get("algorithmic_hbm_bytes_per_launch"):
             roof["wasted_traffic_ratio"] = roof["traffic"] / roof["algorithmic_hbm_bytes_per_launch"]
         if pmc:
             roof["counters"] = {"source": pmc_file + " (rocprofv3 --pmc passes of this command; "
