@@ -219,13 +219,13 @@ def lean_vs_exact_after_10_cycles(device):
 LOG_DIR = os.path.join(ROOT, "gpurun_out", "bench_logs")
 
 
-def live_traffic(args):
-    """HBM bytes per launch of the tracking kernel(s), measured NOW: two child runs of this command for ONE step
-    under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md
-    prescribes: the two counters do not fit one pass), the counters summed over the tracking kernel's launches of
-    that step.  KB x 1024, raw: the guide's x2 correction of FETCH_SIZE on gfx950 is calibrated for 16 B / lane
-    coalesced streams, not for this kernel's 8-byte gathers and stores.  Returns None when the profiler is not
-    there, fails or takes too long -- the line then quotes the committed summary, labelled."""
+def live_counters(args):
+    """Counters of the tracking kernel(s) measured NOW: four child runs of this command for ONE step under
+    `rocprofv3 --kernel-trace --pmc <group>` (separate passes, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+    WRITE_SIZE do not fit one pass, an SQ group is eight counters), the counters summed over the tracking kernel's
+    launches of that step.  HBM bytes: KB x 1024, raw (the guide's x2 correction of FETCH_SIZE on gfx950 is
+    calibrated for 16 B / lane coalesced streams, not for this kernel's 8-byte gathers and stores).  Returns None
+    when the profiler is not there, fails or takes too long -- the line then quotes the committed summary, labelled."""
     import csv
     import glob
     import shutil
@@ -234,39 +234,60 @@ def live_traffic(args):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None          # (no profiler, or this run is itself being profiled)
-    out = {}
-    tmp = tempfile.mkdtemp(prefix="jb_traffic_", dir="/tmp")
+    groups = {"fetch": "FETCH_SIZE GRBM_GUI_ACTIVE", "write": "WRITE_SIZE",
+              "sq": "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY",
+              "f64": "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64"}
+    kernels = ("k_transport", "k_imc_cell", "k_ddmc_all", "k_ddmc_q", "k_hybrid")
+    c, ms = {}, {}
+    tmp = tempfile.mkdtemp(prefix="jb_counters_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", JB_BENCH_CHILD="1")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--",
-                   sys.executable, os.path.abspath(__file__), "--workload", args.workload,
+        for name, counters in groups.items():
+            d = os.path.join(tmp, name)
+            cmd = [prof, "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "-o", "run",
+                   "--", sys.executable, os.path.abspath(__file__), "--workload", args.workload,
                    "--particles-per-gpu", str(args.particles_per_gpu), "--block-nx", str(args.block_nx),
-                   "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-other-variant", "--no-live-traffic"]
+                   "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-other-variant", "--no-live-counters"]
             if args.arithmetic:
                 cmd += ["--arithmetic", args.arithmetic]
             res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=150)
             if res.returncode != 0:
                 return None
-            tot, seen = 0.0, False
+            seen = False
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in
-                                                            ("k_transport", "k_imc_cell", "k_ddmc_all", "k_ddmc_q", "k_hybrid")):
-                        tot += float(r["Counter_Value"])
+                    if any(k in r["Kernel_Name"] for k in kernels):
+                        c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                         seen = True
             if not seen:
                 return None
-            out[counter] = tot * 1024.0
+            dur = 0.0
+            for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if any(k in r["Kernel_Name"] for k in kernels):
+                        dur += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+            ms[name] = dur
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return {"fetch_bytes": out["FETCH_SIZE"], "write_bytes": out["WRITE_SIZE"],
-            "bytes": out["FETCH_SIZE"] + out["WRITE_SIZE"],
-            "how": "two child runs of this command for one step (first cycle) under rocprofv3 --kernel-trace --pmc "
-                   "FETCH_SIZE / WRITE_SIZE, summed over the tracking kernel's launches; KB x 1024, raw"}
+    try:
+        simd_cycles = 1024.0 * (c["GRBM_GUI_ACTIVE"] / 8.0) * (ms["sq"] / ms["fetch"])
+        lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        fr = {"valu_issue_frac": min(1.0, 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles),
+              "fp64_counter_frac": ((2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"])
+                                    * 64.0 * lane_util / (ms["f64"] * 1e-3) / (FP64_VALU_PEAK_TF * 1e12)),
+              "valu_lane_utilisation": lane_util,
+              "wave_time_fraction_waiting_on_memory": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+              "effective_clock_GHz": c["GRBM_GUI_ACTIVE"] / 8.0 / (ms["fetch"] * 1e-3) / 1e9,
+              "kernel_ms_under_rocprof": ms["sq"]}
+    except (KeyError, ZeroDivisionError):
+        fr = {}
+    return {"fetch_bytes": c["FETCH_SIZE"] * 1024.0, "write_bytes": c["WRITE_SIZE"] * 1024.0,
+            "bytes": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "fractions": fr, "raw": c,
+            "how": "four child runs of this command for one step (first cycle) under rocprofv3 --kernel-trace --pmc "
+                   "<FETCH_SIZE GRBM_GUI_ACTIVE | WRITE_SIZE | SQ group | FP64 group>, summed over the tracking "
+                   "kernel's launches; HBM bytes = KB x 1024, raw"}
 
 
 def self_launch(args) -> int:
@@ -503,9 +524,10 @@ def main() -> None:
     ap.add_argument("--no-blocks-variant", action="store_true",
                     help="several GPUs, c5: skip the extra run on the block partition when 'auto' chose the "
                          "replicated mesh (config.blocks_variant)")
-    ap.add_argument("--no-live-traffic", action="store_true",
-                    help="do not measure roofline.traffic with two child runs under rocprofv3 (1 GPU); the line then "
-                         "quotes the committed counter summary, labelled")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not measure roofline.traffic / valu_issue_frac / fp64_counter_frac with four child runs "
+                         "under rocprofv3 (1 GPU, default line); the line then quotes the committed counter summary, "
+                         "labelled")
     ap.add_argument("--no-other-variant", action="store_true",
                     help="skip the one extra step in the other arithmetic variant (profiling runs)")
     ap.add_argument("--arithmetic", choices=("lean", "exact"), default=None,
@@ -810,13 +832,20 @@ def main() -> None:
                     "alike) divided by the number of launches they cover"}
         roof["traffic_source"] = ((pmc_file + " (rocprofv3 --pmc passes of this command; not measured in this run)")
                                   if pmc else None)
-        if args.gpus == 1 and not args.no_live_traffic and not args.no_cpu_baseline:
-            # (the default run: measure it now -- the GPU is idle, the timed region is over)
-            live = live_traffic(args)
+        if args.gpus == 1 and not args.no_live_counters and not args.no_cpu_baseline:
+            # (the default run: measure them now -- the GPU is idle, the timed region is over)
+            live = live_counters(args)
             if live is not None:
                 roof["traffic"] = live["bytes"]
                 roof["traffic_source"] = "measured in this run: " + live["how"]
                 roof["traffic_fetch_write"] = [live["fetch_bytes"], live["write_bytes"]]
+                if live["fractions"]:
+                    roof.update({k: v for k, v in live["fractions"].items()})
+                    roof["valu_issue_definition"] = ("measured in this run (the child passes of traffic_source): "
+                                                     "valu_issue_frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), "
+                                                     "clamped to 1; fp64_counter_frac = FP64 flop the counters saw (fma 2, add / mul 1, "
+                                                     "x lanes in use) / launch time / 78.6 TF/s")
+                roof["counters_measured_in_run"] = live["raw"]
         if roof.get("traffic") and roof.get("algorithmic_hbm_bytes_per_launch"):
             roof["wasted_traffic_ratio"] = roof["traffic"] / roof["algorithmic_hbm_bytes_per_launch"]
         if pmc:
