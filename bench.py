@@ -250,7 +250,7 @@ def live_counters(args):
                    "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-other-variant", "--no-live-counters"]
             if args.arithmetic:
                 cmd += ["--arithmetic", args.arithmetic]
-            res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=150)
+            res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=90)
             if res.returncode != 0:
                 return None
             seen = False
