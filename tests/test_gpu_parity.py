@@ -463,8 +463,8 @@ def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel
         drv.Step()
     run_oracle_cycles(O, pin, 2)
     variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
-    assert {"lds": "k_ddmc_all<1, true, records in LDS>", "queues-1d": "k_ddmc_all<1, true, cell codes, queues>",
-            "queues": "k_ddmc_all<3, true, cell codes, queues>"}.get(coop, "k_ddmc_all<3") in variant
+    assert {"lds": "k_ddmc_all<1, true, records in LDS>", "queues-1d": "k_ddmc_all<1, true, cell codes, queues",
+            "queues": "k_ddmc_all<3, true, cell codes, queues"}.get(coop, "k_ddmc_all<3") in variant
     _compare_swarm(drv.md, O)
     _compare_fields(drv.md, O)
     assert drv.md.events == O.events
