@@ -67,6 +67,7 @@ struct jb_context {
   bool lean_arith = true;
   int blocks_per_cu_env = 0;  // JB_TRANSPORT_BLOCKS_PER_CU at jb_initialize (tuning aid), 0 = occupancy query
   bool no_ddmc_all = false;   // JB_NO_DDMC_ALL=1 at jb_initialize (tests: k_hybrid on all-DDMC meshes)
+  int ddmc_lds_codes = 1;          // JB_DDMC_LDS_CODES=0: k_ddmc_q gathers the cell codes from device memory on any mesh (tests, A/B)
   int ddmc_queues = 1;             // JB_DDMC_QUEUES=0: k_ddmc_all instead of k_ddmc_q where both apply (tests, A/B)
   int max_classes = kMaxClasses;   // JB_DDMC_MAX_CLASSES: fewer (tests of the fall-back to the 64-byte gather)
   int coop_gather = -1;       // JB_COOP_GATHER=0 / 1 / 2: k_ddmc_all's quad-cooperative gather off / on / on with 64-bit addresses, whatever the table size
@@ -90,7 +91,9 @@ struct jb_context {
   bool sort_scratch_tried = false;   // the sort's scratch records have been asked for (first policy call)
 };
 constexpr int kTransportEventPairs = 64;
-constexpr int kCounterWords = 1024;  // CNT_N.. | 16..17 cursors | 32.. per-rank counts (<= 480 ranks)
+constexpr int kRankEnd = 1024;                               // CNT_N.. | 16..17 cursors | 32..1023 per-rank counts
+constexpr int kCounterWords = kRankEnd + kQueues * kQueueStride;  // | 1024.. the queue heads, one line each (CNT_QUEUE)
+static_assert(CNT_QUEUE == kRankEnd, "the queue heads follow the per-rank counts");
 constexpr int kCursorBase = 16;
 constexpr int kRankBase = 32;
 
@@ -242,6 +245,7 @@ extern "C" jb_status jb_initialize(const jb_params *params, const jb_eos *eos,
   if (const char *e = getenv("JB_NO_IMC_CELL")) ctx->no_imc_cell = e[0] == '1';
   if (const char *e = getenv("JB_COOP_GATHER")) ctx->coop_gather = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : (e[0] == '4' ? 4 : 0));  // (tests, A/B runs)
   if (const char *e = getenv("JB_DDMC_QUEUES")) ctx->ddmc_queues = e[0] != '0';
+  if (const char *e = getenv("JB_DDMC_LDS_CODES")) ctx->ddmc_lds_codes = e[0] != '0';
   if (const char *e = getenv("JB_DDMC_MAX_CLASSES")) {   // (tests: the fall-back when a mesh has more distinct step records)
     const int v = atoi(e);
     ctx->max_classes = v < 0 ? 0 : (v > kMaxClasses ? kMaxClasses : v);
@@ -825,7 +829,7 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
   // are already drained.  JB_TRANSPORT_BLOCKS_PER_CU overrides the occupancy query (tuning aid).
   const int per_cu_env = ctx->blocks_per_cu_env;
   const bool gray = M.lam_abs != nullptr;
-  (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream);
+  (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * kQueueStride * sizeof(unsigned long long), ctx->stream);
 #define JB_LAUNCH_X(T, G, X, L)                                                                    \
   do {                                                                                             \
     static int occ = 0;  /* (one query per kernel instantiation and process) */                    \
@@ -928,6 +932,8 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
                             last <= (1ll << 32);
         const bool codes = queues || (codes_ok && (ctx->coop_gather == 4 || (ctx->coop_gather < 0 && !in_lds)));
         const int gather = codes ? 4 : (coop ? (wide ? 3 : 1) : (in_lds ? 2 : 0));
+        // ... the codes themselves in LDS on a mesh of at most kLdsCodeCells cells (JB_DDMC_LDS_CODES=0: not)
+        const bool lcodes = queues && ctx->ddmc_lds_codes && (long long)M.nblocks * M.ntot <= (long long)kLdsCodeCells;
         // A particle that sits at a face of its cell when it is loaded or relocated (one in ~1e8) needs
         // the albedo step: k_ddmc_all lists it, and k_hybrid<.., both loops>, launched behind it on
         // that list (its length read on the device: no synchronisation), tracks it to the end.
@@ -941,7 +947,8 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         const size_t ncell_all = (size_t)M.nblocks * (size_t)M.ntot;
         const size_t lds_tally_bytes =
             (tally && (long long)ncell_all <= (long long)kLdsTally ? sizeof(double) * ((ncell_all + 1) / 2 * 2) : 0) +
-            (codes ? 64 * (size_t)mesh->nclass_host : (in_lds ? 64 * ncell_all : 0));
+            (codes ? 64 * (size_t)mesh->nclass_host : (in_lds ? 64 * ncell_all : 0)) +
+            (lcodes ? sizeof(unsigned) * ((ncell_all + 1) / 2 * 2) : 0);
         (void)hipMemsetAsync(n_handed, 0, sizeof(unsigned long long), ctx->stream);
 #define JB_LAUNCH_DDMC_ALL(TL, CO)                                                                          \
   do {                                                                                                      \
@@ -956,17 +963,22 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
     hipLaunchKernelGGL((k_ddmc_all<NDIM, TL, CO>), dim3(g), dim3(kBlock), lds_tally_bytes, ctx->stream, mesh->dm_dev, ctx->dp, S, \
                        t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc, handed, n_handed); \
   } while (0)
-#define JB_LAUNCH_DDMC_Q(TL)                                                                               \
+#define JB_LAUNCH_DDMC_Q1(TL, LC)                                                                          \
   do {                                                                                                      \
     int oc = 0;                                                                                             \
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, k_ddmc_q<NDIM, TL>, kBlock, lds_tally_bytes) != hipSuccess || oc < 1) oc = 3; \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, k_ddmc_q<NDIM, TL, LC>, kBlock, lds_tally_bytes) != hipSuccess || oc < 1) oc = 3; \
     const int g = grid_for(ctx, last - first, per_cu_env > 0 ? per_cu_env : oc);                            \
-    hipLaunchKernelGGL((k_ddmc_q<NDIM, TL>), dim3(g), dim3(kBlock), lds_tally_bytes, ctx->stream, mesh->dm_dev, ctx->dp, S, \
+    hipLaunchKernelGGL((k_ddmc_q<NDIM, TL, LC>), dim3(g), dim3(kBlock), lds_tally_bytes, ctx->stream, mesh->dm_dev, ctx->dp, S, \
                        t_start, dt, first, last, ctx->counters_d, (const int *)M.not_all_ddmc, handed, n_handed); \
+  } while (0)
+#define JB_LAUNCH_DDMC_Q(TL)                                                                               \
+  do {                                                                                                      \
+    if (lcodes) JB_LAUNCH_DDMC_Q1(TL, true);                                                                \
+    else JB_LAUNCH_DDMC_Q1(TL, false);                                                                      \
   } while (0)
 #define JB_LAUNCH_HANDED(TL, NA)                                                                            \
   do {                                                                                                      \
-    (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream); \
+    (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * kQueueStride * sizeof(unsigned long long), ctx->stream); \
     hipLaunchKernelGGL((k_hybrid<NDIM, TL, NA, 0, 0>), dim3(kQueues), dim3(kBlock), 0, ctx->stream, mesh->dm_dev, \
                        ctx->dp, S, t_start, dt, 0ll, (long long)(last - first), ctx->counters_d,            \
                        (const unsigned *)handed, (unsigned *)nullptr, (unsigned long long *)nullptr,         \
@@ -979,11 +991,14 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
              {"k_ddmc_all<2, true>", "k_ddmc_all<2, true, quad gather>", "k_ddmc_all<2, true, records in LDS>", "k_ddmc_all<2, true, cell codes>"}},
             {{"k_ddmc_all<3, false>", "k_ddmc_all<3, false, quad gather>", "k_ddmc_all<3, false, records in LDS>", "k_ddmc_all<3, false, cell codes>"},
              {"k_ddmc_all<3, true>", "k_ddmc_all<3, true, quad gather>", "k_ddmc_all<3, true, records in LDS>", "k_ddmc_all<3, true, cell codes>"}}};
-        static const char *const qnames[3][2] = {
-            {"k_ddmc_all<1, false, cell codes, queues>", "k_ddmc_all<1, true, cell codes, queues>"},
-            {"k_ddmc_all<2, false, cell codes, queues>", "k_ddmc_all<2, true, cell codes, queues>"},
-            {"k_ddmc_all<3, false, cell codes, queues>", "k_ddmc_all<3, true, cell codes, queues>"}};
-        mesh->last_variant = queues ? qnames[NDIM - 1][tally ? 1 : 0]
+        static const char *const qnames[2][3][2] = {
+            {{"k_ddmc_all<1, false, cell codes, queues>", "k_ddmc_all<1, true, cell codes, queues>"},
+             {"k_ddmc_all<2, false, cell codes, queues>", "k_ddmc_all<2, true, cell codes, queues>"},
+             {"k_ddmc_all<3, false, cell codes, queues>", "k_ddmc_all<3, true, cell codes, queues>"}},
+            {{"k_ddmc_all<1, false, cell codes, queues, codes in LDS>", "k_ddmc_all<1, true, cell codes, queues, codes in LDS>"},
+             {"k_ddmc_all<2, false, cell codes, queues, codes in LDS>", "k_ddmc_all<2, true, cell codes, queues, codes in LDS>"},
+             {"k_ddmc_all<3, false, cell codes, queues, codes in LDS>", "k_ddmc_all<3, true, cell codes, queues, codes in LDS>"}}};
+        mesh->last_variant = queues ? qnames[lcodes ? 1 : 0][NDIM - 1][tally ? 1 : 0]
                                     : names[NDIM - 1][tally ? 1 : 0][gather == 4 ? 3 : (gather == 3 ? 1 : gather)];
         if (tally) {
           if (queues) JB_LAUNCH_DDMC_Q(true);
@@ -1006,6 +1021,7 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         }
 #undef JB_LAUNCH_HANDED
 #undef JB_LAUNCH_DDMC_Q
+#undef JB_LAUNCH_DDMC_Q1
 #undef JB_LAUNCH_DDMC_ALL
         return JB_COMPLETE;
       }
@@ -1034,7 +1050,7 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
                                                                  kBlock, 0) != hipSuccess || occ < 1)) \
       occ = 3;                                                                                     \
     const int g = grid_for(ctx, (L) - (F), per_cu_env > 0 ? per_cu_env : occ);                     \
-    (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * sizeof(unsigned long long), ctx->stream); \
+    (void)hipMemsetAsync(ctx->counters_d + CNT_QUEUE, 0, kQueues * kQueueStride * sizeof(unsigned long long), ctx->stream); \
     hipLaunchKernelGGL((k_hybrid<NDIM, T, NA, MD, PH>), dim3(g), dim3(kBlock), 0, ctx->stream,     \
                        mesh->dm_dev, ctx->dp, S, t_start, dt, (long long)(F), (long long)(L), ctx->counters_d,   \
                        (const unsigned *)(LIN), (unsigned *)(LOUT), (unsigned long long *)(COUT),  \
@@ -1196,6 +1212,10 @@ extern "C" jb_status jb_get_transport_stats(jb_context *ctx, jb_transport_stats 
   fprintf(stderr, "JB_TIMING phases reloc %llu claim %llu done %llu take %llu real %llu | episodes %llu passes %llu services %llu\n",
           ctx->counters_h[24], ctx->counters_h[25], ctx->counters_h[26], ctx->counters_h[27],
           ctx->counters_h[28], ctx->counters_h[29], ctx->counters_h[30], ctx->counters_h[31]);
+#ifdef JB_TIMING_LOOP
+  fprintf(stderr, "JB_TIMING_LOOP top %llu code wait %llu step %llu retire+tail %llu\n", ctx->counters_h[20],
+          ctx->counters_h[21], ctx->counters_h[22], ctx->counters_h[23]);
+#endif
 #endif
 #ifdef JB_HYB_STATS  // (diagnostic build of k_hybrid: see jb_kernel_hybrid.hpp)
   {
@@ -1547,7 +1567,7 @@ extern "C" jb_status jb_pack_outgoing(jb_context *ctx, jb_mesh *mesh, const jb_s
   jb_status st = check_swarm(swarm, "jb_pack_outgoing");
   if (st != JB_COMPLETE) return st;
   if (first < 0 || last > swarm->n || first > last) return fail(JB_ERR_INVALID, "bad particle range");
-  if (nranks < mesh->nranks_seen || nranks > kCounterWords - kRankBase)
+  if (nranks < mesh->nranks_seen || nranks > kRankEnd - kRankBase)
     return fail(JB_ERR_INVALID, "nranks = %d does not cover the owners in the mesh view", nranks);
   unsigned long long *per_rank = ctx->counters_d + kRankBase;
   JB_HIP(hipMemsetAsync(per_rank, 0, sizeof(unsigned long long) * nranks, ctx->stream));
@@ -1621,7 +1641,7 @@ extern "C" jb_status jb_exchange(jb_context *ctx, jb_mesh *mesh, jb_swarm_view *
   if (st != JB_COMPLETE) return st;
   if (first < 0 || last > swarm->n || first > last) return fail(JB_ERR_INVALID, "bad particle range");
   if (rank < 0 || rank >= nranks) return fail(JB_ERR_INVALID, "rank outside [0, nranks)");
-  if (nranks < mesh->nranks_seen || nranks + 3 > kCounterWords - kRankBase)
+  if (nranks < mesh->nranks_seen || nranks + 3 > kRankEnd - kRankBase)
     return fail(JB_ERR_INVALID, "nranks = %d does not cover the owners in the mesh view", nranks);
   *nsent = 0; *nreceived = 0; *moved_anywhere = 0;
   const int row = nranks + 3;   // what a rank contributes to the all-gather: counts | send, receive, swarm room

@@ -46,7 +46,13 @@ struct WaveQueues {
   double dn_t[kQDone];
 };
 
-template <int NDIM, bool TALLY>
+// LCODES: the cell codes of a mesh of at most kLdsCodeCells cells (the reference's 1-D decks) are copied to LDS
+// as well, and the event loop has no vector-memory instruction left: its gather no longer queues in the CU's
+// vector L1 behind the scattered photon loads and stores of the other waves' service phases (measured on
+// BASELINE configs[2] as shipped: 910 of a pass's 2560 wave-cycles were that wait; the table is 544 bytes).
+constexpr int kLdsCodeCells = 1024;
+
+template <int NDIM, bool TALLY, bool LCODES = false>
 __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     k_ddmc_q(const DevMesh *__restrict__, DevParams, DevSwarm, double, double, long long, long long,
              unsigned long long *, const int *, unsigned *, unsigned long long *) {
@@ -75,9 +81,11 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     if (tally_in_lds)
       for (int q = threadIdx.x; q < ncell_all; q += blockDim.x) lds_tally[q] = 0.0;
   }
-  {
-    const int ncls = ((gcptr_i)M.not_all_ddmc)[1];
-    for (int q = threadIdx.x; q < 8 * ncls; q += blockDim.x) lds_cls[q] = ((gcptr)M.ddmc_class)[q];
+  const int ncls = ((gcptr_i)M.not_all_ddmc)[1];
+  for (int q = threadIdx.x; q < 8 * ncls; q += blockDim.x) lds_cls[q] = ((gcptr)M.ddmc_class)[q];
+  unsigned *const lds_code = (unsigned *)(lds_cls + 8 * ncls);
+  if constexpr (LCODES) {
+    for (int q = threadIdx.x; q < ncell_all; q += blockDim.x) lds_code[q] = ((gcptr_u)M.ddmc_code)[q];
   }
   __shared__ LdsBlockTableT<false, kQBlocks> lds_blocks;   // (the host launches this kernel on <= kQBlocks resident blocks)
   // the wave's queues (structure of arrays: consecutive lanes, consecutive 8-byte words; one block per wave, so
@@ -92,7 +100,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
                      *const dn_pdfl = Q.dn_pdfl;
   double *const dn_t = Q.dn_t;
 
-  constexpr long long kChunk = JB_DDMC_ALL_CHUNK;
+  // (slots per claim: with 12-step histories the claims come three times as often per unit of time -- 256 against
+  // 128 slots: 7.58 against 7.79 ms on the 1-D deck, 17.75 against 17.62 on the 3-D one)
+  constexpr long long kChunk = NDIM == 1 ? 2 * JB_DDMC_ALL_CHUNK : JB_DDMC_ALL_CHUNK;
   const double vv = P.c;
   const double t_end = t_start + dt;
   const int lane = threadIdx.x & 63;
@@ -143,7 +153,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     return on;
   };
   auto load_code = [&](unsigned recno) {
-    return *(gcptr_u)((const char *)code_base + (recno << 2));
+    if constexpr (LCODES) return lds_code[recno];
+    else return *(gcptr_u)((const char *)code_base + (recno << 2));
   };
   auto below = [&](unsigned long long m) {   // set bits of m below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -151,8 +162,36 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
 
   // A lane whose history has left the loop puts it on the DONE queue (as long as there is room: a lane that
   // finds none keeps it, and the loop is left); a lane without a photon takes the next one off the READY queue.
+  // (wave-uniform: some lane stands idle because the READY queue had nothing for it)
+  bool have_idle = true;
   auto retire_refill = [&]() {
     const unsigned long long fm = __ballot(r_ls >= DS_DONE);
+    const int nf = __popcll(fm);
+    if (!have_idle && nf != 0 && nf <= kQDone - done_cnt && nf <= ready_cnt) {
+      // the common case: every finished history finds room AND a successor, and no other lane is waiting for one --
+      // ONE exchange: entry out, entry in
+      if (r_ls >= DS_DONE) {
+        const int rk = below(fm);
+        const int q = done_cnt + rk;
+        dn_nrec[q] = (unsigned long long)r_n | ((unsigned long long)r_rec << 32);
+        dn_t[q] = r_t;
+        dn_rng[q] = r_rng;
+        dn_pzs[q] = r_pzs;
+        dn_pdfl[q] = (unsigned long long)(unsigned)r_pd | ((unsigned long long)(unsigned)(r_ls | (r_mir ? 8 : 0)) << 32);
+        const int p = ready_cnt - 1 - rk;   // (off the top)
+        const unsigned long long nr = rd_nrec[p];
+        r_n = (unsigned)nr;
+        r_rec = (unsigned)(nr >> 32);
+        r_t = rd_t[p];
+        r_rng = rd_rng[p];
+        r_pd = 0;
+        r_mir = false;
+        r_ls = DS_VIRT;
+      }
+      done_cnt += nf;
+      ready_cnt -= nf;
+      return;
+    }
     if (fm != 0ull) {
       const int room = kQDone - done_cnt;
       const int r = below(fm);
@@ -165,29 +204,28 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         dn_pdfl[q] = (unsigned long long)(unsigned)r_pd | ((unsigned long long)(unsigned)(r_ls | (r_mir ? 8 : 0)) << 32);
         r_ls = DS_IDLE;
       }
-      const int nf = __popcll(fm);
       done_cnt += nf < room ? nf : room;
     }
-    if (ready_cnt > 0) {
-      const unsigned long long wm = __ballot(r_ls == DS_IDLE);
-      if (wm != 0ull) {
-        const int r = below(wm);
-        const int want = __popcll(wm);
-        const int take = want < ready_cnt ? want : ready_cnt;
-        if (r_ls == DS_IDLE && r < take) {
-          const int q = ready_cnt - 1 - r;   // (off the top)
-          const unsigned long long nr = rd_nrec[q];
-          r_n = (unsigned)nr;
-          r_rec = (unsigned)(nr >> 32);
-          r_t = rd_t[q];
-          r_rng = rd_rng[q];
-          r_pd = 0;
-          r_mir = false;
-          r_ls = DS_VIRT;
-        }
-        ready_cnt -= take;
+    const unsigned long long wm = __ballot(r_ls == DS_IDLE);
+    const int want = __popcll(wm);
+    int take = 0;
+    if (ready_cnt > 0 && wm != 0ull) {
+      const int r = below(wm);
+      take = want < ready_cnt ? want : ready_cnt;
+      if (r_ls == DS_IDLE && r < take) {
+        const int q = ready_cnt - 1 - r;   // (off the top)
+        const unsigned long long nr = rd_nrec[q];
+        r_n = (unsigned)nr;
+        r_rec = (unsigned)(nr >> 32);
+        r_t = rd_t[q];
+        r_rng = rd_rng[q];
+        r_pd = 0;
+        r_mir = false;
+        r_ls = DS_VIRT;
       }
+      ready_cnt -= take;
     }
+    have_idle = take < want;
   };
 
   constexpr unsigned long long kMul2 = kLcgMul * kLcgMul, kInc2 = (kLcgMul + 1ull) * kLcgInc;
@@ -196,6 +234,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
 #ifdef JB_TIMING   // (diagnostic build, tools/dev/timing.sh: wave-cycles in the DONE batches / the fills / the event loop)
   unsigned long long cyc_ph[4] = {0, 0, 0, 0}, cyc_mark = __builtin_readcyclecounter();
   unsigned c_epi = 0;
+  unsigned long long cyc_lp[4] = {0, 0, 0, 0};
 #define JB_QT(k) { const unsigned long long now_ = __builtin_readcyclecounter(); cyc_ph[k] += now_ - cyc_mark; cyc_mark = now_; }
 #else
 #define JB_QT(k)
@@ -291,7 +330,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
             long long q_last = q_first + per_q;
             if (q_last > last) q_last = last;
             unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&queue[cur], (unsigned long long)kChunk);
+            if (lane == 0) base = atomicAdd(&queue[cur * kQueueStride], (unsigned long long)kChunk);
             chunk_pos = q_first + (long long)uniform_u64(base);
             chunk_end = chunk_pos + kChunk < q_last ? chunk_pos + kChunk : q_last;
             if (chunk_pos >= q_last) {  // this queue is drained: move on
@@ -513,11 +552,15 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       break;
     }
     int waste = 0;
-    // (nothing of the service phase is left in flight when the loop starts: see k_ddmc_all)
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    // (nothing of the service phase is left in flight when the loop starts: see k_ddmc_all; with the codes in LDS
+    // the loop never waits for the vector-memory counter, and the service phase's stores drain behind it)
+    if constexpr (!LCODES) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
     code = load_code(r_ls == DS_VIRT ? r_rec : 0u);
     for (;;) {
       ++c_pass;
+#ifdef JB_TIMING_LOOP
+      const unsigned long long tl0 = __builtin_readcyclecounter();
+#endif
       // One DDMC step per running lane (transport_utils.hpp:184-263 on the virtual state): k_ddmc_all's pass for
       // cell codes, word for word -- what does not depend on the cell first, then the code requested at the end of
       // the pass before, everything committed through selects.
@@ -529,6 +572,12 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       const double u2 = u52_to_double(s2 >> 12);
       const double nlog = -m_log(u52_to_double(s1 >> 12));
       __builtin_amdgcn_sched_barrier(0);
+#ifdef JB_TIMING_LOOP
+      const unsigned long long tl1 = __builtin_readcyclecounter();
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      const unsigned long long tl2 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       const unsigned cd = code;
       const bool ghost = (int)cd < 0;
       // (a ghost cell has no record: any row will do for the arithmetic nobody commits)
@@ -580,7 +629,16 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       // ---- histories that have ended leave for the DONE queue and their lanes take the next photons -- once
       //      kRetireMin lanes stand still (the ~40 instructions of that exchange are the same for one lane and for
       //      eight: a lane that waits a pass for company costs 1/64 of a pass)
-      if (__popcll(__ballot(r_ls != DS_VIRT)) >= kRetireMin) retire_refill();
+#ifdef JB_TIMING_LOOP
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long tl3 = __builtin_readcyclecounter() + (r_ls == 99 ? 1 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      unsigned long long vm = __ballot(r_ls == DS_VIRT);
+      if (kRetireMin <= 1 ? vm != ~0ull : 64 - __popcll(vm) >= kRetireMin) {
+        retire_refill();
+        vm = __ballot(r_ls == DS_VIRT);
+      }
       // the code of the cell every lane is in now, for the next pass (32-bit byte offset from a scalar base: the
       // codes of < 2^29 cells span < 2 GiB)
       code = load_code(r_ls == DS_VIRT ? r_rec : 0u);
@@ -588,7 +646,12 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       // leave the loop: a finished history found no room (the DONE queue is full: a whole batch for the service
       // phase), nothing runs, or lanes stand idle and there are photons to be loaded (at the tail of the launch:
       // once they have idled long enough).  The common case -- room, and all 64 lanes running -- first.
-      const unsigned long long vm = __ballot(r_ls == DS_VIRT);
+#ifdef JB_TIMING_LOOP
+      {
+        const unsigned long long tl4 = __builtin_readcyclecounter();
+        cyc_lp[0] += tl1 - tl0; cyc_lp[1] += tl2 - tl1; cyc_lp[2] += tl3 - tl2; cyc_lp[3] += tl4 - tl3;
+      }
+#endif
       if (done_cnt == kQDone) break;
       if (vm == ~0ull) continue;
       if (vm == 0ull) break;
@@ -623,6 +686,12 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     atomicAdd(&counters[24], cyc_ph[0] >> 10);
     atomicAdd(&counters[25], cyc_ph[1] >> 10);
     atomicAdd(&counters[26], cyc_ph[2] >> 10);
+#ifdef JB_TIMING_LOOP   // (event loop: top -> code wanted | waiting for the code | step | retire / refill + tail)
+    atomicAdd(&counters[20], cyc_lp[0] >> 10);
+    atomicAdd(&counters[21], cyc_lp[1] >> 10);
+    atomicAdd(&counters[22], cyc_lp[2] >> 10);
+    atomicAdd(&counters[23], cyc_lp[3] >> 10);
+#endif
     atomicAdd(&counters[29], (unsigned long long)c_epi);
     atomicAdd(&counters[30], (unsigned long long)c_pass);
     atomicAdd(&counters[31], (unsigned long long)c_service);

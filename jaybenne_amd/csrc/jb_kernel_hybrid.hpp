@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(kBlock, PHASE == 0 ? JB_HYBRID_REMAINDER_WAVES
           long long q_last = q_first + per_q;
           if (q_last > last) q_last = last;
           unsigned long long base = 0;
-          if (lane == 0) base = atomicAdd(&queue[cur], (unsigned long long)kChunk);
+          if (lane == 0) base = atomicAdd(&queue[cur * kQueueStride], (unsigned long long)kChunk);
           chunk_pos = q_first + (long long)uniform_u64(base);
           chunk_end = chunk_pos + kChunk < q_last ? chunk_pos + kChunk : q_last;
           if (chunk_pos >= q_last) {  // this queue is drained: move on

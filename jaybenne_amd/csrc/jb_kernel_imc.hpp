@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(kBlock, NDIM < 3 ? JB_IMC_WAVES_PER_SIMD_LOWD
         const int leader = __ffsll((long long)idle) - 1;
         const int want = __popcll(idle);
         unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(&queue[cur], (unsigned long long)want);
+        if (lane == leader) base = atomicAdd(&queue[cur * kQueueStride], (unsigned long long)want);
         base = __shfl(base, leader, 64);
         const long long q_first = first + (long long)cur * per_q;
         long long q_last = q_first + per_q;

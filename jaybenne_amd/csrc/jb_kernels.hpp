@@ -29,7 +29,12 @@ constexpr int kBlock = 256;  // 4 waves per workgroup
 // counters[]: 0 census, 1 absorbed, 2 escaped, 3 outgoing, 4 events, 5 unfinished
 enum { CNT_CENSUS = 0, CNT_ABSORBED, CNT_ESCAPED, CNT_OUTGOING, CNT_EVENTS, CNT_UNFINISHED, CNT_PASSES, CNT_SERVICE, CNT_N };
 constexpr int kLdsTally = 1024;  // cells (all resident blocks, ghosts included) tallied in LDS
-constexpr int CNT_QUEUE = 8;  // heads of the 8 particle queues of the running transport launch
+// Heads of the 8 particle queues of the running transport launch, each in a 128-byte line of its own: the claims
+// are returning atomics from every XCD, and atomics on one line are served one after the other -- with the eight
+// heads in ONE line (rounds 1 - 5) and 128-slot claims, BASELINE configs[2] as shipped (12-step histories: 7.8e5
+// claims per 1e8 photons) ran 10.03 ms whatever else was changed; see DESIGN.md 4.2.
+constexpr int CNT_QUEUE = 1024;
+constexpr int kQueueStride = 16;
 constexpr int kQueues = 8;    // one per XCD (workgroups b and b + 8 share an XCD and its L2)
 
 // lane 0's value in every lane, as a wave-uniform (scalar register) quantity
@@ -920,7 +925,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
         const int leader = __ffsll((long long)idle) - 1;
         const int want = __popcll(idle);
         unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(&queue[cur], (unsigned long long)want);
+        if (lane == leader) base = atomicAdd(&queue[cur * kQueueStride], (unsigned long long)want);
         base = __shfl(base, leader, 64);
         const long long q_first = first + (long long)cur * per_q;
         long long q_last = q_first + per_q;
@@ -968,7 +973,7 @@ __launch_bounds__(kBlock, DDMC ? JB_DDMC_WAVES_PER_SIMD
           long long q_last = q_first + per_q;
           if (q_last > last) q_last = last;
           unsigned long long base = 0;
-          if (lane == 0) base = atomicAdd(&queue[cur], (unsigned long long)kChunk);
+          if (lane == 0) base = atomicAdd(&queue[cur * kQueueStride], (unsigned long long)kChunk);
           chunk_pos = q_first + (long long)uniform_u64(base);
           chunk_end = chunk_pos + kChunk < q_last ? chunk_pos + kChunk : q_last;
           if (chunk_pos >= q_last) {  // this queue is drained: move on

@@ -222,9 +222,11 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         "all-DDMC, 3-D, small mesh": "k_ddmc_allILi3ELb1ELi0E",
         "all-DDMC, 1-D, records in LDS (configs[2] as shipped)": "k_ddmc_allILi1ELb1ELi2E",
         "all-DDMC, 3-D, cell codes": "k_ddmc_allILi3ELb1ELi4E",
-        "all-DDMC, 3-D, cell codes + LDS queues (configs[2] in 3-D: the default)": "k_ddmc_qILi3ELb1E",
-        "all-DDMC, 2-D, cell codes + LDS queues": "k_ddmc_qILi2ELb1E",
-        "all-DDMC, 1-D, cell codes + LDS queues (configs[2] as shipped: the default)": "k_ddmc_qILi1ELb1E",
+        "all-DDMC, 3-D, cell codes + LDS queues (configs[2] in 3-D: the default)": "k_ddmc_qILi3ELb1ELb0E",
+        "all-DDMC, 2-D, cell codes + LDS queues": "k_ddmc_qILi2ELb1ELb0E",
+        "all-DDMC, 1-D, cell codes + LDS queues, codes gathered": "k_ddmc_qILi1ELb1ELb0E",
+        "all-DDMC, 1-D, cell codes + LDS queues, codes in LDS (configs[2] as shipped: the default)": "k_ddmc_qILi1ELb1ELb1E",
+        "all-DDMC, 3-D, cell codes + LDS queues, codes in LDS (a mesh of <= 1024 cells)": "k_ddmc_qILi3ELb1ELb1E",
         "hybrid, 2-D, IMC phase in cell-local coordinates (configs[4])": "k_hybridILi2ELb1ELb1ELi3ELi1E",
         "hybrid, 1-D, IMC phase in cell-local coordinates": "k_hybridILi1ELb1ELb1ELi3ELi1E",
         "hybrid, 3-D, IMC phase in cell-local coordinates": "k_hybridILi3ELb1ELb1ELi3ELi1E",
@@ -285,8 +287,9 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
         elif "k_ddmc_all" in key:
             # four waves per SIMD (128 registers): the event loop -- one record number, time, stream state and
             # the pending leak per lane -- is free of scratch; the service phase of the 3-D forms parks up to
-            # five values per lane around it (round 5: measured equal to the 121-register kernel of round 4)
-            assert vgpr <= 128 and scratch <= 48, f"{what}: {vgpr} registers, {scratch} bytes of scratch"
+            # five values per lane around it (round 5: measured equal to the 121-register kernel of round 4; the
+            # non-default 1-D records-in-LDS form: 60 bytes since the queue heads sit a cache line apart)
+            assert vgpr <= 128 and scratch <= 64, f"{what}: {vgpr} registers, {scratch} bytes of scratch"
             assert not scratch_in_inner_loops(names[0]), f"{what}: register spills inside the event loop"
         else:
             assert scratch == 0 and not scratch_in_inner_loops(names[0]), f"{what}: {scratch} bytes of scratch per lane (register spills)"
@@ -298,7 +301,7 @@ def test_hot_kernels_fit_three_waves_per_simd(tmp_path):
     assert len(ddmc) > 0
     max_dynamic_lds = 8 * 1024 + 64 * 256
     for n, (vgpr, scratch) in ddmc.items():
-        assert vgpr <= 128 and scratch <= 48 and not scratch_in_inner_loops(n), (n, vgpr, scratch)
+        assert vgpr <= 128 and scratch <= 64 and not scratch_in_inner_loops(n), (n, vgpr, scratch)
         lds = int(re.search(r"\.amdhsa_kernel %s.*?\.amdhsa_group_segment_fixed_size (\d+)" % re.escape(n), text, re.S).group(1))
         assert lds <= 65536 - max_dynamic_lds, (n, lds)
     # no launch of the hybrid IMC/DDMC path touches scratch memory inside an event loop (the IMC and DDMC

@@ -374,7 +374,7 @@ def test_quad_cooperative_gather_on_all_ddmc_meshes(gpu_device, deck, overrides,
     assert drv.md.events == O.events
 
 
-@pytest.mark.parametrize("mode", ["forced", "queues", "one class allowed", "no class allowed"])
+@pytest.mark.parametrize("mode", ["forced", "queues", "queues, codes gathered", "one class allowed", "no class allowed"])
 @pytest.mark.parametrize("deck,overrides,cycles", [c for c in CASES if c[0].endswith("_ddmc")])
 def test_cell_codes_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, mode, monkeypatch):
     """k_ddmc_all<.., cell codes> (round 6): the event loop gathers a 4-byte code per step -- the number of the
@@ -385,13 +385,16 @@ def test_cell_codes_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, mode
     classes: level x neighbour pattern) and every deck take that way out.  "queues": the library's default where
     the codes apply and at most 64 blocks are resident -- k_ddmc_q (jb_kernel_ddmc_q.hpp): finished histories
     and new photons pass through two queues in LDS, the event loop runs at full width; "forced" is k_ddmc_all on
-    the same codes.  Same bits in all of them."""
+    the same codes.  On a mesh of at most 1024 cells k_ddmc_q keeps the codes in LDS too (no vector-memory
+    instruction left in its event loop); "queues, codes gathered" (JB_DDMC_LDS_CODES=0) is the form the larger
+    meshes run, on every deck.  Same bits in all of them."""
     from oracle import orc
     if mode == "forced":
         monkeypatch.setenv("JB_COOP_GATHER", "4")
-    elif mode == "queues":
+    elif mode.startswith("queues"):
         monkeypatch.delenv("JB_COOP_GATHER", raising=False)
         monkeypatch.setenv("JB_DDMC_QUEUES", "1")
+        monkeypatch.setenv("JB_DDMC_LDS_CODES", "1" if mode == "queues" else "0")
     else:
         monkeypatch.delenv("JB_COOP_GATHER", raising=False)
         monkeypatch.setenv("JB_DDMC_MAX_CLASSES", "1" if mode == "one class allowed" else "0")
@@ -404,8 +407,10 @@ def test_cell_codes_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, mode
     variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
     if mode == "forced":
         assert "cell codes" in variant and "queues" not in variant
-    elif mode == "queues":    # (the 3-D SMR deck keeps 72 blocks resident: more than the kernel's LDS table holds)
+    elif mode.startswith("queues"):    # (the 3-D SMR deck keeps 72 blocks resident: more than the kernel's LDS table holds)
         assert "cell codes" in variant and ("queues" in variant) == (drv.md.nblocks <= 64)
+        small = drv.md.nblocks <= 64 and drv.md.nblocks * drv.md.mesh.ntot <= 1024
+        assert ("codes in LDS" in variant) == (mode == "queues" and small)
     elif mode == "no class allowed":
         assert "k_ddmc_all" in variant and "cell codes" not in variant
     _compare_swarm(drv.md, O)
@@ -413,7 +418,7 @@ def test_cell_codes_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, mode
     assert drv.md.events == O.events
 
 
-@pytest.mark.parametrize("coop", ["0", "1", "2", "4", "lds", "queues", "queues-1d"])
+@pytest.mark.parametrize("coop", ["0", "1", "2", "4", "lds", "queues", "queues-1d", "queues-1d-gathered"])
 def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel(gpu_device, coop, monkeypatch):
     """k_ddmc_all's event loop starts every step from the cell centre, which is what the albedo
     step leaves behind unless the photon sits within 2.5 eps_imc dx of a face of its cell
@@ -425,10 +430,12 @@ def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel
     into the neighbouring cell."""
     import torch
     from oracle import orc
-    if coop in ("lds", "queues-1d"):   # the 1-D deck as shipped: 136 cells (k_ddmc_all: step records in LDS)
+    if coop in ("lds", "queues-1d", "queues-1d-gathered"):   # the 1-D deck as shipped: 136 cells (k_ddmc_all: step
+        # records in LDS; k_ddmc_q: the cell codes in LDS, or gathered from device memory as on a large mesh)
         deck, ov = "stepdiff_ddmc", {"jaybenne/num_particles": 20000}
         monkeypatch.delenv("JB_COOP_GATHER", raising=False)
         monkeypatch.setenv("JB_DDMC_QUEUES", "0" if coop == "lds" else "1")
+        monkeypatch.setenv("JB_DDMC_LDS_CODES", "0" if coop == "queues-1d-gathered" else "1")
     else:
         if coop == "queues":            # the library's default: cell codes + the wave's photons staged through LDS queues
             monkeypatch.delenv("JB_COOP_GATHER", raising=False)
@@ -463,7 +470,8 @@ def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel
         drv.Step()
     run_oracle_cycles(O, pin, 2)
     variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
-    assert {"lds": "k_ddmc_all<1, true, records in LDS>", "queues-1d": "k_ddmc_all<1, true, cell codes, queues",
+    assert {"lds": "k_ddmc_all<1, true, records in LDS>", "queues-1d": "k_ddmc_all<1, true, cell codes, queues, codes in LDS>",
+            "queues-1d-gathered": "k_ddmc_all<1, true, cell codes, queues>",
             "queues": "k_ddmc_all<3, true, cell codes, queues"}.get(coop, "k_ddmc_all<3") in variant
     _compare_swarm(drv.md, O)
     _compare_fields(drv.md, O)
