@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
   unsigned long long r_rng = 0ull, r_pzs = 0ull;
   double r_t = 0.0;
   int r_pd = 0;
-  bool r_mir = false;
+  unsigned r_mir = 0u;   // (0 / 1: an integer, so that it stays in a vector register -- as a lane predicate it was
+                         // carried through the loop in a scalar pair and rebuilt from a register every pass)
   unsigned code = 0u;
 
   auto faces_of = [&](Step &s, const Blk &Bq, int i, int j, int k) {  // transport.cpp:114-119
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         dn_t[q] = r_t;
         dn_rng[q] = r_rng;
         dn_pzs[q] = r_pzs;
-        dn_pdfl[q] = (unsigned long long)(unsigned)r_pd | ((unsigned long long)(unsigned)(r_ls | (r_mir ? 8 : 0)) << 32);
+        dn_pdfl[q] = (unsigned long long)(unsigned)r_pd | ((unsigned long long)((unsigned)r_ls | (r_mir << 3)) << 32);
         const int p = ready_cnt - 1 - rk;   // (off the top)
         const unsigned long long nr = rd_nrec[p];
         r_n = (unsigned)nr;
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         r_t = rd_t[p];
         r_rng = rd_rng[p];
         r_pd = 0;
-        r_mir = false;
+        r_mir = 0u;
         r_ls = DS_VIRT;
       }
       done_cnt += nf;
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         dn_t[q] = r_t;
         dn_rng[q] = r_rng;
         dn_pzs[q] = r_pzs;
-        dn_pdfl[q] = (unsigned long long)(unsigned)r_pd | ((unsigned long long)(unsigned)(r_ls | (r_mir ? 8 : 0)) << 32);
+        dn_pdfl[q] = (unsigned long long)(unsigned)r_pd | ((unsigned long long)((unsigned)r_ls | (r_mir << 3)) << 32);
         r_ls = DS_IDLE;
       }
       done_cnt += nf < room ? nf : room;
@@ -220,7 +221,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         r_t = rd_t[q];
         r_rng = rd_rng[q];
         r_pd = 0;
-        r_mir = false;
+        r_mir = 0u;
         r_ls = DS_VIRT;
       }
       ready_cnt -= take;
@@ -555,7 +556,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
     // (nothing of the service phase is left in flight when the loop starts: see k_ddmc_all; with the codes in LDS
     // the loop never waits for the vector-memory counter, and the service phase's stores drain behind it)
     if constexpr (!LCODES) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-    code = load_code(r_ls == DS_VIRT ? r_rec : 0u);
+    code = load_code(r_rec);
     for (;;) {
       ++c_pass;
 #ifdef JB_TIMING_LOOP
@@ -588,15 +589,17 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       r.ffaa = r0.x; r.c1 = r0.y; r.c2 = r0.z; r.c3 = r0.w;
       r.c4 = r1.x; r.c5 = r1.y; r.leak_tot = r1.z; r.rcp = r1.w;
       const bool gl = run && ghost;
-      if (__ballot(gl) != 0ull) {   // a leak through a block face: the particle sits this pass out (k_ddmc_all)
+      // (events of the pass: the running lanes, less those that sit it out below)
+      c_ev += (unsigned int)__popcll(__ballot(run));
+      if (const unsigned long long gm = __ballot(gl); gm != 0ull) {   // a leak through a block face: the particle sits this pass out (k_ddmc_all)
+        c_ev -= (unsigned int)__popcll(gm);
         const bool tab = gl && (cd & kCodeTable) != 0u;
         r_rec = tab ? cd & kCodeRecMask : r_rec;
         if constexpr (multi_d) r_pd = tab ? kPdZero : r_pd;
-        if constexpr (NDIM == 1) r_mir = (tab && (cd & kCodeMirror) != 0u) ? !r_mir : r_mir;
+        if constexpr (NDIM == 1) r_mir ^= (tab && (cd & kCodeMirror) != 0u) ? 1u : 0u;
         r_ls = (gl && !tab) ? DS_RELOC : r_ls;
       }
       const bool live = run && !ghost;
-      c_ev += (unsigned int)__popcll(__ballot(live));
       // transport_utils.hpp:184-191
       const double a2 = r.ffaa + r.leak_tot;
       const double cdf_ddmc = a2 + DBL_MIN;
@@ -622,7 +625,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       r_rng = live ? (leak ? s4 : (ev ? s2 : s1)) : r_rng;
       r_pzs = leak ? s2 : r_pzs;
       r_pd = leak ? delta : r_pd;
-      if constexpr (NDIM == 1) r_mir = r_mir && !leak;   // (a new leak: a new direction)
+      if constexpr (NDIM == 1) r_mir = leak ? 0u : r_mir;   // (a new leak: a new direction)
       if constexpr (NDIM == 3) r_rec = leak ? r_rec + (unsigned)delta : r_rec;
       else r_rec = (leak && delta != kPdStay) ? r_rec + (unsigned)delta : r_rec;
       r_ls = live ? ((ev && absorbed) ? DS_ABS : (done ? (ev ? DS_DONE : DS_CENSUS) : DS_VIRT)) : r_ls;
@@ -641,7 +644,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       }
       // the code of the cell every lane is in now, for the next pass (32-bit byte offset from a scalar base: the
       // codes of < 2^29 cells span < 2 GiB)
-      code = load_code(r_ls == DS_VIRT ? r_rec : 0u);
+      // (a lane without a running photon reads the code of the cell its last one was in: nobody looks at it)
+      code = load_code(r_rec);
       __builtin_amdgcn_sched_barrier(0);
       // leave the loop: a finished history found no room (the DONE queue is full: a whole batch for the service
       // phase), nothing runs, or lanes stand idle and there are photons to be loaded (at the tail of the launch:
@@ -672,15 +676,25 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       }
     }
   }
-  const unsigned long long r_census = c_census, r_abs = c_abs, r_esc = c_esc, r_out = c_out, r_ev = c_ev;
+  // the launch's counters: summed over the workgroup in LDS first (every wave of the launch ends at about the same
+  // time, and atomics on ONE line of device memory are served one after the other: 7 per wave were 28,000)
+  __shared__ unsigned long long lds_cnt[8];
+  __syncthreads();   // (the queues are dead: every wave is past its last pass)
+  if (threadIdx.x < 8) lds_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
   if (lane == 0) {
-    if (r_census) atomicAdd(&counters[CNT_CENSUS], r_census);
-    if (r_abs) atomicAdd(&counters[CNT_ABSORBED], r_abs);
-    if (r_esc) atomicAdd(&counters[CNT_ESCAPED], r_esc);
-    if (r_out) atomicAdd(&counters[CNT_OUTGOING], r_out);
-    if (r_ev) atomicAdd(&counters[CNT_EVENTS], r_ev);
-    atomicAdd(&counters[CNT_PASSES], (unsigned long long)c_pass);
-    atomicAdd(&counters[CNT_SERVICE], (unsigned long long)c_service);
+    if (c_census) atomicAdd(&lds_cnt[CNT_CENSUS], (unsigned long long)c_census);
+    if (c_abs) atomicAdd(&lds_cnt[CNT_ABSORBED], (unsigned long long)c_abs);
+    if (c_esc) atomicAdd(&lds_cnt[CNT_ESCAPED], (unsigned long long)c_esc);
+    if (c_out) atomicAdd(&lds_cnt[CNT_OUTGOING], (unsigned long long)c_out);
+    if (c_ev) atomicAdd(&lds_cnt[CNT_EVENTS], c_ev);
+    atomicAdd(&lds_cnt[CNT_PASSES], (unsigned long long)c_pass);
+    atomicAdd(&lds_cnt[CNT_SERVICE], (unsigned long long)c_service);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && threadIdx.x != CNT_UNFINISHED && lds_cnt[threadIdx.x] != 0ull)
+    atomicAdd(&counters[threadIdx.x], lds_cnt[threadIdx.x]);
+  if (lane == 0) {
 #ifdef JB_TIMING   // (the words jb_api.hip prints as "reloc claim done take real | episodes passes services": here
     // DONE batches, fills, event loop, - , - | loop entries, passes, batches)
     atomicAdd(&counters[24], cyc_ph[0] >> 10);
