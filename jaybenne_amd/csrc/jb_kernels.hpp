@@ -273,7 +273,16 @@ __global__ void __launch_bounds__(kBlock) k_face_prob(DevMesh M, DevParams P) {
 // finds a claimed slot waits for its publication (the writer waits for nobody).  Numbers beyond
 // max_classes are handed out but not stored: the host sees the count and keeps the 64-byte gather.
 // The numbering depends on who comes first; nothing downstream does.
-__device__ __forceinline__ int classify_step_record(const DevMesh &M, const double (&r)[8], int max_classes) {
+// Every look-up in the table is a chain of four reads that bypass the caches (count, slot, number, record) and two
+// cache invalidations (the acquire loads): ~8 us.  A wave therefore remembers the record it found last
+// (ClassLast, wave-uniform: scalar registers) and asks the table only about another one -- on a uniform mesh
+// once per wave and then at the faces of the block (k_ddmc_pack on 128^3 cells: 434 -> see DESIGN.md 4.2).
+struct ClassLast {
+  int w[16];
+  int id = -1;
+};
+
+__device__ __forceinline__ int classify_step_record(const DevMesh &M, const double (&r)[8], int max_classes, ClassLast &last) {
   int *const count = M.not_all_ddmc + 1;
   int cls = -1;
   unsigned long long todo = __ballot(true);
@@ -281,16 +290,26 @@ __device__ __forceinline__ int classify_step_record(const DevMesh &M, const doub
   while (todo != 0ull) {
     const int leader = __ffsll((long long)todo) - 1;
     bool same = true;
+    bool known = last.id >= 0;   // (wave-uniform)
+    int w[16];
     unsigned h = 0x9E3779B9u;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int lo = __builtin_amdgcn_readlane(__double2loint(r[q]), leader);
       const int hi = __builtin_amdgcn_readlane(__double2hiint(r[q]), leader);
       same = same && lo == __double2loint(r[q]) && hi == __double2hiint(r[q]);
+      known = known && lo == last.w[2 * q] && hi == last.w[2 * q + 1];
+      w[2 * q] = lo;
+      w[2 * q + 1] = hi;
       h = (h ^ (unsigned)lo) * 0x85EBCA6Bu;
       h = (h ^ (unsigned)hi) * 0xC2B2AE35u;
     }
     h ^= h >> 15;
+    if (known) {
+      cls = same ? last.id : cls;
+      todo &= ~__ballot(same);
+      continue;
+    }
     int found = -1;
     if (lane == leader) {
       if (*(volatile int *)count > max_classes) {
@@ -330,6 +349,11 @@ __device__ __forceinline__ int classify_step_record(const DevMesh &M, const doub
       }
     }
     found = __builtin_amdgcn_readlane(found, leader);
+    if (found < max_classes) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) last.w[q] = w[q];
+      last.id = found;
+    }
     cls = same ? found : cls;
     todo &= ~__ballot(same);
   }
@@ -340,6 +364,7 @@ template <int NDIM>
 __global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P, int max_classes) {
   constexpr bool multi_d = NDIM >= 2, three_d = NDIM == 3;
   const long long total = (long long)M.nblocks * M.ncell;
+  ClassLast last;
   for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
        c += (long long)gridDim.x * blockDim.x) {
     int b, k, j, i, cell;
@@ -386,7 +411,7 @@ __global__ void __launch_bounds__(kBlock) k_ddmc_pack(DevMesh M, DevParams P, in
       r[7] = m_rcp_refined(P.c * cdf_ddmc);
       if (M.ddmc_code != nullptr) {
         const double rec8[8] = {r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]};
-        M.ddmc_code[(long long)b * M.ntot + q] = (unsigned)classify_step_record(M, rec8, max_classes);
+        M.ddmc_code[(long long)b * M.ntot + q] = (unsigned)classify_step_record(M, rec8, max_classes, last);
       }
     }
   }
@@ -1680,26 +1705,61 @@ __global__ void __launch_bounds__(kBlock)
 //   0..8  x y z vx vy vz t w e   9 id   10 (ip | jp << 32)   11 (kp | gblock << 32)   12 rng state
 constexpr int kRecWords = 13;
 
+// Both kernels address the per-rank counters once per wave and destination rank, not once per photon: atomics on
+// one 128-byte line of device memory are served one after the other (~13 ns each with every XCD sending them:
+// DESIGN.md 4.2), and a rank of a spatially decomposed BASELINE configs[4] run hands over ~1.3e6 photons per
+// cycle.  for_each_destination: the lanes of the wave that hold an outgoing photon, grouped by the rank that owns
+// its block; f(rank, lanes of the group as a mask, this lane's place in the group) runs with the group's lanes.
+template <class F>
+__device__ __forceinline__ void for_each_destination(bool out, int r, F f) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(out);
+  while (todo != 0ull) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int rl = __builtin_amdgcn_readlane(r, leader);
+    const unsigned long long grp = __ballot(out && r == rl);
+    if (out && r == rl) f(rl, grp, __popcll(grp & ((1ull << lane) - 1ull)), lane == leader);
+    todo &= ~grp;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
     k_count_outgoing(DevMesh M, DevSwarm S, long long n_first, long long n_total,
                      unsigned long long *per_rank) {
-  for (long long n = n_first + (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
-       n += (long long)gridDim.x * blockDim.x)
-    if (S.status[n] == ST_OUTGOING || S.status[n] == ST_OUTGOING_ABSORBED)
-      atomicAdd(&per_rank[M.owner[S.blk[n]]], 1ull);
+  const int lane = threadIdx.x & 63;
+  // (wave-uniform trip count: every lane of the wave takes part in the grouping)
+  for (long long n0 = n_first + (long long)blockIdx.x * blockDim.x + (threadIdx.x - lane); n0 < n_total;
+       n0 += (long long)gridDim.x * blockDim.x) {
+    const long long n = n0 + lane;
+    const int st = n < n_total ? S.status[n] : ST_ABSORBED;
+    const bool out = st == ST_OUTGOING || st == ST_OUTGOING_ABSORBED;
+    const int r = out ? M.owner[S.blk[n]] : 0;
+    for_each_destination(out, r, [&](int rl, unsigned long long grp, int, bool first) {
+      if (first) atomicAdd(&per_rank[rl], (unsigned long long)__popcll(grp));
+    });
+  }
 }
 
 __global__ void __launch_bounds__(kBlock)
     k_pack_outgoing(DevMesh M, DevSwarm S, long long n_first, long long n_total,
                     const long long *rank_first, unsigned long long *rank_cursor, long long *rec) {
-  for (long long n = n_first + (long long)blockIdx.x * blockDim.x + threadIdx.x; n < n_total;
-       n += (long long)gridDim.x * blockDim.x) {
-    const int st = S.status[n];
-    if (st != ST_OUTGOING && st != ST_OUTGOING_ABSORBED) continue;
+  const int lane = threadIdx.x & 63;
+  for (long long n0 = n_first + (long long)blockIdx.x * blockDim.x + (threadIdx.x - lane); n0 < n_total;
+       n0 += (long long)gridDim.x * blockDim.x) {
+    const long long n = n0 + lane;
+    const int st = n < n_total ? S.status[n] : ST_ABSORBED;
+    const bool out = st == ST_OUTGOING || st == ST_OUTGOING_ABSORBED;
+    const int g = out ? S.blk[n] : 0;
+    const int r = out ? M.owner[g] : 0;
+    long long slot = -1;
+    for_each_destination(out, r, [&](int rl, unsigned long long grp, int place, bool first) {
+      unsigned long long base = 0ull;
+      if (first) base = atomicAdd(&rank_cursor[rl], (unsigned long long)__popcll(grp));
+      base = __shfl(base, __ffsll((long long)grp) - 1, 64);
+      slot = rank_first[rl] + (long long)base + place;
+    });
+    if (!out) continue;
     S.status[n] = ST_ABSORBED;  // the slot is a hole from now on (removed by the next compaction)
-    const int g = S.blk[n];
-    const int r = M.owner[g];
-    const long long slot = rank_first[r] + (long long)atomicAdd(&rank_cursor[r], 1ull);
     long long *o = rec + slot * kRecWords;
     o[0] = __double_as_longlong(S.x[n]); o[1] = __double_as_longlong(S.y[n]);
     o[2] = __double_as_longlong(S.z[n]); o[3] = __double_as_longlong(S.vx[n]);
