@@ -933,7 +933,10 @@ static jb_status launch_transport(jb_context *ctx, jb_mesh *mesh, const DevSwarm
         const bool codes = queues || (codes_ok && (ctx->coop_gather == 4 || (ctx->coop_gather < 0 && !in_lds)));
         const int gather = codes ? 4 : (coop ? (wide ? 3 : 1) : (in_lds ? 2 : 0));
         // ... the codes themselves in LDS on a mesh of at most kLdsCodeCells cells (JB_DDMC_LDS_CODES=0: not)
-        const bool lcodes = queues && ctx->ddmc_lds_codes && (long long)M.nblocks * M.ntot <= (long long)kLdsCodeCells;
+        // (and at most 64 classes: tally 8 KB + classes 4 KB + codes 4 KB + 37.7 KB static stay under the 64 KB a
+        // workgroup may have; with up to kMaxClasses = 256 records, 16 KB, the codes would not fit beside them)
+        const bool lcodes = queues && ctx->ddmc_lds_codes && (long long)M.nblocks * M.ntot <= (long long)kLdsCodeCells &&
+                            mesh->nclass_host <= 64;
         // A particle that sits at a face of its cell when it is loaded or relocated (one in ~1e8) needs
         // the albedo step: k_ddmc_all lists it, and k_hybrid<.., both loops>, launched behind it on
         // that list (its length read on the device: no synchronisation), tracks it to the end.

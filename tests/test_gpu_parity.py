@@ -418,6 +418,35 @@ def test_cell_codes_on_all_ddmc_meshes(gpu_device, deck, overrides, cycles, mode
     assert drv.md.events == O.events
 
 
+def test_small_mesh_with_a_step_record_of_its_own_in_every_cell(gpu_device, monkeypatch):
+    """The 1-D all-DDMC deck with a density that differs from cell to cell: 128 distinct step records on 136
+    cells.  k_ddmc_q keeps the class records in LDS (<= 256) but not the codes beside them (<= 64 classes: the
+    64 KB of LDS a workgroup may have), i.e. runs the gathered form on a mesh that would otherwise take the LDS
+    one; same bits as the oracle."""
+    from oracle import orc
+    monkeypatch.delenv("JB_COOP_GATHER", raising=False)
+    deck, ov = "stepdiff_ddmc", {"jaybenne/num_particles": 20000}
+    pin = load_deck(deck, ov)
+    drv = _gpu_problem(pin, gpu_device)
+    O, mesh, _ = make_oracle(load_deck(deck, ov), orc.MATH_PORTABLE)
+    rho = O.fields["rho"]
+    rho *= 1.0 + 0.003 * np.arange(rho.shape[-1])[None, None, None, :]   # (denser only: every cell stays DDMC)
+    O.fields["u"][...] = rho * O.fields["sie"]
+    drv.md.set_field("rho", rho)
+    drv.md.set_field("u", O.fields["u"])
+    for _ in range(2):
+        drv.Step()
+    run_oracle_cycles(O, pin, 2)
+    variant = drv.md.lib.jb_last_transport_variant(drv.md.handle).decode()
+    nclass = drv.md.lib.jb_mesh_ddmc_classes(drv.md.handle)
+    assert 64 < nclass <= 256, nclass
+    assert variant == "TransportPhotons_DDMC: k_ddmc_all<1, true, cell codes, queues>" or \
+        variant.endswith("k_ddmc_all<1, true, cell codes, queues>"), variant
+    _compare_swarm(drv.md, O)
+    _compare_fields(drv.md, O)
+    assert drv.md.events == O.events
+
+
 @pytest.mark.parametrize("coop", ["0", "1", "2", "4", "lds", "queues", "queues-1d", "queues-1d-gathered"])
 def test_all_ddmc_photons_sitting_at_cell_faces_are_handed_to_the_general_kernel(gpu_device, coop, monkeypatch):
     """k_ddmc_all's event loop starts every step from the cell centre, which is what the albedo
