@@ -287,7 +287,8 @@ int jb_get_arithmetic(const jb_context *ctx);
  * ", records in LDS" when the mesh has at most 256 cells and the kernel keeps them in LDS,
  * ", cell codes" when the mesh has at most 256 DISTINCT step records: jb_mesh_ddmc_classes -- and
  * ", cell codes, queues" when, with at most 64 resident blocks, the wave's photons are also staged
- * through queues in LDS: k_ddmc_q, the default on such meshes);
+ * through queues in LDS: k_ddmc_q, the default on such meshes; ", codes in LDS" behind that when the
+ * mesh has at most 1024 cells and 64 distinct records and the codes sit in LDS too);
  * "k_hybrid<2, lean, exact geometry>" on a mesh that mixes IMC and DDMC cells (three launches: IMC
  * phase, DDMC phase, remainder); "" before the first launch.  jb_mesh_exact_geometry: 1 if every
  * resident block has power-of-two cell widths and a lower corner that is a whole number of them
