@@ -65,7 +65,17 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
   const double t_start = A.t_start, dt = A.dt;
   const long long first = A.first, last = A.last;
   unsigned long long *const counters = g1(A.counters);
-  constexpr bool NT = JB_DDMC_NT != 0;   // non-temporal swarm accesses (see swarm_ld)
+  // non-temporal swarm accesses (see swarm_ld): on a large mesh they keep the particle stream from pushing the
+  // cell codes out of L2 (C3: 17.4 against 18.2 ms); on a mesh whose codes sit in LDS nothing competes with the
+  // stream, and the hint costs time at the same traffic (the 1-D deck: 7.38 against 7.06 ms, 4.4 + 13.8 GB either way)
+#ifndef JB_DDMC_Q_NT_LD_SMALL   // (A/B: loads / stores apart)
+#define JB_DDMC_Q_NT_LD_SMALL 0
+#endif
+#ifndef JB_DDMC_Q_NT_ST_SMALL
+#define JB_DDMC_Q_NT_ST_SMALL 0
+#endif
+  constexpr bool NT_LD = JB_DDMC_NT != 0 && (!LCODES || JB_DDMC_Q_NT_LD_SMALL != 0);
+  constexpr bool NT_ST = JB_DDMC_NT != 0 && (!LCODES || JB_DDMC_Q_NT_ST_SMALL != 0);
   constexpr bool multi_d = NDIM >= 2;
   constexpr int kRetireMin = NDIM == 1 ? 1 : JB_DDMC_Q_RETIRE_MIN;
   typedef double v4d __attribute__((ext_vector_type(4)));
@@ -307,7 +317,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           resample = ls == DS_CENSUS;
           if (ls == DS_ABS) {  // transport.cpp:157-163
             if (lds_blocks.owned[b] != 0) {
-              atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], swarm_ld<NT>(&g1(S.w)[n]));
+              atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], swarm_ld<NT_LD>(&g1(S.w)[n]));
               status = ST_ABSORBED;
             } else {
               status = ST_OUTGOING_ABSORBED;
@@ -348,11 +358,11 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           const bool mine = ((need >> lane) & 1ull) != 0ull && rank < give;
           if (mine) {
             cand = chunk_pos + rank;
-            st_in = swarm_ld<NT>(&g1(S.status)[cand]);
-            rng_in = swarm_ld<NT>(&g1(S.rng)[cand]);
-            b_in = swarm_ld<NT>(&g1(S.blk)[cand]);
-            t_in = swarm_ld<NT>(&g1(S.t)[cand]); x_in = swarm_ld<NT>(&g1(S.x)[cand]); y_in = swarm_ld<NT>(&g1(S.y)[cand]); z_in = swarm_ld<NT>(&g1(S.z)[cand]);
-            vx_in = swarm_ld<NT>(&g1(S.vx)[cand]); vy_in = swarm_ld<NT>(&g1(S.vy)[cand]); vz_in = swarm_ld<NT>(&g1(S.vz)[cand]);
+            st_in = swarm_ld<NT_LD>(&g1(S.status)[cand]);
+            rng_in = swarm_ld<NT_LD>(&g1(S.rng)[cand]);
+            b_in = swarm_ld<NT_LD>(&g1(S.blk)[cand]);
+            t_in = swarm_ld<NT_LD>(&g1(S.t)[cand]); x_in = swarm_ld<NT_LD>(&g1(S.x)[cand]); y_in = swarm_ld<NT_LD>(&g1(S.y)[cand]); z_in = swarm_ld<NT_LD>(&g1(S.z)[cand]);
+            vx_in = swarm_ld<NT_LD>(&g1(S.vx)[cand]); vy_in = swarm_ld<NT_LD>(&g1(S.vy)[cand]); vz_in = swarm_ld<NT_LD>(&g1(S.vz)[cand]);
           }
           chunk_pos += give;
           need &= ~__ballot(mine);
@@ -428,7 +438,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
             if (t < t_end) {
               enter(Bn);
               if (ls == DS_VIRT) {  // (the loop does not carry the direction: park it)
-                swarm_st<NT>(&g1(S.vx)[n], vx); swarm_st<NT>(&g1(S.vy)[n], vy); swarm_st<NT>(&g1(S.vz)[n], vz);
+                swarm_st<NT_ST>(&g1(S.vx)[n], vx); swarm_st<NT_ST>(&g1(S.vy)[n], vy); swarm_st<NT_ST>(&g1(S.vz)[n], vz);
               }
             } else {
               ls = DS_DONE;
@@ -480,7 +490,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
             if constexpr (TALLY) {  // jaybenne.cpp:547-561
               const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
 #ifndef JB_DDMC_EXP_NOTALLY      // (timing experiment: results are wrong)
-              const double wgt = swarm_ld<NT>(&g1(S.w)[n]);
+              const double wgt = swarm_ld<NT_LD>(&g1(S.w)[n]);
               if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
               else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], wgt / dv);
 #else
@@ -489,15 +499,15 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
             }
           }
         }
-        swarm_st<NT>(&g1(S.blk)[n], b);
-        swarm_st<NT>(&g1(S.t)[n], t);
-        swarm_st<NT>(&g1(S.x)[n], x); swarm_st<NT>(&g1(S.y)[n], y); swarm_st<NT>(&g1(S.z)[n], z);
+        swarm_st<NT_ST>(&g1(S.blk)[n], b);
+        swarm_st<NT_ST>(&g1(S.t)[n], t);
+        swarm_st<NT_ST>(&g1(S.x)[n], x); swarm_st<NT_ST>(&g1(S.y)[n], y); swarm_st<NT_ST>(&g1(S.z)[n], z);
         if (write_v) {
-          swarm_st<NT>(&g1(S.vx)[n], vx); swarm_st<NT>(&g1(S.vy)[n], vy); swarm_st<NT>(&g1(S.vz)[n], vz);
+          swarm_st<NT_ST>(&g1(S.vx)[n], vx); swarm_st<NT_ST>(&g1(S.vy)[n], vy); swarm_st<NT_ST>(&g1(S.vz)[n], vz);
         }
-        swarm_st<NT>(&g1(S.ip)[n], ip); swarm_st<NT>(&g1(S.jp)[n], jp); swarm_st<NT>(&g1(S.kp)[n], kp);
-        swarm_st<NT>(&g1(S.status)[n], status);
-        swarm_st<NT>(&g1(S.rng)[n], rng.s);
+        swarm_st<NT_ST>(&g1(S.ip)[n], ip); swarm_st<NT_ST>(&g1(S.jp)[n], jp); swarm_st<NT_ST>(&g1(S.kp)[n], kp);
+        swarm_st<NT_ST>(&g1(S.status)[n], status);
+        swarm_st<NT_ST>(&g1(S.rng)[n], rng.s);
         ls = DS_IDLE;
       }
       {
@@ -512,11 +522,11 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
       //      as it stands
       if (ls == DS_PARK) {
         if (!fresh) {
-          swarm_st<NT>(&g1(S.blk)[n], b);
-          swarm_st<NT>(&g1(S.t)[n], t);
-          swarm_st<NT>(&g1(S.x)[n], x); swarm_st<NT>(&g1(S.y)[n], y); swarm_st<NT>(&g1(S.z)[n], z);
-          swarm_st<NT>(&g1(S.vx)[n], vx); swarm_st<NT>(&g1(S.vy)[n], vy); swarm_st<NT>(&g1(S.vz)[n], vz);
-          swarm_st<NT>(&g1(S.rng)[n], rng.s);
+          swarm_st<NT_ST>(&g1(S.blk)[n], b);
+          swarm_st<NT_ST>(&g1(S.t)[n], t);
+          swarm_st<NT_ST>(&g1(S.x)[n], x); swarm_st<NT_ST>(&g1(S.y)[n], y); swarm_st<NT_ST>(&g1(S.z)[n], z);
+          swarm_st<NT_ST>(&g1(S.vx)[n], vx); swarm_st<NT_ST>(&g1(S.vy)[n], vy); swarm_st<NT_ST>(&g1(S.vz)[n], vz);
+          swarm_st<NT_ST>(&g1(S.rng)[n], rng.s);
         }
         const unsigned long long pm = __ballot(true);
         const int leader = __ffsll((long long)pm) - 1;
