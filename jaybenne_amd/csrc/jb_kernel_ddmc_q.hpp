@@ -287,6 +287,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         rec = face ? rec : (unsigned)b * ntot_u + (unsigned)cidx_l(kp, jp, ip);
         mir = face && mir;
       };
+      double wgt_done = 0.0;
       if (phase == 0) {
         // ---- the DONE queue: block, cell indices and leak channel of every entry from its record number and
         //      record-number step
@@ -303,6 +304,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           const int fl = (int)(unsigned)(pf >> 32);
           ls = fl & 7;
           mir = (fl & 8) != 0;
+          // (the weight, for the tally or the absorption: asked for now, needed after the decode and the resampling)
+          wgt_done = swarm_ld<NT_LD>(&g1(S.w)[n]);
         }
         done_cnt = 0;
         if (ls != DS_IDLE) {
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           resample = ls == DS_CENSUS;
           if (ls == DS_ABS) {  // transport.cpp:157-163
             if (lds_blocks.owned[b] != 0) {
-              atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], swarm_ld<NT_LD>(&g1(S.w)[n]));
+              atomicAdd(&M.edelta[b][cidx_l(kp, jp, ip)], wgt_done);
               status = ST_ABSORBED;
             } else {
               status = ST_OUTGOING_ABSORBED;
@@ -490,7 +493,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
             if constexpr (TALLY) {  // jaybenne.cpp:547-561
               const double dv = Bd.dx[0] * Bd.dx[1] * Bd.dx[2];
 #ifndef JB_DDMC_EXP_NOTALLY      // (timing experiment: results are wrong)
-              const double wgt = swarm_ld<NT_LD>(&g1(S.w)[n]);
+              // (a photon that was at census when it was loaded comes through the fill, not the DONE queue)
+              const double wgt = phase == 0 ? wgt_done : swarm_ld<NT_LD>(&g1(S.w)[n]);
               if (tally_in_lds) atomicAdd(&lds_tally[b * (int)M.ntot + cidx(M, kp, jp, ip)], wgt / dv);
               else atomicAdd(&lds_blocks.tally[b][cidx(M, kp, jp, ip)], wgt / dv);
 #else
@@ -506,7 +510,8 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
           swarm_st<NT_ST>(&g1(S.vx)[n], vx); swarm_st<NT_ST>(&g1(S.vy)[n], vy); swarm_st<NT_ST>(&g1(S.vz)[n], vz);
         }
         swarm_st<NT_ST>(&g1(S.ip)[n], ip); swarm_st<NT_ST>(&g1(S.jp)[n], jp); swarm_st<NT_ST>(&g1(S.kp)[n], kp);
-        swarm_st<NT_ST>(&g1(S.status)[n], status);
+        // (loaded as ST_ACTIVE -- nothing else is tracked --: a photon that reaches census keeps its status word)
+        if (status != ST_ACTIVE) swarm_st<NT_ST>(&g1(S.status)[n], status);
         swarm_st<NT_ST>(&g1(S.rng)[n], rng.s);
         ls = DS_IDLE;
       }
