@@ -122,6 +122,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
   bool more = true;
   long long chunk_pos = 0, chunk_end = 0;
   int ready_cnt = 0, done_cnt = 0;   // (wave-uniform)
+#ifdef JB_DDMC_EXP_SEQSTORE
+  long long exp_wr_cur = 0, exp_wr_end = 0;
+#endif
 
   unsigned int c_census = 0, c_abs = 0, c_esc = 0, c_out = 0;
   unsigned long long c_ev = 0;
@@ -347,6 +350,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
             if (lane == 0) base = atomicAdd(&queue[cur * kQueueStride], (unsigned long long)kChunk);
             chunk_pos = q_first + (long long)uniform_u64(base);
             chunk_end = chunk_pos + kChunk < q_last ? chunk_pos + kChunk : q_last;
+#ifdef JB_DDMC_EXP_SEQSTORE   // (timing experiment: results are wrong)
+            if (exp_wr_cur >= exp_wr_end && chunk_pos < q_last) { exp_wr_cur = chunk_pos; exp_wr_end = chunk_end; }
+#endif
             if (chunk_pos >= q_last) {  // this queue is drained: move on
               chunk_pos = chunk_end = 0;
               cur = (cur + 1) % kQueues;
@@ -503,6 +509,12 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
             }
           }
         }
+#ifdef JB_DDMC_EXP_SEQSTORE
+        if (phase == 0) {
+          if (exp_wr_cur + 64 > exp_wr_end) exp_wr_cur = exp_wr_end - 64 > first ? exp_wr_end - 64 : first;
+          n = exp_wr_cur + lane;
+        }
+#endif
         swarm_st<NT_ST>(&g1(S.blk)[n], b);
         swarm_st<NT_ST>(&g1(S.t)[n], t);
         swarm_st<NT_ST>(&g1(S.x)[n], x); swarm_st<NT_ST>(&g1(S.y)[n], y); swarm_st<NT_ST>(&g1(S.z)[n], z);
@@ -515,6 +527,9 @@ __global__ void __launch_bounds__(kBlock, JB_DDMC_ALL_WAVES_PER_SIMD)
         swarm_st<NT_ST>(&g1(S.rng)[n], rng.s);
         ls = DS_IDLE;
       }
+#ifdef JB_DDMC_EXP_SEQSTORE
+      if (phase == 0) exp_wr_cur += 64;
+#endif
       {
         const int n_done = __popcll(__ballot(was_done));
         const int n_census = __popcll(__ballot(was_done && status == ST_ACTIVE));
