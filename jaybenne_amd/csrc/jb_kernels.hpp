@@ -318,7 +318,11 @@ __device__ __forceinline__ int classify_step_record(const DevMesh &M, const doub
         unsigned slot = h % (unsigned)kClassSlots;
         for (int probe = 0; probe < kClassSlots && found < 0; ++probe, slot = (slot + 1u) % (unsigned)kClassSlots) {
           int *const st = M.ddmc_class_slot + 2 * slot;
-          int s = __hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          // (relaxed, not acquire: an agent-scope acquire is a load + an invalidation of the XCD's whole L2 -- thousands
+          // of them while every other wave of the launch streams the cell data through it.  What is read behind the
+          // flag is read past the caches (volatile: sc0 sc1), and only after the flag has been seen -- the branch on
+          // it stands between the two --, so the writer's release (write-back, then the flag) is all that is needed)
+          int s = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (s == 0) s = atomicCAS(st, 0, 1);
           if (s == 0) {           // ours: number it, store it, publish it
             const int id = atomicAdd(count, 1);
@@ -331,7 +335,7 @@ __device__ __forceinline__ int classify_step_record(const DevMesh &M, const doub
             found = id < max_classes ? id : max_classes;
             break;
           }
-          while (s == 1) s = __hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          while (s == 1) s = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int id = ((volatile int *)st)[1];
           if (id >= max_classes) { found = max_classes; break; }
           bool eq = true;
